@@ -1,0 +1,105 @@
+"""Synthetic problem-instance generators for the benchmark configurations.
+
+Every instance is built exactly the way the reference builds one receding-horizon step after
+a (re)plan: a 2-via-point ReferencePath from the start pose to the goal pose
+(boundplanner_with_mpc_example.py:129-135 conventions: br1 seed (0,0,1), e_r_bound +-90 deg),
+BoundMPC.update() state seeding (BoundMPC.py:271-336), then BoundMPC.step() preparation
+(BoundMPC.py:388-589) -> (x0, lbx, ubx, p).
+
+  config 2: fixed sets   -- EE set = workspace box [-1,-1,0]-[1,1,1.2] (BoundPlanner.py:32-33),
+                            collision sets = 0.7 m boxes around each collision point
+  config 3: as config 2 + K~U{3..9} random unit-normal halfspaces per set
+"""
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+from .bound_mpc import BoundMPC
+from .params import (COL_JOINT_SIZES, Params, Q_LIM_LOWER, Q_LIM_UPPER, get_default_params,
+                     normalize_set_size)
+
+
+def _box_set(lo, hi):
+    a = np.vstack((np.eye(3), -np.eye(3)))
+    b = np.concatenate((np.asarray(hi, float), -np.asarray(lo, float)))
+    return a, b
+
+
+def _rand_unit(rng):
+    v = rng.normal(size=3)
+    return v / np.linalg.norm(v)
+
+
+def sample_start_goal(rng, fk_batch, n):
+    """q_start, q_goal ~ U(0.5 q_lo, 0.5 q_hi); reject collision points below z=0.05 or
+    start/goal closer than 0.1 m."""
+    qs, qg = [], []
+    while len(qs) < n:
+        m = max(64, 2 * (n - len(qs)))
+        a = rng.uniform(0.5 * Q_LIM_LOWER, 0.5 * Q_LIM_UPPER, size=(m, 7))
+        b = rng.uniform(0.5 * Q_LIM_LOWER, 0.5 * Q_LIM_UPPER, size=(m, 7))
+        fa, fb = fk_batch(a), fk_batch(b)
+        ok = (fa["col_pts"][:, :, 2].min(axis=1) >= 0.05) & (fb["col_pts"][:, :, 2].min(axis=1) >= 0.05)
+        ok &= (fa["ee_pos"][:, 2] >= 0.05) & (fb["ee_pos"][:, 2] >= 0.05)
+        ok &= np.linalg.norm(fa["ee_pos"] - fb["ee_pos"], axis=1) >= 0.1
+        for i in np.nonzero(ok)[0]:
+            if len(qs) < n:
+                qs.append(a[i]); qg.append(b[i])
+    return np.array(qs), np.array(qg)
+
+
+def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1):
+    """Returns dict with x0, lbx, ubx, p ([B, n] float64, row-major per instance) + the state
+    needed to drive closed loops."""
+    rng = np.random.default_rng(seed)
+    base = get_default_params()
+    prm = Params(n=N, dt=dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    q_start, q_goal = sample_start_goal(rng, fk_batch, B)
+    fs, fg = fk_batch(q_start), fk_batch(q_goal)
+    n_w = 44 * N + 6
+    out = {k: np.zeros((B, n_w)) for k in ("x0", "lbx", "ubx")}
+    out["p"] = np.zeros((B, 875))
+    out["q_start"], out["q_goal"] = q_start, q_goal
+    out["mpcs"] = []
+    ws_lo, ws_hi = [-1.0, -1.0, 0.0], [1.0, 1.0, 1.2]
+    for b in range(B):
+        p0 = np.concatenate((fs["ee_pos"][b], R.from_matrix(fs["ee_rot"][b]).as_rotvec()))
+        p1 = fg["ee_pos"][b]
+        a_ee, b_ee = _box_set(ws_lo, ws_hi)
+        if randomize_sets:
+            k = rng.integers(3, 10)
+            rows_a, rows_b = [], []
+            while len(rows_a) < k:
+                a = _rand_unit(rng)
+                d = rng.uniform(0.05, 0.4)
+                bb = a @ p0[:3] + d
+                if a @ p1 <= bb:       # both path ends must satisfy the row
+                    rows_a.append(a); rows_b.append(bb)
+            a_ee = np.vstack((a_ee, rows_a)); b_ee = np.concatenate((b_ee, rows_b))
+        sets = normalize_set_size([[a_ee, b_ee]], 15)
+        mpc = BoundMPC([p0[:3].copy(), p0[:3].copy()],
+                       [fs["ee_rot"][b].copy(), fs["ee_rot"][b].copy()],
+                       [np.array([1.0, 0.0, 0.0])], [np.array([1.0, 0.0, 0.0])],
+                       [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180],
+                       [np.zeros((15, 3))], [np.ones(15)], [], p0=p0, params=prm)
+        mpc.update([p0[:3].copy(), p1.copy()], [fs["ee_rot"][b].copy(), fg["ee_rot"][b].copy()],
+                   [np.array([0.0, 0.0, 1.0])], [np.array([0.0, 0.0, 1.0])],
+                   [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180],
+                   [sets[0][0]], [sets[0][1]], [], np.zeros(6), p0=p0, params=prm)
+        col0 = fs["col_pts"][b]
+        w0, lbx, ubx, p, _ = mpc.prepare(q_start[b], np.zeros(7), np.zeros(7), p0, np.zeros(6),
+                                         np.zeros(7), q_start[b], col_pts0=col0, col_ptsf=col0)
+        if randomize_sets:
+            # extra random halfspaces on the 6 collision sets, appended after the 6 box rows
+            aj = p[515:785].reshape(6, 3, 15).transpose(0, 2, 1).copy()   # [pt][row][c]
+            bj = p[785:875].reshape(15, 6).T.copy()                       # [pt][row]
+            for i in range(6):
+                k = rng.integers(3, 10)
+                for r in range(6, 6 + k):
+                    a = _rand_unit(rng)
+                    aj[i, r] = a
+                    bj[i, r] = a @ col0[i] + rng.uniform(0.05, 0.4) - COL_JOINT_SIZES[i]
+            p[515:785] = aj.transpose(0, 2, 1).reshape(-1)
+            p[785:875] = bj.T.reshape(-1)
+        out["x0"][b], out["lbx"][b], out["ubx"][b], out["p"][b] = w0, lbx, ubx, p
+        out["mpcs"].append(mpc)
+    return out

@@ -34,6 +34,10 @@ typedef struct {
     double tol;       /* IPOPT tol, BoundMPC.py:203 (10e-6 = 1e-5) */
     int max_iter;     /* BoundMPC.py:204 */
     int verbose;
+    int hess;         /* 0 Gauss-Newton Hessian, 1 + second-order kinematic terms (default) */
+    int mu_strategy;  /* 0 LOQO adaptive, 1 monotone Fiacco-McCormick */
+    double hess_switch; /* hess==2: use second-order terms once the KKT error is below this */
+    double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule (IPOPT names) */
 } bmpc_oracle_opts;
 
 void bmpc_oracle_default_opts(bmpc_oracle_opts* o, int N);
