@@ -1,0 +1,12 @@
+// Platform bindings of the device code for gfx950 (HIP).  The device code in bmpc_device.hpp is
+// written against these few names so that tests/emu can run the identical source on CPU threads
+// for debugging (test infrastructure only; the product always compiles this header with hipcc).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define BMPC_DEV __device__
+#define BMPC_INL __device__ __forceinline__
+#define BMPC_SYNC() __syncthreads()
+#define BMPC_LANE() ((int)threadIdx.x)
+#define BMPC_BLOCK() ((int)blockIdx.x)
+#define BMPC_NBLOCKS() ((int)gridDim.x)

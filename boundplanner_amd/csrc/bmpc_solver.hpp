@@ -1,0 +1,830 @@
+// bmpc_solver.hpp -- the per-instance interior-point loop (device code, one wavefront).
+// Algorithm and notation: oracle/bmpc_solve.c (same steps, same constants); layout: DESIGN.md.
+#pragma once
+#include "bmpc_device.hpp"
+
+namespace bmpc {
+
+struct KktAcc {   // per-lane partial sums carried across a sweep
+    double cmax, csum, cmin, zsum, prim, theta, logs, lamsum, dual;
+    int nrows;
+};
+struct Kkt {
+    double err, dual, prim, compl_, sd, sc, f, theta, avgc, minc, logs, cmu;
+    int nrows;
+};
+
+struct WsPtr {
+    double *zeta, *dz, *zsave, *t, *z, *dt, *dzr, *tsave, *K, *kf;
+};
+BMPC_INL void ws_carve(double* b, int N, WsPtr& w) {
+    w.zeta = b; b += N * ZPAD; w.dz = b; b += N * ZPAD; w.zsave = b; b += N * ZPAD;
+    w.t = b; b += N * NSLOT; w.z = b; b += N * NSLOT; w.dt = b; b += N * NSLOT;
+    w.dzr = b; b += N * NSLOT; w.tsave = b; b += N * NSLOT;
+    w.K = b; b += N * NU * NX; w.kf = b;
+}
+
+// dynamics defect of stage k (needs zeta_k in L.zeta, zeta_{k+1} in L.znext, v in rc)
+BMPC_INL double defect_row(const Lds& L, const DynC& d, int i) {
+    const double* z = L.zeta;
+    double v;
+    if (i < Z_DQ) v = z[i] + d.dt * z[i + 7] + 0.5 * d.dt * d.dt * z[i + 14] + d.b3 * z[Z_U + i];
+    else if (i < Z_DDQ) v = z[i] + d.dt * z[i + 7] + d.b2 * z[Z_U + i - 7];
+    else if (i < Z_PI) v = z[i] + d.b1 * z[Z_U + i - 14];
+    else if (i < Z_RS) v = z[i] + d.dt * L.rc[RC_V + 3 + (i - Z_PI)];
+    else if (i == Z_RS) v = z[i] + d.dt * z[Z_DRS];
+    else if (i == Z_PS) v = z[i] + d.dt * z[Z_DPS];
+    else v = z[i];
+    return v - L.znext[i];
+}
+
+// 9x9 Cholesky in registers (every lane redundantly); returns false when not positive definite
+BMPC_DEV bool chol9(const double* W, double reg, double* Lc /*45 packed lower*/) {
+    bool ok = true;
+#define LI(i, j) Lc[(i) * ((i) + 1) / 2 + (j)]
+    for (int j = 0; j < NU; j++) {
+        double d = W[(NX + j) * LDW + NX + j] + reg;
+        for (int l = 0; l < j; l++) d -= LI(j, l) * LI(j, l);
+        if (!(d > 0)) { ok = false; d = 1.0; }
+        d = sqrt(d);
+        LI(j, j) = d;
+        for (int i = j + 1; i < NU; i++) {
+            double s = W[(NX + i) * LDW + NX + j];
+            for (int l = 0; l < j; l++) s -= LI(i, l) * LI(j, l);
+            LI(i, j) = s / d;
+        }
+    }
+    return ok;
+}
+BMPC_DEV void chol9_solve(const double* Lc, double* b) {
+    for (int i = 0; i < NU; i++) {
+        double s = b[i];
+        for (int l = 0; l < i; l++) s -= LI(i, l) * b[l];
+        b[i] = s / LI(i, i);
+    }
+    for (int i = NU - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int l = i + 1; l < NU; l++) s -= LI(l, i) * b[l];
+        b[i] = s / LI(i, i);
+    }
+#undef LI
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward sweep: evaluation + KKT error + adjoint multipliers + Riccati factorisation with
+// two right-hand sides (g = g0 + mu g1).  Returns false if a control block is not PD.
+// ------------------------------------------------------------------------------------------
+BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
+                             double ad_pend, const double* iw0, double reg, double hreg, Kkt& kk) {
+    const int N = A.o.N;
+    const double* sp = L.sp;
+    const double* wts = sp + P_W;
+    KktAcc ac;
+    ac.cmax = 0; ac.csum = 0; ac.cmin = 1e300; ac.zsum = 0; ac.prim = 0; ac.theta = 0; ac.logs = 0;
+    ac.lamsum = 0; ac.dual = 0; ac.nrows = 0;
+    double fsum = 0;
+    bool ok = true;
+    if (lane < NX) { L.lam[lane] = 0; L.pv0[lane] = 0; L.pv1[lane] = 0; }
+    StageEval E;
+    for (int k = N - 1; k >= 1; k--) {
+        const bool term = (k == N - 1);
+        if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
+        for (int e = lane; e < NZ * LDW; e += 64) L.W[e] = (e / LDW == e % LDW) ? hreg : 0.0;
+        if (lane < ZPAD) { L.g0[lane] = 0; L.g1[lane] = 0; L.gz[lane] = 0; }
+        BMPC_SYNC();
+        stage_eval(A, L, dc, k, lane, true, iw0, E);
+        fsum += E.fval;
+        // ---- rows: slack/multiplier data, KKT partial sums ----
+        for (int m = 0; m < 4; m++) {
+            int s = lane + 64 * m;
+            if (s >= NSLOT) break;
+            Row r;
+            row_eval(A, L, b, k, s, r);
+            double sg = 0, r0 = 0, r1 = 0, zz = 0;
+            if (r.kind) {
+                double t = ws.t[k * NSLOT + s];
+                zz = ws.z[k * NSLOT + s];
+                if (ad_pend != 0.0) { zz += ad_pend * ws.dzr[k * NSLOT + s]; ws.z[k * NSLOT + s] = zz; }
+                sg = zz / t; r0 = sg * (r.h + t); r1 = 1.0 / t;
+                double c = t * zz;
+                ac.cmax = fmax(ac.cmax, c); ac.csum += c; ac.cmin = fmin(ac.cmin, c); ac.zsum += zz;
+                ac.prim = fmax(ac.prim, fabs(r.h + t)); ac.theta += fabs(r.h + t); ac.logs += log(t);
+                ac.nrows++;
+            }
+            L.rowS[s] = sg; L.rowS[NSLOT + s] = r0; L.rowS[2 * NSLOT + s] = r1; L.rowS[3 * NSLOT + s] = zz;
+            int pr = pose_row_index(s);
+            if (pr >= 0) {
+                for (int c = 0; c < 6; c++) L.rowA[pr * 6 + c] = r.a[c];
+                L.rowSl[pr] = (r.kind == 3) ? (double)r.sel : -1.0;
+            }
+        }
+        BMPC_SYNC();
+        // ---- group accumulations (one output per lane, serial over rows) ----
+        {
+            const int slot_of_pr[3] = {S_EE, S_PHI - 21, S_TSET - 22};
+            for (int o = lane; o < 69; o += 64) {
+                // outputs: 0..20 M6 (sym), 21..38 mS[3][6], 39..41 sS, 42..59 b{0,1,z}[6], 60..68 bS{0,1,z}[3]
+                double acc = 0;
+                int ia = 0, ib = 0, sel = 0, vecsel = 0;
+                if (o < 21) { int e = o, i = 0; while (e >= 6 - i) { e -= 6 - i; i++; } ia = i; ib = i + e; }
+                else if (o < 39) { sel = (o - 21) / 6 + 1; ia = (o - 21) % 6; }
+                else if (o < 42) { sel = o - 39 + 1; }
+                else if (o < 60) { vecsel = (o - 42) / 6; ia = (o - 42) % 6; }
+                else { vecsel = (o - 60) / 3; sel = (o - 60) % 3 + 1; }
+                for (int pr = 0; pr < NPOSE; pr++) {
+                    double rsel = L.rowSl[pr];
+                    if (rsel < 0) continue;
+                    int s = pr + (pr < 21 ? slot_of_pr[0] : (pr == 21 ? slot_of_pr[1] : slot_of_pr[2]));
+                    if (o < 21) acc += L.rowS[s] * L.rowA[pr * 6 + ia] * L.rowA[pr * 6 + ib];
+                    else if (o < 39) { if ((int)rsel == sel) acc -= L.rowS[s] * L.rowA[pr * 6 + ia]; }
+                    else if (o < 42) { if ((int)rsel == sel) acc += L.rowS[s]; }
+                    else if (o < 60) acc += L.rowS[(vecsel == 0 ? NSLOT : vecsel == 1 ? 2 * NSLOT : 3 * NSLOT) + s] * L.rowA[pr * 6 + ia];
+                    else { if ((int)rsel == sel) acc -= L.rowS[(vecsel == 0 ? NSLOT : vecsel == 1 ? 2 * NSLOT : 3 * NSLOT) + s]; }
+                }
+                if (o < 21) { L.Hp[6 * ia + ib] += acc; if (ia != ib) L.Hp[6 * ib + ia] += acc; }
+                else if (o < 39) L.mS[(sel - 1) * 6 + ia] = acc;
+                else if (o < 42) L.sS[sel - 1] = acc;
+                else if (o < 60) { double* dst = vecsel == 0 ? L.bp0 : vecsel == 1 ? L.bp1 : L.bpz; dst[ia] += acc; }
+                else { double* dst = vecsel == 0 ? L.bS0 : vecsel == 1 ? L.bS1 : L.bSz; dst[sel - 1] = acc; }
+            }
+            for (int o = lane; o < 132; o += 64) {
+                // per point c: 0..5 M3 sym, 6..8 mc, 9 sc, 10..18 b3{0,1,z}[3], 19..21 bc{0,1,z}
+                int c = o / 22, q = o - 22 * c;
+                const double* a = sp + P_ASETJ + 45 * c;
+                double acc = 0;
+                int ia = 0, ib = 0, vs = 0;
+                if (q < 6) { int e = q, i = 0; while (e >= 3 - i) { e -= 3 - i; i++; } ia = i; ib = i + e; }
+                else if (q < 9) ia = q - 6;
+                else if (q >= 10 && q < 19) { vs = (q - 10) / 3; ia = (q - 10) % 3; }
+                else if (q >= 19) vs = q - 19;
+                for (int rr = 0; rr < 15; rr++) {
+                    int s = S_COL + 15 * c + rr;
+                    double sg = L.rowS[s];
+                    double rv = L.rowS[(vs == 0 ? NSLOT : vs == 1 ? 2 * NSLOT : 3 * NSLOT) + s];
+                    if (q < 6) acc += sg * a[rr + 15 * ia] * a[rr + 15 * ib];
+                    else if (q < 9) acc -= sg * a[rr + 15 * ia];
+                    else if (q == 9) acc += sg;
+                    else if (q < 19) acc += rv * a[rr + 15 * ia];
+                    else acc -= rv;
+                }
+                if (q < 6) { L.M3[9 * c + 3 * ia + ib] = acc; L.M3[9 * c + 3 * ib + ia] = acc; }
+                else if (q < 9) L.mc[3 * c + ia] = acc;
+                else if (q == 9) L.sc[c] = acc;
+                else if (q < 19) { double* dst = vs == 0 ? L.b30 : vs == 1 ? L.b31 : L.b3z; dst[3 * c + ia] = acc; }
+                else { double* dst = vs == 0 ? L.bc0 : vs == 1 ? L.bc1 : L.bcz; dst[c] = acc; }
+            }
+            // natural-diagonal rows straight into W / g
+            if (lane < 38) {
+                int s0, s1, pos;
+                if (lane < 28) { s0 = 2 * lane; s1 = 2 * lane + 1; int blk = lane / 7, jj = lane - 7 * blk; pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + jj; }
+                else if (lane < 32) { s0 = S_NONNEG + lane - 28; s1 = -1; int m = lane - 28; pos = (m == 0 ? Z_RS : m == 1 ? Z_DRS : m == 2 ? Z_PS : Z_DPS); }
+                else { s0 = S_D1 + lane - 32; s1 = -1; pos = Z_D + lane - 32; }
+                double c0 = (lane < 28) ? 1.0 : -1.0;   // upper rows +1, all others -1
+                double h = L.rowS[s0], a0 = c0 * L.rowS[NSLOT + s0], a1 = c0 * L.rowS[2 * NSLOT + s0], az = c0 * L.rowS[3 * NSLOT + s0];
+                if (s1 >= 0) { h += L.rowS[s1]; a0 -= L.rowS[NSLOT + s1]; a1 -= L.rowS[2 * NSLOT + s1]; az -= L.rowS[3 * NSLOT + s1]; }
+                L.W[pos * LDW + pos] += h; L.g0[pos] += a0; L.g1[pos] += a1; L.gz[pos] += az;
+            }
+        }
+        BMPC_SYNC();
+        // ---- chain pose/velocity space through O = d(pose, v)/d(q, dq, pi) ----
+        for (int e = lane; e < 204; e += 64) {
+            int mat = e / 102, rr = (e % 102) / 17, cc = e % 17;
+            double v = 0;
+            if (mat == 0) {   // Op: rows p_pos (J lin) ; p_rot (dt/2 G_w | dt/2 J_w | I)
+                if (rr < 3) v = (cc < 7) ? L.J[7 * rr + cc] : 0.0;
+                else if (cc < 7) v = 0.5 * dc.dt * L.G[7 * rr + cc];
+                else if (cc < 14) v = 0.5 * dc.dt * L.J[7 * rr + cc - 7];
+                else v = (cc - 14 == rr - 3) ? 1.0 : 0.0;
+                L.Op[e] = v;
+            } else {          // Ov: [G | J | 0]
+                v = (cc < 7) ? L.G[7 * rr + cc] : (cc < 14 ? L.J[7 * rr + cc - 7] : 0.0);
+                L.Ov[e - 102] = v;
+            }
+        }
+        BMPC_SYNC();
+        for (int e = lane; e < 204; e += 64) {
+            int mat = e / 102, rr = (e % 102) / 17, cc = e % 17;
+            const double* H = mat ? L.Hv : L.Hp;
+            const double* O = mat ? L.Ov : L.Op;
+            double v = 0;
+            for (int a = 0; a < 6; a++) v += H[6 * rr + a] * O[17 * a + cc];
+            (mat ? L.T2 : L.T1)[17 * rr + cc] = v;
+        }
+        BMPC_SYNC();
+        {
+            auto pos17 = [](int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); };
+            const int spos[3] = {Z_PS, Z_RS, Z_D + 5};
+            for (int e = lane; e < 289 + 51 + 3 + 20; e += 64) {
+                if (e < 289) {
+                    int i = e / 17, j = e % 17;
+                    double v = 0;
+                    for (int a = 0; a < 6; a++) v += L.Op[17 * a + i] * L.T1[17 * a + j] + L.Ov[17 * a + i] * L.T2[17 * a + j];
+                    L.W[pos17(i) * LDW + pos17(j)] += v;
+                } else if (e < 340) {
+                    int i = (e - 289) / 3, sl = (e - 289) % 3;
+                    double v = 0;
+                    for (int a = 0; a < 6; a++) v += L.Op[17 * a + i] * L.mS[6 * sl + a];
+                    L.W[pos17(i) * LDW + spos[sl]] += v;
+                    L.W[spos[sl] * LDW + pos17(i)] += v;
+                } else if (e < 343) {
+                    int sl = e - 340;
+                    L.W[spos[sl] * LDW + spos[sl]] += L.sS[sl];
+                    L.g0[spos[sl]] += L.bS0[sl]; L.g1[spos[sl]] += L.bS1[sl]; L.gz[spos[sl]] += L.bSz[sl];
+                } else if (e < 360) {
+                    int i = e - 343;
+                    double v0 = 0, v1 = 0, vz = 0;
+                    for (int a = 0; a < 6; a++) {
+                        v0 += L.Op[17 * a + i] * L.bp0[a] + L.Ov[17 * a + i] * L.bv[a];
+                        v1 += L.Op[17 * a + i] * L.bp1[a];
+                        vz += L.Op[17 * a + i] * L.bpz[a] + L.Ov[17 * a + i] * L.bv[a];
+                    }
+                    L.g0[pos17(i)] += v0; L.g1[pos17(i)] += v1; L.gz[pos17(i)] += vz;
+                }
+            }
+        }
+        BMPC_SYNC();
+        // ---- collision points: q x q, q x d, d x d ----
+        for (int e = lane; e < 49 + 42 + 6 + 7; e += 64) {
+            if (e < 49) {
+                int i = e / 7, j = e % 7;
+                double v = 0;
+                for (int c = 0; c < 6; c++)
+                    for (int a = 0; a < 3; a++) {
+                        double t = 0;
+                        for (int bb = 0; bb < 3; bb++) t += L.M3[9 * c + 3 * a + bb] * L.Jp[21 * c + 7 * bb + j];
+                        v += L.Jp[21 * c + 7 * a + i] * t;
+                    }
+                L.W[(Z_Q + i) * LDW + Z_Q + j] += v;
+            } else if (e < 91) {
+                int i = (e - 49) / 6, c = (e - 49) % 6;
+                double v = 0;
+                for (int a = 0; a < 3; a++) v += L.Jp[21 * c + 7 * a + i] * L.mc[3 * c + a];
+                L.W[(Z_Q + i) * LDW + Z_D + c] += v;
+                L.W[(Z_D + c) * LDW + Z_Q + i] += v;
+            } else if (e < 97) {
+                int c = e - 91;
+                L.W[(Z_D + c) * LDW + Z_D + c] += L.sc[c];
+                L.g0[Z_D + c] += L.bc0[c]; L.g1[Z_D + c] += L.bc1[c]; L.gz[Z_D + c] += L.bcz[c];
+            } else {
+                int i = e - 97;
+                double v0 = 0, v1 = 0, vz = 0;
+                for (int c = 0; c < 6; c++)
+                    for (int a = 0; a < 3; a++) {
+                        double jp = L.Jp[21 * c + 7 * a + i];
+                        v0 += jp * L.b30[3 * c + a]; v1 += jp * L.b31[3 * c + a]; vz += jp * L.b3z[3 * c + a];
+                    }
+                L.g0[Z_Q + i] += v0; L.g1[Z_Q + i] += v1; L.gz[Z_Q + i] += vz;
+            }
+        }
+        BMPC_SYNC();
+        // ---- direct quadratic cost terms (natural coordinates) ----
+        if (lane < 20) {
+            int pos; double w2; double val; double extra = 0;
+            if (lane < 3) { pos = Z_DQ + 2 + lane; w2 = 2 * wts[6]; }
+            else if (lane < 10) { pos = Z_U + lane - 3; w2 = 2 * wts[7]; }
+            else if (lane < 14) { int m = lane - 10; pos = (m == 0 ? Z_RS : m == 1 ? Z_DRS : m == 2 ? Z_PS : Z_DPS); w2 = 2 * ((m & 1) ? wts[10] : wts[9]); }
+            else { int i = lane - 14; pos = Z_D + i; w2 = term ? (2 * wts[10] + (i != 4 ? 2 * wts[8] : 0.0)) : 0.0; extra = (term && i != 4) ? 2 * wts[8] * sp[P_SLACKS0 + i] : 0.0; }
+            val = w2 * L.yz[pos] + extra;
+            L.W[pos * LDW + pos] += w2; L.g0[pos] += val; L.gz[pos] += val;
+        }
+        BMPC_SYNC();
+        // ---- natural -> zeta coordinates: H = T^T Hy T (column pass, then row pass + vectors) ----
+        for (int e = lane; e < NZ * 9; e += 64) {
+            int i = e / 9, t = e % 9;
+            double* row = L.W + i * LDW;
+            if (t < 7) row[Z_U + t] += dc.c3 * row[Z_Q + t] + dc.c2 * row[Z_DQ + t] + dc.c1 * row[Z_DDQ + t];
+            else if (t == 7) row[Z_DRS] += 0.5 * dc.dt * row[Z_RS];
+            else row[Z_DPS] += 0.5 * dc.dt * row[Z_PS];
+        }
+        BMPC_SYNC();
+        for (int e = lane; e < NZ * 9 + 27; e += 64) {
+            if (e < NZ * 9) {
+                int j = e / 9, t = e % 9;
+                double* W = L.W;
+                if (t < 7) W[(Z_U + t) * LDW + j] += dc.c3 * W[(Z_Q + t) * LDW + j] + dc.c2 * W[(Z_DQ + t) * LDW + j] + dc.c1 * W[(Z_DDQ + t) * LDW + j];
+                else if (t == 7) W[Z_DRS * LDW + j] += 0.5 * dc.dt * W[Z_RS * LDW + j];
+                else W[Z_DPS * LDW + j] += 0.5 * dc.dt * W[Z_PS * LDW + j];
+            } else {
+                int vsel = (e - NZ * 9) / 9, t = (e - NZ * 9) % 9;
+                double* g = vsel == 0 ? L.g0 : vsel == 1 ? L.g1 : L.gz;
+                if (t < 7) g[Z_U + t] += dc.c3 * g[Z_Q + t] + dc.c2 * g[Z_DQ + t] + dc.c1 * g[Z_DDQ + t];
+                else if (t == 7) g[Z_DRS] += 0.5 * dc.dt * g[Z_RS];
+                else g[Z_DPS] += 0.5 * dc.dt * g[Z_PS];
+            }
+        }
+        BMPC_SYNC();
+        if (k == 1 && lane < 2) {   // zeta-diagonal rows rs~_1, ps~_1 >= 0
+            int s = S_RS1 + lane, pos = lane ? Z_PS : Z_RS;
+            L.W[pos * LDW + pos] += L.rowS[s];
+            L.g0[pos] -= L.rowS[NSLOT + s]; L.g1[pos] -= L.rowS[2 * NSLOT + s]; L.gz[pos] -= L.rowS[3 * NSLOT + s];
+        }
+        // ---- coupling with stage k+1 ----
+        if (!term) {
+            if (lane < NZ) {
+                int c = lane;
+                for (int a = 0; a < 3; a++) {
+                    double v = 0;
+                    if (c < Z_DQ) v = dc.dt * L.G[7 * (3 + a) + c];
+                    else if (c < Z_DDQ) v = dc.dt * L.J[7 * (3 + a) + c - 7];
+                    else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * L.G[7 * (3 + a) + c - Z_U] + dc.c2 * L.J[7 * (3 + a) + c - Z_U]);
+                    L.Et[a * NZ + c] = v;
+                }
+                int idx[3]; double cf[3];
+                int n = phi_col(c, dc, idx, cf);
+                for (int a = 0; a < 3; a++) {
+                    double v = 0;
+                    for (int t = 0; t < n; t++) v += cf[t] * L.P[idx[t] * LDP + Z_PI + a];
+                    L.Y[c * 3 + a] = v;
+                }
+            }
+            if (lane < NX) {
+                double r = defect_row(L, dc, lane);
+                L.rdef[lane] = r;
+                ac.prim = fmax(ac.prim, fabs(r)); ac.theta += fabs(r);
+            }
+            BMPC_SYNC();
+            if (lane < NX) {
+                double v = L.pv0[lane];
+                for (int j = 0; j < NX; j++) v += L.P[lane * LDP + j] * L.rdef[j];
+                L.vt0[lane] = v;
+            } else {
+                L.vt1[lane - NX] = L.pv1[lane - NX];
+            }
+            BMPC_SYNC();
+            for (int e = lane; e < NZ * NZ; e += 64) {
+                int i = e / NZ, j = e % NZ;
+                int ii[3], jj[3]; double ci[3], cj[3];
+                int ni = phi_col(i, dc, ii, ci), nj = phi_col(j, dc, jj, cj);
+                double v = 0;
+                for (int a = 0; a < ni; a++)
+                    for (int bb = 0; bb < nj; bb++) v += ci[a] * cj[bb] * L.P[ii[a] * LDP + jj[bb]];
+                for (int a = 0; a < 3; a++) {
+                    double eai = L.Et[a * NZ + i], eaj = L.Et[a * NZ + j];
+                    v += L.Y[i * 3 + a] * eaj + eai * L.Y[j * 3 + a];
+                    if (eai != 0.0)
+                        for (int bb = 0; bb < 3; bb++) v += eai * L.P[(Z_PI + a) * LDP + Z_PI + bb] * L.Et[bb * NZ + j];
+                }
+                L.W[i * LDW + j] += v;
+            }
+            if (lane < NZ) {
+                int c = lane, idx[3]; double cf[3];
+                int n = phi_col(c, dc, idx, cf);
+                double gl = 0, a0 = 0, a1 = 0;
+                for (int t = 0; t < n; t++) { gl += cf[t] * L.lam[idx[t]]; a0 += cf[t] * L.vt0[idx[t]]; a1 += cf[t] * L.vt1[idx[t]]; }
+                for (int a = 0; a < 3; a++) {
+                    double ea = L.Et[a * NZ + c];
+                    gl += ea * L.lam[Z_PI + a]; a0 += ea * L.vt0[Z_PI + a]; a1 += ea * L.vt1[Z_PI + a];
+                }
+                L.gz[c] += gl; L.g0[c] += a0; L.g1[c] += a1;
+            }
+        }
+        BMPC_SYNC();
+        // ---- adjoint multipliers + dual residual (gz now holds the Lagrangian gradient) ----
+        if (lane < NZ) {
+            double gl = L.gz[lane];
+            if (lane >= NX || (k == 1 && lane >= 24)) ac.dual = fmax(ac.dual, fabs(gl));
+            if (lane < NX) { L.lam[lane] = gl; ac.lamsum += fabs(gl); }
+        }
+        // ---- control block factorisation, gains, Schur complement ----
+        double Lc[45];
+        if (!chol9(L.W, reg, Lc)) ok = false;
+        if (lane < NX + 2) {
+            double rhs[NU];
+            for (int l = 0; l < NU; l++)
+                rhs[l] = (lane < NX) ? L.W[(NX + l) * LDW + lane] : (lane == NX ? L.g0[NX + l] : L.g1[NX + l]);
+            chol9_solve(Lc, rhs);
+            for (int l = 0; l < NU; l++) {
+                if (lane < NX) { L.Kl[l * NX + lane] = -rhs[l]; ws.K[(size_t)k * NU * NX + l * NX + lane] = -rhs[l]; }
+                else { L.kf[(lane - NX) * 16 + l] = -rhs[l]; ws.kf[k * 32 + (lane - NX) * 16 + l] = -rhs[l]; }
+            }
+        }
+        BMPC_SYNC();
+        for (int e = lane; e < NX * NX; e += 64) {
+            int i = e / NX, j = e % NX;
+            if (j < i) continue;
+            double v = L.W[i * LDW + j];
+            for (int l = 0; l < NU; l++) v += L.W[(NX + l) * LDW + i] * L.Kl[l * NX + j];
+            L.P[i * LDP + j] = v;
+            L.P[j * LDP + i] = v;
+        }
+        {
+            int i = lane & (NX - 1);
+            const double* g = (lane < NX) ? L.g0 : L.g1;
+            const double* kf = L.kf + ((lane < NX) ? 0 : 16);
+            double v = g[i];
+            for (int l = 0; l < NU; l++) v += L.W[(NX + l) * LDW + i] * kf[l];
+            ((lane < NX) ? L.pv0 : L.pv1)[i] = v;
+        }
+        if (lane < NZ) L.znext[lane] = L.zeta[lane];
+        BMPC_SYNC();
+    }
+    // initial defect of the pinned part of x_1 (zeta_1 is still in L.zeta)
+    if (lane < 24) {
+        double r = L.x1fix[lane] - L.zeta[lane];
+        L.r0[lane] = r;
+        ac.prim = fmax(ac.prim, fabs(r)); ac.theta += fabs(r);
+    }
+    double cmax = wg_max(ac.cmax, L.red, lane), csum = wg_sum(ac.csum, L.red, lane), cmin = wg_min(ac.cmin, L.red, lane);
+    double zsum = wg_sum(ac.zsum, L.red, lane), prim = wg_max(ac.prim, L.red, lane), theta = wg_sum(ac.theta, L.red, lane);
+    double logs = wg_sum(ac.logs, L.red, lane), lamsum = wg_sum(ac.lamsum, L.red, lane), dual = wg_max(ac.dual, L.red, lane);
+    int nrows = (int)(wg_sum((double)ac.nrows, L.red, lane) + 0.5);
+    int neq = NX * (N - 2) + 24;
+    kk.sd = fmax(100.0, (lamsum + zsum) / (double)(neq + nrows)) / 100.0;
+    kk.sc = fmax(100.0, zsum / (double)nrows) / 100.0;
+    kk.dual = dual; kk.prim = prim; kk.compl_ = cmax;
+    kk.err = fmax(fmax(dual / kk.sd, prim), cmax / kk.sc);
+    kk.f = fsum; kk.theta = theta; kk.avgc = csum / nrows; kk.minc = cmin; kk.logs = logs; kk.nrows = nrows;
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward sweep: Newton step, row steps, fraction-to-boundary, merit derivative
+// ------------------------------------------------------------------------------------------
+struct StepInfo { double ap, ad, dphi_f, dphi_bar; bool ok; };
+
+BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
+                            double mu, const double* iw0, StepInfo& si) {
+    const int N = A.o.N;
+    const double* sp = L.sp;
+    const double* wts = sp + P_W;
+    double tau = fmax(0.99, 1.0 - mu);
+    double ap_l = 1.0, ad_l = 1.0, dbar_l = 0.0, dphi_f = 0.0;
+    si.ok = true;
+    // stage-1 step: pinned part = initial defect, free part (rs~, ps~, d) minimises the cost-to-go
+    {
+        double Pf[36], rhs[8];
+        for (int i = 0; i < 8; i++) {
+            double s = L.pv0[24 + i] + mu * L.pv1[24 + i];
+            for (int j = 0; j < 24; j++) s += L.P[(24 + i) * LDP + j] * L.r0[j];
+            rhs[i] = -s;
+        }
+#define PF(i, j) Pf[(i) * ((i) + 1) / 2 + (j)]
+        for (int j = 0; j < 8; j++) {
+            double d = L.P[(24 + j) * LDP + 24 + j];
+            for (int l = 0; l < j; l++) d -= PF(j, l) * PF(j, l);
+            if (!(d > 0)) { si.ok = false; d = 1.0; }
+            d = sqrt(d);
+            PF(j, j) = d;
+            for (int i = j + 1; i < 8; i++) {
+                double s = L.P[(24 + i) * LDP + 24 + j];
+                for (int l = 0; l < j; l++) s -= PF(i, l) * PF(j, l);
+                PF(i, j) = s / d;
+            }
+        }
+        for (int i = 0; i < 8; i++) { double s = rhs[i]; for (int l = 0; l < i; l++) s -= PF(i, l) * rhs[l]; rhs[i] = s / PF(i, i); }
+        for (int i = 7; i >= 0; i--) { double s = rhs[i]; for (int l = i + 1; l < 8; l++) s -= PF(l, i) * rhs[l]; rhs[i] = s / PF(i, i); }
+#undef PF
+        BMPC_SYNC();
+        if (lane < 24) L.dx[lane] = L.r0[lane];
+        if (lane == 0) for (int i = 0; i < 8; i++) L.dx[24 + i] = rhs[i];
+        BMPC_SYNC();
+    }
+    StageEval E;
+    for (int k = 1; k < N; k++) {
+        if (lane < NZ) {
+            double z = ws.zeta[k * ZPAD + lane];
+            L.zeta[lane] = z;
+            ws.zsave[k * ZPAD + lane] = z;
+            L.znext[lane] = (k < N - 1) ? ws.zeta[(k + 1) * ZPAD + lane] : 0.0;
+        }
+        for (int e = lane; e < NU * NX; e += 64) L.Kl[e] = ws.K[(size_t)k * NU * NX + e];
+        if (lane < 32) L.kf[lane] = ws.kf[k * 32 + lane];
+        BMPC_SYNC();
+        stage_eval(A, L, dc, k, lane, false, iw0, E);
+        // g0 := dzeta, g1 := dy (natural)
+        if (lane < NX) L.g0[lane] = L.dx[lane];
+        else if (lane < NZ) {
+            int l = lane - NX;
+            double s = L.kf[l] + mu * L.kf[16 + l];
+            for (int j = 0; j < NX; j++) s += L.Kl[l * NX + j] * L.dx[j];
+            L.g0[lane] = s;
+        }
+        BMPC_SYNC();
+        if (lane < NZ) { ws.dz[k * ZPAD + lane] = L.g0[lane]; L.g1[lane] = nat_from_zeta(L.g0, lane, dc); }
+        BMPC_SYNC();
+        if (lane < 24) {
+            double s = 0;
+            if (lane < 3) { for (int j = 0; j < 7; j++) s += L.J[7 * lane + j] * L.g1[Z_Q + j]; L.dloc[lane] = s; }
+            else if (lane < 6) {
+                for (int j = 0; j < 7; j++) s += L.G[7 * lane + j] * L.g1[Z_Q + j] + L.J[7 * lane + j] * L.g1[Z_DQ + j];
+                L.dloc[lane] = L.g1[Z_PI + lane - 3] + 0.5 * dc.dt * s;
+            } else {
+                int c = (lane - 6) / 3, a = (lane - 6) % 3;
+                for (int j = 0; j < 7; j++) s += L.Jp[21 * c + 7 * a + j] * L.g1[Z_Q + j];
+                L.dpt[lane - 6] = s;
+            }
+        }
+        BMPC_SYNC();
+        // directional derivative of f (every lane, registers)
+        {
+            double s = 0;
+            for (int a = 0; a < 6; a++) s += E.g12[a] * L.dloc[a];
+            for (int a = 0; a < 6; a++) {
+                double dv = 0;
+                for (int j = 0; j < 7; j++) dv += E.G[a][j] * L.g1[Z_Q + j] + E.J[a][j] * L.g1[Z_DQ + j];
+                s += E.g12[6 + a] * dv;
+            }
+            for (int j = 2; j <= 4; j++) s += 2 * wts[6] * L.yz[Z_DQ + j] * L.g1[Z_DQ + j];
+            for (int j = 0; j < 7; j++) s += 2 * wts[7] * L.yz[Z_U + j] * L.g1[Z_U + j];
+            s += 2 * wts[9] * L.yz[Z_RS] * L.g1[Z_RS] + 2 * wts[10] * L.yz[Z_DRS] * L.g1[Z_DRS] +
+                 2 * wts[9] * L.yz[Z_PS] * L.g1[Z_PS] + 2 * wts[10] * L.yz[Z_DPS] * L.g1[Z_DPS];
+            if (k == N - 1)
+                for (int i = 0; i < 6; i++) {
+                    double gg = 2 * wts[10] * L.yz[Z_D + i] + (i != 4 ? 2 * wts[8] * (sp[P_SLACKS0 + i] + L.yz[Z_D + i]) : 0.0);
+                    s += gg * L.g1[Z_D + i];
+                }
+            dphi_f += s;
+        }
+        for (int m = 0; m < 4; m++) {
+            int s = lane + 64 * m;
+            if (s >= NSLOT) break;
+            Row r;
+            row_eval(A, L, b, k, s, r);
+            if (!r.kind) continue;
+            double adot;
+            if (r.kind == 1) adot = r.coef * L.g1[r.pos];
+            else if (r.kind == 2) adot = r.coef * L.g0[r.pos];
+            else if (r.kind == 3) {
+                adot = 0;
+                for (int c = 0; c < 6; c++) adot += r.a[c] * L.dloc[c];
+                if (r.sel == 1) adot -= L.g1[Z_PS];
+                else if (r.sel == 2) adot -= L.g1[Z_RS];
+                else if (r.sel == 3) adot -= L.g1[Z_D + 5];
+            } else {
+                int c = r.pos;
+                adot = r.a[0] * L.dpt[3 * c] + r.a[1] * L.dpt[3 * c + 1] + r.a[2] * L.dpt[3 * c + 2] - L.g1[Z_D + c];
+            }
+            double t = ws.t[k * NSLOT + s], z = ws.z[k * NSLOT + s];
+            double dti = -(r.h + t) - adot;
+            double dzi = (mu - t * z - z * dti) / t;
+            ws.dt[k * NSLOT + s] = dti; ws.dzr[k * NSLOT + s] = dzi; ws.tsave[k * NSLOT + s] = t;
+            if (dti < 0) ap_l = fmin(ap_l, -tau * t / dti);
+            if (dzi < 0) ad_l = fmin(ad_l, -tau * z / dzi);
+            dbar_l -= mu * dti / t;
+        }
+        // next dx = A dx + B dw + defect
+        if (k < N - 1) {
+            if (lane < NX) {
+                const double* d = L.g0;
+                int i = lane;
+                double v;
+                if (i < Z_DQ) v = d[i] + dc.dt * d[i + 7] + 0.5 * dc.dt * dc.dt * d[i + 14] + dc.b3 * d[Z_U + i];
+                else if (i < Z_DDQ) v = d[i] + dc.dt * d[i + 7] + dc.b2 * d[Z_U + i - 7];
+                else if (i < Z_PI) v = d[i] + dc.b1 * d[Z_U + i - 14];
+                else if (i < Z_RS) {
+                    int a = i - Z_PI;
+                    v = d[i];
+                    for (int j = 0; j < 7; j++)
+                        v += dc.dt * (L.G[7 * (3 + a) + j] * L.g1[Z_Q + j] + L.J[7 * (3 + a) + j] * L.g1[Z_DQ + j]);
+                } else if (i == Z_RS) v = d[i] + dc.dt * d[Z_DRS];
+                else if (i == Z_PS) v = d[i] + dc.dt * d[Z_DPS];
+                else v = d[i];
+                L.dxn[i] = v + defect_row(L, dc, i);
+            }
+            BMPC_SYNC();
+            if (lane < NX) L.dx[lane] = L.dxn[lane];
+        }
+        BMPC_SYNC();
+    }
+    si.ap = fmin(1.0, wg_min(ap_l, L.red, lane));
+    si.ad = fmin(1.0, wg_min(ad_l, L.red, lane));
+    si.dphi_bar = wg_sum(dbar_l, L.red, lane);
+    si.dphi_f = dphi_f;
+}
+
+// trial point zeta = zsave + alpha dz, t = tsave + alpha dt: barrier objective pieces
+BMPC_DEV void trial_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
+                          double alpha, const double* iw0, double& f1, double& th1, double& ls1) {
+    const int N = A.o.N;
+    double th_l = 0, ls_l = 0, fs = 0;
+    StageEval E;
+    for (int k = N - 1; k >= 1; k--) {
+        if (lane < NZ) {
+            double z = ws.zsave[k * ZPAD + lane] + alpha * ws.dz[k * ZPAD + lane];
+            L.zeta[lane] = z;
+            ws.zeta[k * ZPAD + lane] = z;
+        }
+        BMPC_SYNC();
+        stage_eval(A, L, dc, k, lane, false, iw0, E);
+        fs += E.fval;
+        for (int m = 0; m < 4; m++) {
+            int s = lane + 64 * m;
+            if (s >= NSLOT) break;
+            Row r;
+            row_eval(A, L, b, k, s, r);
+            if (!r.kind) continue;
+            double t = ws.tsave[k * NSLOT + s] + alpha * ws.dt[k * NSLOT + s];
+            ws.t[k * NSLOT + s] = t;
+            th_l += fabs(r.h + t);
+            ls_l += log(t);
+        }
+        if (k < N - 1 && lane < NX) th_l += fabs(defect_row(L, dc, lane));
+        BMPC_SYNC();
+        if (lane < NZ) L.znext[lane] = L.zeta[lane];
+        BMPC_SYNC();
+    }
+    if (lane < 24) th_l += fabs(L.x1fix[lane] - L.zeta[lane]);
+    th1 = wg_sum(th_l, L.red, lane);
+    ls1 = wg_sum(ls_l, L.red, lane);
+    f1 = fs;
+}
+
+// ------------------------------------------------------------------------------------------
+// One instance
+// ------------------------------------------------------------------------------------------
+BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, int b, int lane) {
+    const SolverOpts& o = A.o;
+    const int N = o.N, n_w = 44 * N + 6;
+    const double dt = o.dt;
+    DynC dc;
+    dc.dt = dt; dc.c1 = dt / 2; dc.c2 = dt * dt / 6; dc.c3 = dt * dt * dt / 24;
+    dc.b1 = dt; dc.b2 = dt * dt; dc.b3 = 7 * dt * dt * dt / 12;
+    WsPtr ws;
+    ws_carve(wsbase, N, ws);
+    const double* x0 = A.x0 + (size_t)b * n_w;
+    const double* lbx = A.lbx + (size_t)b * n_w;
+    for (int e = lane; e < NPAR; e += 64) L.sp[e] = A.p[(size_t)b * NPAR + e];
+    // stage-0 pins (BoundMPC.py:551-556): lbx == ubx there
+    double iw0[3];
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    if (lane < 7) {
+        int j = lane;
+        double q0 = lbx[j * N], dq0 = lbx[7 * N + j * N], ddq0 = lbx[14 * N + j * N], u0 = lbx[21 * N + j * N];
+        L.x1fix[Z_Q + j] = q0 + dt * dq0 + dt * dt / 2 * ddq0 + dt * dt * dt / 8 * u0;
+        L.x1fix[Z_DQ + j] = dq0 + dt * ddq0 + dt * dt / 3 * u0;
+        L.x1fix[Z_DDQ + j] = ddq0 + dt / 2 * u0;
+    } else if (lane < 10) {
+        int c = lane - 7;
+        L.x1fix[Z_PI + c] = lbx[28 * N + (3 + c) * N] + dt / 2 * lbx[34 * N + (3 + c) * N];
+    }
+    BMPC_SYNC();
+    // ---- initial iterate from x0 (natural -> zeta) ----
+    for (int k = 1; k < N; k++) {
+        double q[7], dq[7];
+        for (int j = 0; j < 7; j++) { q[j] = x0[j * N + k]; dq[j] = x0[7 * N + j * N + k]; }
+        Kin kin;
+        double J[6][7], G[6][7], v[6];
+        kin_eval(A.rc, q, kin);
+        kin_jac(kin, dq, J, G, v);
+        if (lane < 7) {
+            int j = lane;
+            double uu = x0[21 * N + j * N + k];
+            ws.zeta[k * ZPAD + Z_Q + j] = q[j] - dc.c3 * uu;
+            ws.zeta[k * ZPAD + Z_DQ + j] = dq[j] - dc.c2 * uu;
+            ws.zeta[k * ZPAD + Z_DDQ + j] = x0[14 * N + j * N + k] - dc.c1 * uu;
+            ws.zeta[k * ZPAD + Z_U + j] = uu;
+        } else if (lane < 10) {
+            int c = lane - 7;
+            ws.zeta[k * ZPAD + Z_PI + c] = x0[28 * N + (3 + c) * N + k] - dt / 2 * v[3 + c];
+        } else if (lane == 10) {
+            double rs = x0[40 * N + 6 + k], drs = x0[41 * N + 6 + k], ps = x0[42 * N + 6 + k], dps = x0[43 * N + 6 + k];
+            ws.zeta[k * ZPAD + Z_RS] = rs - dt / 2 * drs; ws.zeta[k * ZPAD + Z_PS] = ps - dt / 2 * dps;
+            ws.zeta[k * ZPAD + Z_DRS] = drs; ws.zeta[k * ZPAD + Z_DPS] = dps;
+        } else if (lane < 17) {
+            int i = lane - 11;
+            ws.zeta[k * ZPAD + Z_D + i] = x0[40 * N + i];
+        }
+    }
+    BMPC_SYNC();
+    // ---- row slacks / multipliers: t = max(-h, 1e-2), z = 1 ----
+    {
+        StageEval E;
+        for (int k = N - 1; k >= 1; k--) {
+            if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
+            BMPC_SYNC();
+            stage_eval(A, L, dc, k, lane, false, iw0, E);
+            for (int m = 0; m < 4; m++) {
+                int s = lane + 64 * m;
+                if (s >= NSLOT) break;
+                Row r;
+                row_eval(A, L, b, k, s, r);
+                ws.t[k * NSLOT + s] = r.kind ? fmax(-r.h, 1e-2) : 1.0;
+                ws.z[k * NSLOT + s] = r.kind ? 1.0 : 0.0;
+                ws.dzr[k * NSLOT + s] = 0.0;
+            }
+            BMPC_SYNC();
+        }
+    }
+    int st = 1, it = 0;
+    double mu = o.mu_init;
+    const int MAXF = 8;
+    double filt_th[MAXF], filt_phi[MAXF], filt_mu = -1, theta_max = 1e300, theta_min = 0;
+    int nfilt = 0;
+    double ad_pend = 0.0, reg = 1e-9, hreg = 0.0;
+    Kkt kk;
+    for (it = 0;; it++) {
+        bool ok = backward_sweep(A, L, ws, dc, b, lane, ad_pend, iw0, reg, hreg, kk);
+        ad_pend = 0.0;
+        if (kk.err <= o.tol && kk.dual <= 1.0 && kk.prim <= 1e-4 && kk.compl_ <= 1e-4) { st = 0; break; }
+        if (it >= o.max_iter) { st = 1; break; }
+        // monotone Fiacco-McCormick barrier update (oracle: mu_strategy 1)
+        {
+            double emu = fmax(fmax(kk.dual / kk.sd, kk.prim), fmax(fabs(kk.compl_ - mu), fabs(kk.minc - mu)) / kk.sc);
+            while (emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+                mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                emu = fmax(fmax(kk.dual / kk.sd, kk.prim), fmax(kk.compl_ - mu, 0.0) / kk.sc);
+            }
+        }
+        int tries = 0;
+        StepInfo si;
+        for (;;) {
+            if (ok) { forward_sweep(A, L, ws, dc, b, lane, mu, iw0, si); ok = si.ok; }
+            if (ok) break;
+            hreg = (hreg == 0.0) ? 1e-4 : hreg * 8;
+            if (++tries > 12) { st = 3; break; }
+            ok = backward_sweep(A, L, ws, dc, b, lane, 0.0, iw0, reg, hreg, kk);
+        }
+        if (st == 3) break;
+        if (tries == 0) hreg = (hreg < 1e-8) ? 0.0 : hreg / 3;
+        double f0 = kk.f, th0 = kk.theta, ls0 = kk.logs;
+        double D = si.dphi_f + si.dphi_bar;
+        double phi0 = f0 - mu * ls0;
+        if (it == 0) { theta_max = 1e4 * fmax(1.0, th0); theta_min = 1e-4 * fmax(1.0, th0); }
+        if (mu != filt_mu) { nfilt = 0; filt_mu = mu; }
+        double alpha = si.ap;
+        bool armijo_case = false;
+        for (int bt = 0; bt < 10; bt++) {
+            double f1, th1, ls1;
+            trial_sweep(A, L, ws, dc, b, lane, alpha, iw0, f1, th1, ls1);
+            double phi1 = f1 - mu * ls1;
+            bool acc = (th1 <= theta_max);
+            for (int j = 0; acc && j < nfilt; j++)
+                if (th1 >= filt_th[j] && phi1 >= filt_phi[j]) acc = false;
+            if (acc) {
+                bool sw = (th0 <= theta_min) && (D < 0) && (alpha * pow(-D, 2.3) > pow(th0, 1.1));
+                if (sw) { acc = (phi1 <= phi0 + 1e-4 * alpha * D + 1e-12 * fabs(phi0)); armijo_case = acc; }
+                else acc = (th1 <= (1 - 1e-5) * th0) || (phi1 <= phi0 - 1e-5 * th0);
+            }
+            if (acc) break;
+            alpha *= 0.5;
+        }
+        if (!armijo_case) {
+            if (nfilt == MAXF) { for (int j = 0; j + 1 < MAXF; j++) { filt_th[j] = filt_th[j + 1]; filt_phi[j] = filt_phi[j + 1]; } nfilt--; }
+            filt_th[nfilt] = (1 - 1e-5) * th0;
+            filt_phi[nfilt] = phi0 - 1e-5 * th0;
+            nfilt++;
+        }
+        ad_pend = si.ad;
+    }
+    // ---- outputs in the reference layout ----
+    double* x = A.x + (size_t)b * n_w;
+    double viol_l = 0;
+    {
+        for (int e = lane; e < n_w; e += 64) x[e] = 0.0;
+        BMPC_SYNC();
+        if (lane < 7) {
+            int j = lane;
+            for (int blk = 0; blk < 4; blk++) x[blk * 7 * N + j * N] = lbx[blk * 7 * N + j * N];
+        } else if (lane < 13) {
+            int c = lane - 7;
+            x[28 * N + c * N] = lbx[28 * N + c * N];
+            x[34 * N + c * N] = lbx[34 * N + c * N];
+        }
+        StageEval E;
+        for (int k = N - 1; k >= 1; k--) {
+            if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
+            BMPC_SYNC();
+            stage_eval(A, L, dc, k, lane, false, iw0, E);
+            if (lane < 28) {
+                int blk = lane / 7, j = lane - 7 * blk;
+                int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + j;
+                x[blk * 7 * N + j * N + k] = L.yz[pos];
+            } else if (lane < 34) {
+                int c = lane - 28;
+                x[28 * N + c * N + k] = L.rc[RC_POSE + c];
+                x[34 * N + c * N + k] = L.rc[RC_V + c];
+            } else if (lane == 34) {
+                x[40 * N + 6 + k] = L.yz[Z_RS]; x[41 * N + 6 + k] = L.yz[Z_DRS];
+                x[42 * N + 6 + k] = L.yz[Z_PS]; x[43 * N + 6 + k] = L.yz[Z_DPS];
+                if (k == 1) { x[40 * N + 6] = L.zeta[Z_RS]; x[42 * N + 6] = L.zeta[Z_PS]; }
+            } else if (lane < 41 && k == N - 1) {
+                int i = lane - 35;
+                x[40 * N + i] = L.yz[Z_D + i];
+            }
+            // constraint violation as BoundMPC.py:613-615 (g rows only, 1e-6 dead band)
+            for (int m = 0; m < 4; m++) {
+                int s = lane + 64 * m;
+                if (s >= NSLOT) break;
+                if (s < S_EE) continue;
+                Row r;
+                row_eval(A, L, b, k, s, r);
+                if (r.kind && r.h > 1e-6) viol_l += r.h;
+            }
+            if (k < N - 1 && lane < NX) { double r = fabs(defect_row(L, dc, lane)); if (r > 1e-6 && lane < Z_D) viol_l += r; }
+            BMPC_SYNC();
+            if (lane < NZ) L.znext[lane] = L.zeta[lane];
+            BMPC_SYNC();
+        }
+        if (lane < 24) { double r = fabs(L.x1fix[lane] - L.zeta[lane]); if (r > 1e-6) viol_l += r; }
+    }
+    double viol = wg_sum(viol_l, L.red, lane);
+    if (lane == 0) {
+        A.f[b] = kk.f;
+        A.iters[b] = it;
+        A.status[b] = st;
+        A.viol[b] = viol;
+    }
+    BMPC_SYNC();
+}
+
+}  // namespace bmpc

@@ -1,0 +1,53 @@
+// CPU thread emulation of ONE workgroup of the HIP solver -- TEST INFRASTRUCTURE ONLY.
+// Compiles the identical device source (boundplanner_amd/csrc/bmpc_device.hpp, bmpc_solver.hpp)
+// with 64 std::threads standing in for the 64 lanes and a barrier for __syncthreads(), so the
+// kernel logic can be debugged and compared with the oracle without a GPU.  Never shipped,
+// never used by the product path or by the -m gpu tests.
+#include <barrier>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+static std::barrier<>* g_bar = nullptr;
+static thread_local int t_lane = 0;
+#define BMPC_DEV
+#define BMPC_INL inline
+#define BMPC_SYNC() g_bar->arrive_and_wait()
+#define BMPC_LANE() t_lane
+#define BMPC_BLOCK() 0
+#define BMPC_NBLOCKS() 1
+using std::fmax;
+using std::fmin;
+
+#include "../../boundplanner_amd/csrc/bmpc_solver.hpp"
+#include "../../boundplanner_amd/csrc/bmpc_robot.hpp"
+
+extern "C" int emu_solve(int N, double dt, double tol, int max_iter, int hess, double hess_switch, double mu_init,
+                         double kappa_mu, double theta_mu, double kappa_eps, const double* x0, const double* lbx,
+                         const double* ubx, const double* p, double* x, double* f, int* iters, int* status,
+                         double* viol) {
+    using namespace bmpc;
+    RobotConst rc;
+    fill_robot_const(rc);
+    KernelArgs A;
+    A.B = 1;
+    A.o = SolverOpts{N, dt, tol, max_iter, hess, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps};
+    A.rc = &rc;
+    A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.p = p;
+    A.x = x; A.f = f; A.viol = viol; A.g = nullptr; A.iters = iters; A.status = status;
+    std::vector<double> ws(ws_doubles(N), 0.0), lds(LDS_DOUBLES + 64, 0.0);
+    A.ws = ws.data();
+    Lds L;
+    lds_carve(lds.data(), L);
+    if (L.misc + 64 - lds.data() > LDS_DOUBLES) { fprintf(stderr, "LDS carve overflow %ld > %d\n", (long)(L.misc + 64 - lds.data()), LDS_DOUBLES); return -2; }
+    std::barrier<> bar(64);
+    g_bar = &bar;
+    std::vector<std::thread> th;
+    for (int l = 0; l < 64; l++)
+        th.emplace_back([&, l] { t_lane = l; solve_instance(A, L, A.ws, 0, l); });
+    for (auto& t : th) t.join();
+    return 0;
+}
