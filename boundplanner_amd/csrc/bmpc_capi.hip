@@ -1,0 +1,264 @@
+// libboundmpc_hip.so: C ABI (include/boundmpc.h) + kernel launches for gfx950.
+#include "bmpc_platform_hip.hpp"
+
+#include "bmpc_solver.hpp"
+#include "bmpc_robot.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/boundmpc.h"
+
+using namespace bmpc;
+
+__global__ __launch_bounds__(64) void bmpc_solve_kernel(KernelArgs A) {
+    __shared__ double lds[LDS_DOUBLES];
+    Lds L;
+    lds_carve(lds, L);
+    const int lane = BMPC_LANE();
+    double* wsb = A.ws + (size_t)BMPC_BLOCK() * ws_doubles(A.o.N);
+    // one wavefront per instance; instances are dealt round-robin over the resident workgroups
+    for (int b = BMPC_BLOCK(); b < A.B; b += BMPC_NBLOCKS()) solve_instance(A, L, wsb, b, lane);
+}
+
+__global__ void bmpc_fk_kernel(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
+                               double* ee_rot, double* col_pts, double* jac, double* dvdq) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double qq[7], dd[7];
+    for (int j = 0; j < 7; j++) { qq[j] = q[(size_t)b * 7 + j]; dd[j] = dq ? dq[(size_t)b * 7 + j] : 0.0; }
+    Kin k;
+    double J[6][7], G[6][7], v[6];
+    kin_eval(rc, qq, k);
+    kin_jac(k, dd, J, G, v);
+    if (ee_pos) for (int a = 0; a < 3; a++) ee_pos[(size_t)b * 3 + a] = k.pee[a];
+    if (ee_rot) for (int a = 0; a < 9; a++) ee_rot[(size_t)b * 9 + a] = k.Ree[a];
+    if (col_pts) for (int c = 0; c < 6; c++) for (int a = 0; a < 3; a++) col_pts[(size_t)b * 18 + 3 * c + a] = k.pc[c][a];
+    if (jac) for (int a = 0; a < 6; a++) for (int j = 0; j < 7; j++) jac[(size_t)b * 42 + 7 * a + j] = J[a][j];
+    if (dvdq) for (int a = 0; a < 6; a++) for (int j = 0; j < 7; j++) dvdq[(size_t)b * 42 + 7 * a + j] = G[a][j];
+}
+
+struct bmpc_handle {
+    bmpc_opts o;
+    int n_w, n_g, n_cu, nblocks_max;
+    RobotConst* d_rc = nullptr;
+    double* d_ws = nullptr;
+    size_t ws_blocks = 0;
+    // staging for the host-pointer entry
+    double *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr, *d_x = nullptr, *d_g = nullptr,
+           *d_f = nullptr, *d_viol = nullptr;
+    int *d_iters = nullptr, *d_status = nullptr;
+    int cap = 0;
+    bool cap_g = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    std::string err;
+};
+
+#define HIPCHK(h, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
+    o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
+    o->hess = 0; o->hess_switch = 0.1; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
+    o->max_batch = 0; o->blocks_per_cu = 0;
+}
+
+extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
+    if (!o || !out) return 1;
+    *out = nullptr;
+    if (o->N < 3 || o->N > 64 || o->nr_segs != 4 || !(o->dt > 0)) return 1;
+    bmpc_handle* h = new bmpc_handle();
+    h->o = *o;
+    h->n_w = 44 * o->N + 6;
+    h->n_g = 147 * (o->N - 1) + 21;
+    *out = h;   // returned even on a HIP failure so that bmpc_last_error() can be read
+    int ndev = 0;
+    HIPCHK(h, hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { h->err = "no HIP device"; return 2; }
+    HIPCHK(h, hipSetDevice(o->device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, o->device));
+    h->n_cu = prop.multiProcessorCount;
+    int bpc = o->blocks_per_cu > 0 ? o->blocks_per_cu : 2;
+    h->nblocks_max = h->n_cu * bpc;
+    RobotConst rc;
+    fill_robot_const(rc);
+    HIPCHK(h, hipMalloc((void**)&h->d_rc, sizeof(RobotConst)));
+    HIPCHK(h, hipMemcpy(h->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
+    h->ws_blocks = (size_t)h->nblocks_max;
+    HIPCHK(h, hipMalloc((void**)&h->d_ws, h->ws_blocks * (size_t)ws_doubles(o->N) * sizeof(double)));
+    HIPCHK(h, hipStreamCreate(&h->stream));
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    return 0;
+}
+
+extern "C" void bmpc_destroy(bmpc_handle* h) {
+    if (!h) return;
+    double* bufs[] = {h->d_x0, h->d_lbx, h->d_ubx, h->d_p, h->d_x, h->d_g, h->d_f, h->d_viol, h->d_ws};
+    for (double* b : bufs) if (b) (void)hipFree(b);
+    if (h->d_iters) (void)hipFree(h->d_iters);
+    if (h->d_status) (void)hipFree(h->d_status);
+    if (h->d_rc) (void)hipFree(h->d_rc);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char* bmpc_last_error(const bmpc_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p) {
+    if (!h) return 1;
+    if (n_w) *n_w = h->n_w;
+    if (n_g) *n_g = h->n_g;
+    if (n_p) *n_p = NPAR;
+    return 0;
+}
+
+extern "C" int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg) {
+    if (!h || !lbg || !ubg) return 1;
+    const double INF = 1e20;
+    const int N = h->o.N;
+    int r = 0;
+    auto put = [&](int n, double lo, double hi) { for (int i = 0; i < n; i++) { lbg[r] = lo; ubg[r] = hi; r++; } };
+    put(35 * (N - 1), 0, 0);
+    for (int k = 1; k < N; k++) {
+        put(15, -INF, 0); put(3, -INF, 0); put(3, 0, INF); put(90, -INF, 0); put(1, -INF, 0);
+        if (k == N - 1) { put(15, -INF, 0); put(3, -INF, 0); put(3, 0, INF); }
+    }
+    return r == h->n_g ? 0 : 1;
+}
+
+static int launch(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
+                  const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
+                  double* d_viol, hipStream_t st) {
+    KernelArgs A;
+    A.B = B;
+    A.o = SolverOpts{h->o.N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,
+                     h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps};
+    A.rc = h->d_rc;
+    A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
+    A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
+    A.ws = h->d_ws;
+    int nblocks = B < h->nblocks_max ? B : h->nblocks_max;
+    if (nblocks < 1) return 0;
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    hipLaunchKernelGGL(bmpc_solve_kernel, dim3(nblocks), dim3(64), 0, st, A);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    return 0;
+}
+
+extern "C" int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
+                              const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
+                              int* d_iters, int* d_status, double* d_viol, void* stream) {
+    if (!h || B < 0 || !d_x0 || !d_lbx || !d_ubx || !d_p || !d_x || !d_f || !d_iters || !d_status || !d_viol) {
+        if (h) h->err = "bmpc_solve_dev: null argument";
+        return 1;
+    }
+    HIPCHK(h, hipSetDevice(h->o.device));
+    return launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, (hipStream_t)stream);
+}
+
+static int ensure_cap(bmpc_handle* h, int B, bool want_g) {
+    if (B <= h->cap && (!want_g || h->cap_g)) return 0;
+    int cap = B > h->cap ? B : h->cap;
+    if (h->o.max_batch > cap) cap = h->o.max_batch;
+    double** bufs[] = {&h->d_x0, &h->d_lbx, &h->d_ubx, &h->d_x};
+    for (double** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; HIPCHK(h, hipMalloc((void**)b, (size_t)cap * h->n_w * sizeof(double))); }
+    if (h->d_p) (void)hipFree(h->d_p);
+    HIPCHK(h, hipMalloc((void**)&h->d_p, (size_t)cap * NPAR * sizeof(double)));
+    if (h->d_f) (void)hipFree(h->d_f);
+    HIPCHK(h, hipMalloc((void**)&h->d_f, (size_t)cap * sizeof(double)));
+    if (h->d_viol) (void)hipFree(h->d_viol);
+    HIPCHK(h, hipMalloc((void**)&h->d_viol, (size_t)cap * sizeof(double)));
+    if (h->d_iters) (void)hipFree(h->d_iters);
+    HIPCHK(h, hipMalloc((void**)&h->d_iters, (size_t)cap * sizeof(int)));
+    if (h->d_status) (void)hipFree(h->d_status);
+    HIPCHK(h, hipMalloc((void**)&h->d_status, (size_t)cap * sizeof(int)));
+    if (h->d_g) { (void)hipFree(h->d_g); h->d_g = nullptr; }
+    h->cap_g = false;
+    if (want_g) { HIPCHK(h, hipMalloc((void**)&h->d_g, (size_t)cap * h->n_g * sizeof(double))); h->cap_g = true; }
+    h->cap = cap;
+    return 0;
+}
+
+extern "C" int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double* lbx, const double* ubx,
+                          const double* p, double* x, double* g, double* lam_g, double* lam_x, double* f,
+                          int* iters, int* status, double* viol) {
+    if (!h || B < 0 || !x0 || !lbx || !ubx || !p || !x || !f || !iters || !status || !viol) {
+        if (h) h->err = "bmpc_solve: null argument";
+        return 1;
+    }
+    if (B == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->o.device));
+    int rc = ensure_cap(h, B, g != nullptr);
+    if (rc) return rc;
+    size_t nw = (size_t)B * h->n_w * sizeof(double);
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_x0, x0, nw, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_lbx, lbx, nw, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_ubx, ubx, nw, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_p, p, (size_t)B * NPAR * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = launch(h, B, h->d_x0, h->d_lbx, h->d_ubx, h->d_p, h->d_x, g ? h->d_g : nullptr, h->d_f, h->d_iters,
+                h->d_status, h->d_viol, st);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(x, h->d_x, nw, hipMemcpyDeviceToHost, st));
+    if (g) HIPCHK(h, hipMemcpyAsync(g, h->d_g, (size_t)B * h->n_g * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(f, h->d_f, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(viol, h->d_viol, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(iters, h->d_iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(status, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (lam_g) memset(lam_g, 0, (size_t)B * h->n_g * sizeof(double));
+    if (lam_x) memset(lam_x, 0, (size_t)B * h->n_w * sizeof(double));
+    return 0;
+}
+
+extern "C" int bmpc_last_kernel_ms(bmpc_handle* h, float* ms) {
+    if (!h || !ms) return 1;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, h->ev0, h->ev1) == hipSuccess) h->last_ms = t;
+    *ms = h->last_ms;
+    return 0;
+}
+
+extern "C" int bmpc_fk(bmpc_handle* h, int B, const double* q, const double* dq, double* ee_pos,
+                       double* ee_rot, double* col_pts, double* jac, double* dvdq) {
+    if (!h || B < 0 || !q) { if (h) h->err = "bmpc_fk: null argument"; return 1; }
+    if (B == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->o.device));
+    double *d_q = nullptr, *d_dq = nullptr, *d_out = nullptr;
+    size_t per = 3 + 9 + 18 + 42 + 42;
+    HIPCHK(h, hipMalloc((void**)&d_q, (size_t)B * 7 * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&d_dq, (size_t)B * 7 * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&d_out, (size_t)B * per * sizeof(double)));
+    HIPCHK(h, hipMemcpy(d_q, q, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice));
+    if (dq) HIPCHK(h, hipMemcpy(d_dq, dq, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice));
+    else HIPCHK(h, hipMemset(d_dq, 0, (size_t)B * 7 * sizeof(double)));
+    double* o_pos = d_out; double* o_rot = o_pos + (size_t)B * 3; double* o_col = o_rot + (size_t)B * 9;
+    double* o_jac = o_col + (size_t)B * 18; double* o_dv = o_jac + (size_t)B * 42;
+    hipLaunchKernelGGL(bmpc_fk_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, B, h->d_rc, d_q, d_dq, o_pos,
+                       o_rot, o_col, o_jac, o_dv);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ee_pos) HIPCHK(h, hipMemcpy(ee_pos, o_pos, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (ee_rot) HIPCHK(h, hipMemcpy(ee_rot, o_rot, (size_t)B * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    if (col_pts) HIPCHK(h, hipMemcpy(col_pts, o_col, (size_t)B * 18 * sizeof(double), hipMemcpyDeviceToHost));
+    if (jac) HIPCHK(h, hipMemcpy(jac, o_jac, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
+    if (dvdq) HIPCHK(h, hipMemcpy(dvdq, o_dv, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_q); (void)hipFree(d_dq); (void)hipFree(d_out);
+    return 0;
+}

@@ -68,7 +68,7 @@ struct KernelArgs {
     double* ws;                         // scratch: nblocks * ws_doubles(N)
 };
 
-BMPC_INL int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32); }
+BMPC_HD int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32); }
 
 // ------------------------------------------------------------------------------------------
 // LDS carve-up (doubles)

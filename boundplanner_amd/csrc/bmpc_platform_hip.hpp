@@ -10,3 +10,4 @@
 #define BMPC_LANE() ((int)threadIdx.x)
 #define BMPC_BLOCK() ((int)blockIdx.x)
 #define BMPC_NBLOCKS() ((int)gridDim.x)
+#define BMPC_HD __host__ __device__ inline

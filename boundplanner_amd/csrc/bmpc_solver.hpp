@@ -24,6 +24,8 @@ BMPC_INL void ws_carve(double* b, int N, WsPtr& w) {
     w.K = b; b += N * NU * NX; w.kf = b;
 }
 
+BMPC_INL double sp_b(const double* sp, int off, int row, int stride, int col) { return sp[off + row * stride + col]; }
+
 // dynamics defect of stage k (needs zeta_k in L.zeta, zeta_{k+1} in L.znext, v in rc)
 BMPC_INL double defect_row(const Lds& L, const DynC& d, int i) {
     const double* z = L.zeta;
@@ -811,11 +813,45 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
                 if (r.kind && r.h > 1e-6) viol_l += r.h;
             }
             if (k < N - 1 && lane < NX) { double r = fabs(defect_row(L, dc, lane)); if (r > 1e-6 && lane < Z_D) viol_l += r; }
+            if (A.g) {
+                // constraint vector in the reference order (casadi_ocp_formulation.py:144-164, 304-380)
+                double* g = A.g + (size_t)b * (147 * (N - 1) + 21);
+                if (k < N - 1 && lane < 35) {
+                    double v = 0.0;
+                    if (lane < 21) v = defect_row(L, dc, lane);
+                    else if (lane >= 24 && lane < 27) v = defect_row(L, dc, Z_PI + lane - 24);
+                    else if (lane == 33) v = defect_row(L, dc, Z_RS);
+                    else if (lane == 34) v = defect_row(L, dc, Z_PS);
+                    g[35 * k + lane] = v;
+                }
+                double* gi = g + 35 * (N - 1) + 112 * (k - 1);
+                for (int m = 0; m < 4; m++) {
+                    int s = lane + 64 * m;
+                    if (s < S_EE || s >= S_END) continue;
+                    if (s >= S_TSET && k != N - 1) continue;
+                    Row r;
+                    row_eval(A, L, b, k, s, r);
+                    double v;
+                    bool lower = (s >= S_ROTL && s < S_COL) || (s >= S_TROTL);
+                    if (r.kind) v = lower ? -r.h : r.h;
+                    else if (s < S_ROTU) v = -sp_b(L.sp, P_BSET, s - S_EE, 4, (int)L.rc[RC_SEG]) - L.yz[Z_PS];
+                    else if (s < S_PHI) { int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c; v = -L.sp[P_BSETJ + rr * 6 + c] - L.rc[RC_SL + c]; }
+                    else v = -sp_b(L.sp, P_BSET, s - S_TSET, 4, (int)L.rc[RC_SEG + 1]) - L.rc[RC_SL + 5];
+                    gi[s - S_EE] = v;
+                }
+            }
             BMPC_SYNC();
             if (lane < NZ) L.znext[lane] = L.zeta[lane];
             BMPC_SYNC();
         }
         if (lane < 24) { double r = fabs(L.x1fix[lane] - L.zeta[lane]); if (r > 1e-6) viol_l += r; }
+        if (A.g && lane < 35) {
+            double* g = A.g + (size_t)b * (147 * (N - 1) + 21);
+            double v = 0.0;
+            if (lane < 21) v = L.x1fix[lane] - L.zeta[lane];
+            else if (lane >= 24 && lane < 27) v = L.x1fix[Z_PI + lane - 24] - L.zeta[Z_PI + lane - 24];
+            g[lane] = v;
+        }
     }
     double viol = wg_sum(viol_l, L.red, lane);
     if (lane == 0) {

@@ -1,0 +1,174 @@
+"""ctypes binding of libboundmpc_hip.so (C ABI: include/boundmpc.h) and the solver object that is
+call-compatible with the CasADi function used at BoundMPC.py:594-617.
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is visible, constructing a
+solver raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libboundmpc_hip.so")
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+class BmpcOpts(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int), ("nr_segs", ctypes.c_int), ("dt", ctypes.c_double),
+                ("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("device", ctypes.c_int),
+                ("hess", ctypes.c_int), ("hess_switch", ctypes.c_double), ("mu_init", ctypes.c_double),
+                ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
+                ("max_batch", ctypes.c_int), ("blocks_per_cu", ctypes.c_int)]
+
+
+EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
+           "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_fk", "bmpc_last_kernel_ms"]
+
+_lib = None
+
+
+def load_library():
+    """Load libboundmpc_hip.so (raises if it was not built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.bmpc_last_error.restype = ctypes.c_char_p
+        lib.bmpc_last_error.argtypes = [ctypes.c_void_p]
+        lib.bmpc_create.argtypes = [ctypes.POINTER(BmpcOpts), ctypes.POINTER(ctypes.c_void_p)]
+        lib.bmpc_destroy.argtypes = [ctypes.c_void_p]
+        lib.bmpc_dims.argtypes = [ctypes.c_void_p, _ip, _ip, _ip]
+        lib.bmpc_gbounds.argtypes = [ctypes.c_void_p, _dp, _dp]
+        lib.bmpc_solve.argtypes = [ctypes.c_void_p, ctypes.c_int] + [_dp] * 4 + [_dp] * 4 + [_dp, _ip, _ip, _dp]
+        lib.bmpc_solve_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_void_p]
+        lib.bmpc_fk.argtypes = [ctypes.c_void_p, ctypes.c_int] + [_dp] * 7
+        lib.bmpc_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        _lib = lib
+    return _lib
+
+
+def _P(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class HipBoundMPC:
+    """Owner of one C handle: batched solves + batched kinematics on one MI355X."""
+
+    def __init__(self, N, dt=0.1, tol=1e-5, max_iter=100, device=0, **kw):
+        lib = load_library()
+        o = BmpcOpts()
+        lib.bmpc_default_opts(ctypes.byref(o), N)
+        o.dt, o.tol, o.max_iter, o.device = dt, tol, max_iter, device
+        for k, v in kw.items():
+            setattr(o, k, v)
+        self._h = ctypes.c_void_p()
+        rc = lib.bmpc_create(ctypes.byref(o), ctypes.byref(self._h))
+        if rc != 0:
+            msg = lib.bmpc_last_error(self._h).decode() if self._h else "invalid options"
+            raise RuntimeError(f"bmpc_create failed ({rc}): {msg} -- the HIP path has no CPU fallback")
+        self.lib, self.N, self.opts = lib, N, o
+        nw, ng, npar = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib.bmpc_dims(self._h, ctypes.byref(nw), ctypes.byref(ng), ctypes.byref(npar))
+        self.n_w, self.n_g, self.n_p = nw.value, ng.value, npar.value
+        self.lbg, self.ubg = np.zeros(self.n_g), np.zeros(self.n_g)
+        lib.bmpc_gbounds(self._h, _P(self.lbg), _P(self.ubg))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.bmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.bmpc_last_error(self._h).decode()}")
+
+    def solve_batch(self, x0, lbx, ubx, p, want_g=False):
+        x0, lbx, ubx, p = (np.ascontiguousarray(np.atleast_2d(a), float) for a in (x0, lbx, ubx, p))
+        B = x0.shape[0]
+        assert x0.shape == (B, self.n_w) and lbx.shape == x0.shape and ubx.shape == x0.shape and p.shape == (B, self.n_p)
+        x = np.empty((B, self.n_w)); f = np.empty(B); viol = np.empty(B)
+        g = np.empty((B, self.n_g)) if want_g else None
+        iters = np.empty(B, np.int32); status = np.empty(B, np.int32)
+        rc = self.lib.bmpc_solve(self._h, B, _P(x0), _P(lbx), _P(ubx), _P(p), _P(x), _P(g), None, None, _P(f),
+                                 iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip), _P(viol))
+        self._chk(rc, "bmpc_solve")
+        return dict(x=x, g=g, f=f, iters=iters, status=status, viol=viol)
+
+    def solve_dev(self, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_f, d_iters, d_status, d_viol, d_g=0, stream=0):
+        """Raw device pointers (ints), asynchronous on `stream`."""
+        rc = self.lib.bmpc_solve_dev(self._h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g or None, d_f, d_iters, d_status,
+                                     d_viol, stream or None)
+        self._chk(rc, "bmpc_solve_dev")
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self.lib.bmpc_last_kernel_ms(self._h, ctypes.byref(ms))
+        return ms.value
+
+    def fk(self, q, dq=None):
+        q = np.ascontiguousarray(q, float).reshape(-1, 7)
+        B = q.shape[0]
+        dq = None if dq is None else np.ascontiguousarray(dq, float).reshape(-1, 7)
+        out = dict(ee_pos=np.empty((B, 3)), ee_rot=np.empty((B, 3, 3)), col_pts=np.empty((B, 6, 3)),
+                   jac=np.empty((B, 6, 7)), dvdq=np.empty((B, 6, 7)))
+        rc = self.lib.bmpc_fk(self._h, B, _P(q), _P(dq), _P(out["ee_pos"]), _P(out["ee_rot"]), _P(out["col_pts"]),
+                              _P(out["jac"]), _P(out["dvdq"]))
+        self._chk(rc, "bmpc_fk")
+        return out
+
+
+class _DM:
+    """Minimal stand-in for casadi.DM results: `.full()` and numpy conversion."""
+
+    def __init__(self, a):
+        self._a = np.asarray(a, float)
+
+    def full(self):
+        return self._a.reshape(-1, 1) if self._a.ndim == 1 else self._a
+
+    def __array__(self, dtype=None):
+        return self._a if dtype is None else self._a.astype(dtype)
+
+    def __float__(self):
+        return float(self._a)
+
+
+class HipNlpSolver:
+    """Call-compatible replacement of the CasADi nlpsol function object of BoundMPC.py:240-246:
+    sol = solver(x0=, lbx=, ubx=, lbg=, ubg=, p=) -> {"x","g","lam_g","lam_x","f"}; solver.stats()."""
+
+    def __init__(self, N, dt=0.1, backend=None, **kw):
+        self.backend = backend or HipBoundMPC(N, dt=dt, **kw)
+        self.lbg, self.ubg = self.backend.lbg, self.backend.ubg
+        self._stats = {}
+
+    def __call__(self, x0, lbx, ubx, p, lbg=None, ubg=None, **_):
+        inf2big = lambda a: np.nan_to_num(np.asarray(a, float), posinf=1e20, neginf=-1e20)
+        r = self.backend.solve_batch(np.asarray(x0, float)[None], inf2big(lbx)[None], inf2big(ubx)[None],
+                                     np.asarray(p, float)[None], want_g=True)
+        st = int(r["status"][0])
+        self._stats = {"iter_count": int(r["iters"][0]), "success": st == 0,
+                       "return_status": ["Solve_Succeeded", "Maximum_Iterations_Exceeded",
+                                         "Search_Direction_Becomes_Too_Small", "Error_In_Step_Computation"][st],
+                       "g_viol": float(r["viol"][0]), "t_kernel_ms": self.backend.last_kernel_ms()}
+        n_w, n_g = self.backend.n_w, self.backend.n_g
+        return {"x": _DM(r["x"][0]), "g": _DM(r["g"][0]), "f": _DM(r["f"][0]),
+                "lam_g": _DM(np.zeros(n_g)), "lam_x": _DM(np.zeros(n_w))}
+
+    def stats(self):
+        return dict(self._stats)
+
+
+def default_fk_fn():
+    """Batched kinematics backed by the HIP library (used by RobotModel when no backend is given)."""
+    be = HipBoundMPC(15)
+    return lambda q, dq=None: be.fk(q, dq)

@@ -1,0 +1,86 @@
+/*
+ * boundmpc.h -- C ABI of libboundmpc_hip.so, the MI355X-native drop-in for the NLP solve of
+ * BoundMPC's receding-horizon step.
+ *
+ * Reference interface replaced (all paths relative to /root/reference):
+ *   bound_planner/BoundMPC/BoundMPC.py:594-603    sol = self.solver(x0=w0, lbx=lbx, ubx=ubx,
+ *                                                 lbg=self.lbg, ubg=self.ubg, p=params)
+ *   bound_planner/BoundMPC/BoundMPC.py:604-617    sol["x"], sol["g"], solver.stats()
+ *   bound_planner/BoundMPC/BoundMPC.py:240-246    solver construction (setup_optimization_problem)
+ *   bound_planner/RobotModel/RobotModel.py:146-267 fk_pos, fk_pos_col, hom_transform_endeffector,
+ *                                                 jacobian_fk (the numeric Pinocchio path)
+ * Vector layouts are the reference's own: decision vector w (44N+6, variable-major/time-minor,
+ * casadi_ocp_formulation.py:89-101), parameter vector p (875, :383-415), constraint vector g
+ * (147(N-1)+21, :106-380).  All host arrays are row-major [instance][index], FP64.
+ *
+ * Plain C, plain pointers and sizes; no torch/HIP types in the signatures (the `_dev` entry
+ * takes a hipStream_t as void*).  A handle is not thread-safe; use one per host thread/stream.
+ * Return value: 0 on success, nonzero on API misuse or a HIP error (see bmpc_last_error).
+ */
+#ifndef BOUNDMPC_H
+#define BOUNDMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bmpc_handle bmpc_handle;
+
+typedef struct {
+    int N;              /* horizon; reference default 15 (utils/util_functions.py:49) */
+    int nr_segs;        /* must be 4 (utils/util_functions.py:49) */
+    double dt;          /* 0.1 */
+    double tol;         /* IPOPT "tol": 10e-6 = 1e-5 (BoundMPC.py:203) */
+    int max_iter;       /* IPOPT "max_iter": 100 (BoundMPC.py:204) */
+    int device;         /* HIP device ordinal */
+    int hess;           /* 0 Gauss-Newton Hessian, 2 hybrid (second-order kinematic terms) */
+    double hess_switch; /* hess==2: KKT error below which second-order terms are used */
+    double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule */
+    int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
+    int blocks_per_cu;  /* resident workgroups per CU (0 = default 2) */
+} bmpc_opts;
+
+void bmpc_default_opts(bmpc_opts* o, int N);
+
+/* replaces setup_optimization_problem(...) + nlpsol construction (BoundMPC.py:240-246) */
+int bmpc_create(const bmpc_opts* o, bmpc_handle** h);
+void bmpc_destroy(bmpc_handle* h);
+const char* bmpc_last_error(const bmpc_handle* h);
+
+/* n_w = 44N+6, n_g = 147(N-1)+21, n_p = 875 */
+int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p);
+
+/* constant constraint bounds (self.lbg / self.ubg, casadi_ocp_formulation.py:145-380);
+ * infinities are returned as +-1e20 */
+int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg);
+
+/* B independent solves = B calls of self.solver(...) (BoundMPC.py:594-603).  Host pointers.
+ * x0/lbx/ubx/x: [B][n_w]; p: [B][875]; g: [B][n_g] or NULL; lam_g/lam_x: NULL or zero-filled
+ * (multipliers are not produced yet); f/viol: [B]; iters/status: [B].
+ * status: 0 converged, 1 max_iter, 2 stalled, 3 numerical.  viol = sum of constraint
+ * violations exactly as BoundMPC.py:613-615, so the caller reproduces
+ * `success = stats["success"] or g_viol < 1e-4`.  Infinite bounds may be passed as +-inf or
+ * +-1e20. */
+int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double* lbx, const double* ubx,
+               const double* p, double* x, double* g, double* lam_g, double* lam_x, double* f,
+               int* iters, int* status, double* viol);
+
+/* Same with DEVICE pointers, asynchronous on `stream` (a hipStream_t); no host sync. */
+int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
+                   const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
+                   int* d_iters, int* d_status, double* d_viol, void* stream);
+
+/* Batched kinematics (RobotModel.py:146-267): ee_pos [B][3], ee_rot [B][9] row-major,
+ * col_pts [B][18] (joint_3..joint_7 origins, link4_col_link), jac [B][42] (6x7 geometric,
+ * LOCAL_WORLD_ALIGNED), dvdq [B][42] = d(J dq)/dq.  Host pointers; outputs may be NULL. */
+int bmpc_fk(bmpc_handle* h, int B, const double* q, const double* dq, double* ee_pos,
+            double* ee_rot, double* col_pts, double* jac, double* dvdq);
+
+/* Duration (ms) of the most recent solve kernel measured with HIP events on its stream
+ * (bmpc_solve: events around the launch; bmpc_solve_dev: caller must have synchronised). */
+int bmpc_last_kernel_ms(bmpc_handle* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -15,6 +15,7 @@ static std::barrier<>* g_bar = nullptr;
 static thread_local int t_lane = 0;
 #define BMPC_DEV
 #define BMPC_INL inline
+#define BMPC_HD inline
 #define BMPC_SYNC() g_bar->arrive_and_wait()
 #define BMPC_LANE() t_lane
 #define BMPC_BLOCK() 0

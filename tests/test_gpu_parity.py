@@ -1,0 +1,115 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def backends():
+    from boundplanner_amd.solver import HipBoundMPC
+    cache = {}
+
+    def get(N, **kw):
+        key = (N, tuple(sorted(kw.items())))
+        if key not in cache:
+            cache[key] = HipBoundMPC(N, **kw)
+        return cache[key]
+    return get
+
+
+def test_fk_matches_oracle(backends):
+    be = backends(10)
+    rng = np.random.default_rng(0)
+    q = rng.uniform(-2, 2, size=(257, 7)); dq = rng.normal(size=(257, 7))
+    a, b = be.fk(q, dq), O.fk_batch(q, dq)
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() < 1e-12, k
+
+
+def test_fk_matches_reference_tapes(backends, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "kin.npz"))
+    out = backends(10).fk(g["q"], g["dq"])
+    assert np.abs(out["ee_pos"] - g["fk_pos"]).max() < 1e-12
+    assert np.abs(out["col_pts"] - g["fk_pos_col"]).max() < 1e-12
+    assert np.abs(out["jac"] - g["jacobian"]).max() < 1e-12
+    assert np.abs(out["ee_rot"] - g["hom_trans"][:, :3, :3]).max() < 1e-12
+    assert np.abs(out["dvdq"] - g["dvdq"]).max() < 1e-11
+
+
+# tolerance: both sides run the same algorithm in FP64; differences come from summation order
+# and libm only, amplified by the iteration.  |dx|_inf <= 1e-6 on q,dq,ddq,p,v (rad, m) and the
+# same iteration count up to +-1 is the stated bar (1e-6 in FP64 mode).
+@pytest.mark.parametrize("N,seed,rnd,B", [(6, 6, True, 16), (10, 1024, False, 64), (20, 8192, True, 48)])
+def test_solve_matches_oracle(backends, N, seed, rnd, B):
+    from boundplanner_amd import scenes
+    be = backends(N)
+    batch = scenes.make_batch(B, N, seed, be.fk, randomize_sets=rnd)
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], hess=0, nthreads=0)
+    same = (r["status"] == ro["status"])
+    assert same.mean() > 0.97
+    conv = (r["status"] == 0) & (ro["status"] == 0)
+    assert conv.mean() > 0.9
+    assert np.abs(r["iters"][conv] - ro["iters"][conv]).max() <= 1
+    sel = np.r_[0:28 * N, 28 * N:40 * N]
+    assert np.abs(r["x"][conv][:, sel] - ro["x"][conv][:, sel]).max() < 1e-6
+    assert np.abs(r["f"][conv] - ro["f"][conv]).max() < 1e-6 * max(1.0, np.abs(ro["f"][conv]).max())
+    assert np.abs(r["viol"][conv] - ro["viol"][conv]).max() < 1e-8
+    # g returned by the kernel == the pinned full-space g evaluated at the returned x
+    for i in np.nonzero(conv)[0][:8]:
+        _, g, _, _ = O.nlp_eval(N, r["x"][i], batch["p"][i], jac=False)
+        assert np.abs(g - r["g"][i]).max() < 1e-9
+
+
+def test_split_index_variants_and_slacks0(backends):
+    from boundplanner_amd import scenes
+    N, B = 10, 12
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 77, be.fk, randomize_sets=True)
+    p = batch["p"].copy()
+    p[0::3, 0:5] = [0, 3, N, N, N]
+    p[1::3, 0:5] = [0, 2, 5, N, N]
+    p[:, 5:11] = [0.01, 0, 0.02, 0, 0, 0.005]
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], p)
+    ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], p, hess=0)
+    conv = (r["status"] == 0) & (ro["status"] == 0)
+    assert conv.sum() >= B - 2
+    assert np.abs(r["x"][conv][:, :40 * N] - ro["x"][conv][:, :40 * N]).max() < 1e-6
+
+
+def test_round_trip_properties_full_size(backends):
+    """Size-independent properties at a BASELINE size (N=20): returned points satisfy the pinned
+    constraints, re-solving from the solution is a fixed point, and a batch equals its halves."""
+    from boundplanner_amd import scenes
+    N, B = 20, 256
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 8192, be.fk, randomize_sets=True)
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    ok = r["status"] == 0
+    assert ok.mean() > 0.95
+    lbg, ubg = be.lbg, be.ubg
+    assert (r["g"][ok] <= ubg + 1e-4).all() and (r["g"][ok] >= lbg - 1e-4).all()
+    assert r["viol"][ok].max() < 1e-4
+    r2 = be.solve_batch(r["x"], batch["lbx"], batch["ubx"], batch["p"])
+    assert (r2["iters"][ok] <= r["iters"][ok]).mean() > 0.9
+    assert np.abs(r2["x"][ok][:, :28 * N] - r["x"][ok][:, :28 * N]).max() < 5e-3
+    h = B // 2
+    ra = be.solve_batch(batch["x0"][:h], batch["lbx"][:h], batch["ubx"][:h], batch["p"][:h])
+    assert np.array_equal(ra["x"], r["x"][:h])      # instance results do not depend on the batch
+
+
+def test_nlpsolver_object_matches_reference_call_convention(backends):
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipNlpSolver
+    N = 10
+    be = backends(N)
+    batch = scenes.make_batch(1, N, 5, be.fk)
+    s = HipNlpSolver(N, backend=be)
+    sol = s(x0=batch["x0"][0], lbx=batch["lbx"][0], ubx=batch["ubx"][0], lbg=s.lbg, ubg=s.ubg, p=batch["p"][0])
+    st = s.stats()
+    assert st["success"] and st["iter_count"] > 0 and st["return_status"] == "Solve_Succeeded"
+    assert sol["x"].full().shape == (44 * N + 6, 1) and sol["g"].full().shape == (147 * (N - 1) + 21, 1)
