@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched BoundMPC NLP solves on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-gather of the solutions)
+
+One "step" = one pass of the hot path over one batch of synthetic problem instances:
+BASELINE.json configs[2] -- 8192 instances per GPU, randomized convex-set obstacles, horizon
+N = 20, iiwa14 (SURVEY.md 8(d) generator, seed 8192 + rank).  Inputs are resident in HBM when the
+timed region starts (bmpc_solve_dev with device pointers).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HORIZON = 20
+BATCH_PER_GPU = 8192
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VEC_PEAK_TFLOPS = 78.6    # vector FP64 peak (spec); the binding resource of this kernel
+
+
+def alg_bytes_per_solve(N):
+    # read x0 + write x + read p + read state0
+    return 8 * (2 * (44 * N + 6) + 875 + 40)
+
+
+def alg_flops_per_solve(N, iters):
+    # iters * N * F_stage, F_stage = 1.2e5 (condensed stage n_x=26, n_u=9)
+    return iters * N * 1.2e5
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=HORIZON)
+    ap.add_argument("--hess", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+
+    N, B = args.horizon, args.batch
+    kw = {} if args.hess is None else {"hess": args.hess}
+    be = HipBoundMPC(N, device=local_rank, **kw)
+    t0 = time.time()
+    batch = scenes.make_batch(B, N, 8192 + rank, be.fk, randomize_sets=True)
+    t_gen = time.time() - t0
+    big = lambda a: np.nan_to_num(a, posinf=1e20, neginf=-1e20)
+    d = {k: torch.from_numpy(big(batch[k])).to(dev) for k in ("x0", "lbx", "ubx", "p")}
+    n_w = be.n_w
+    x = torch.empty((B, n_w), dtype=torch.float64, device=dev)
+    f = torch.empty(B, dtype=torch.float64, device=dev)
+    viol = torch.empty(B, dtype=torch.float64, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    gathered = torch.empty((world * B, n_w), dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        be.solve_dev(B, d["x0"].data_ptr(), d["lbx"].data_ptr(), d["ubx"].data_ptr(), d["p"].data_ptr(),
+                     x.data_ptr(), f.data_ptr(), iters.data_ptr(), status.data_ptr(), viol.data_ptr(),
+                     stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, x)     # RCCL over xGMI: solutions of every shard
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if args.steps <= 16:       # HIP-event duration of the solve kernel on its own stream
+            torch.cuda.synchronize(dev)
+            kernel_ms.append(be.last_kernel_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if not kernel_ms:
+        kernel_ms = [be.last_kernel_ms()]
+
+    it_np, st_np, viol_np = iters.cpu().numpy(), status.cpu().numpy(), viol.cpu().numpy()
+    ok = (st_np == 0) | (viol_np < 1e-4)            # the reference's acceptance test (BoundMPC.py:617)
+    total_solves = world * B * args.steps
+    value = total_solves / elapsed
+    k_ms = float(np.mean(kernel_ms))
+    ach_gbs = alg_bytes_per_solve(N) * B / (k_ms * 1e-3) / 1e9
+    mean_it = float(it_np.mean())
+    ach_tf = alg_flops_per_solve(N, mean_it) * B / (k_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "MPC solves/sec (whole node), iiwa14 7-DOF, N=20",
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {B}-batch per GPU, randomized convex-set obstacles, N={N}, "
+                               "cold start, tol 1e-5, max_iter 100", "batch_per_gpu": B, "horizon": N,
+                   "sharding": "independent instances per rank + RCCL all-gather of x" if world > 1 else "single GPU",
+                   "hess": int(be.opts.hess)},
+        "solver": {"iters_mean": mean_it, "iters_p50": float(np.median(it_np)), "iters_p99": float(np.percentile(it_np, 99)),
+                   "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
+                   "accepted_frac": float(ok.mean()), "gen_s": t_gen},
+        "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "bmpc_solve_kernel",
+                     "kernel_ms": k_ms, "alg_bytes_per_solve": alg_bytes_per_solve(N),
+                     "note": "not HBM- or MFMA-bound: latency/VALU/LDS-bound small-matrix IP loop (DESIGN.md); "
+                             "the meaningful limiter is FP64 VALU, reported in valu_fp64"},
+        "valu_fp64": {"achieved": ach_tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": ach_tf / FP64_VEC_PEAK_TFLOPS, "alg_flops_per_solve": alg_flops_per_solve(N, mean_it)},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle_lib as O               # cpu_baseline leg only
+        cores = len(os.sched_getaffinity(0))
+        nthr = min(cores, 64)
+        ns = min(B, 4 * nthr)
+        hess = int(be.opts.hess)
+        t0 = time.perf_counter()
+        ro = O.solve_batch(N, batch["x0"][:ns], batch["lbx"][:ns], batch["ubx"][:ns], batch["p"][:ns],
+                           nthreads=nthr, hess=hess)
+        tc = time.perf_counter() - t0
+        x_gpu = x[:ns].cpu().numpy()
+        both = (ro["status"] == 0) & (st_np[:ns] == 0)
+        out["cpu_baseline"] = {
+            "value": ns / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
+            "sample": f"first {ns} instances of the same batch, oracle/bmpc_solve.c (same algorithm, FP64, -O2, "
+                      f"OpenMP over instances) on {nthr} host threads in {tc:.1f} s; the reference's CasADi+IPOPT "
+                      "cannot run here (no wheel, no network)",
+            "iters_mean": float(ro["iters"].mean()),
+            "max_abs_dx_vs_gpu": float(np.abs(ro["x"][both][:, :40 * N] - x_gpu[both][:, :40 * N]).max()) if both.any() else None,
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

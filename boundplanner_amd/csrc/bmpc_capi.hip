@@ -69,7 +69,7 @@ struct bmpc_handle {
 
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
-    o->hess = 0; o->hess_switch = 0.1; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
+    o->hess = 2; o->hess_switch = 0.1; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
     o->max_batch = 0; o->blocks_per_cu = 0;
 }
 

@@ -77,7 +77,7 @@ BMPC_DEV void chol9_solve(const double* Lc, double* b) {
 // two right-hand sides (g = g0 + mu g1).  Returns false if a control block is not PD.
 // ------------------------------------------------------------------------------------------
 BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
-                             double ad_pend, const double* iw0, double reg, double hreg, Kkt& kk) {
+                             double ad_pend, const double* iw0, double reg, double hreg, int hess_mode, Kkt& kk) {
     const int N = A.o.N;
     const double* sp = L.sp;
     const double* wts = sp + P_W;
@@ -279,6 +279,80 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
+        // ---- second-order kinematic terms of the Lagrangian Hessian (hybrid mode) ----
+        if (hess_mode) {
+            if (lane < 27) {   // generalised forces: on p_ee (3), on v (6), on the 6 collision points (18)
+                double v;
+                if (lane < 3) v = L.bpz[lane];
+                else if (lane < 9) {
+                    int a = lane - 3;
+                    v = L.bv[a];
+                    if (a >= 3) { v += 0.5 * dc.dt * L.bpz[a]; if (!term) v += dc.dt * L.lam[Z_PI + a - 3]; }
+                } else v = L.b3z[lane - 9];
+                L.misc[lane] = v;
+            }
+            BMPC_SYNC();
+            const int njc[6] = {2, 3, 4, 5, 6, 4};
+            for (int e = lane; e < 98; e += 64) {
+                const double* Fp = L.misc; const double* Fv = L.misc + 3; const double* Fc = L.misc + 9;
+                if (e < 49) {          // q_a x q_b
+                    int a = e / 7, bq = e % 7, m = a < bq ? a : bq, M = a < bq ? bq : a;
+                    double zm[3] = {L.zax[3 * m], L.zax[3 * m + 1], L.zax[3 * m + 2]};
+                    double cM[3] = {L.J[M], L.J[7 + M], L.J[14 + M]}, zc[3];
+                    cross3(zm, cM, zc);
+                    double acc = dot3(Fp, zc);
+                    for (int c = 0; c < 6; c++)
+                        if (M < njc[c]) {
+                            double cc[3] = {L.Jp[21 * c + M], L.Jp[21 * c + 7 + M], L.Jp[21 * c + 14 + M]};
+                            cross3(zm, cc, zc);
+                            acc += dot3(Fc + 3 * c, zc);
+                        }
+                    // q-q block of the v = J(q) dq curvature (third-order kinematics times dq)
+                    for (int j = 0; j < 7; j++) {
+                        double dqj = L.yz[Z_DQ + j];
+                        if (dqj == 0.0) continue;
+                        int m1 = a < j ? a : j, M1 = a < j ? j : a;
+                        double z1[3] = {L.zax[3 * m1], L.zax[3 * m1 + 1], L.zax[3 * m1 + 2]};
+                        double c1[3] = {L.J[M1], L.J[7 + M1], L.J[14 + M1]};
+                        double t1[3] = {0, 0, 0}, t2[3], dzm[3], dcM[3];
+                        if (bq < m1) { double zb[3] = {L.zax[3 * bq], L.zax[3 * bq + 1], L.zax[3 * bq + 2]}; cross3(zb, z1, dzm); cross3(dzm, c1, t1); }
+                        int m2 = bq < M1 ? bq : M1, M2 = bq < M1 ? M1 : bq;
+                        double z2[3] = {L.zax[3 * m2], L.zax[3 * m2 + 1], L.zax[3 * m2 + 2]};
+                        double c2[3] = {L.J[M2], L.J[7 + M2], L.J[14 + M2]};
+                        cross3(z2, c2, dcM);
+                        cross3(z1, dcM, t2);
+                        double lin = Fv[0] * (t1[0] + t2[0]) + Fv[1] * (t1[1] + t2[1]) + Fv[2] * (t1[2] + t2[2]);
+                        double ang = 0;
+                        if (a < j) {
+                            double za[3] = {L.zax[3 * a], L.zax[3 * a + 1], L.zax[3 * a + 2]};
+                            double zj[3] = {L.zax[3 * j], L.zax[3 * j + 1], L.zax[3 * j + 2]};
+                            double zb[3] = {L.zax[3 * bq], L.zax[3 * bq + 1], L.zax[3 * bq + 2]};
+                            double u1[3] = {0, 0, 0}, u2[3] = {0, 0, 0}, tmp[3];
+                            if (bq < a) { cross3(zb, za, tmp); cross3(tmp, zj, u1); }
+                            if (bq < j) { cross3(zb, zj, tmp); cross3(za, tmp, u2); }
+                            ang = Fv[3] * (u1[0] + u2[0]) + Fv[4] * (u1[1] + u2[1]) + Fv[5] * (u1[2] + u2[2]);
+                        }
+                        acc += dqj * (lin + ang);
+                    }
+                    L.W[(Z_Q + a) * LDW + Z_Q + bq] += acc;
+                } else {               // q_i x dq_j  (d2 v / dq_i d dq_j = dJ[:, j]/dq_i)
+                    int i = (e - 49) / 7, j = (e - 49) % 7, m = i < j ? i : j, M = i < j ? j : i;
+                    double zm[3] = {L.zax[3 * m], L.zax[3 * m + 1], L.zax[3 * m + 2]};
+                    double cM[3] = {L.J[M], L.J[7 + M], L.J[14 + M]}, zc[3];
+                    cross3(zm, cM, zc);
+                    double acc = dot3(Fv, zc);
+                    if (i < j) {
+                        double zi[3] = {L.zax[3 * i], L.zax[3 * i + 1], L.zax[3 * i + 2]};
+                        double zj[3] = {L.zax[3 * j], L.zax[3 * j + 1], L.zax[3 * j + 2]}, zz[3];
+                        cross3(zi, zj, zz);
+                        acc += dot3(Fv + 3, zz);
+                    }
+                    L.W[(Z_Q + i) * LDW + Z_DQ + j] += acc;
+                    L.W[(Z_DQ + j) * LDW + Z_Q + i] += acc;
+                }
+            }
+            BMPC_SYNC();
+        }
         // ---- direct quadratic cost terms (natural coordinates) ----
         if (lane < 20) {
             int pos; double w2; double val; double extra = 0;
@@ -714,11 +788,14 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
     int nfilt = 0;
     double ad_pend = 0.0, reg = 1e-9, hreg = 0.0;
     Kkt kk;
+    double err_prev = 1e300;
     for (it = 0;; it++) {
-        bool ok = backward_sweep(A, L, ws, dc, b, lane, ad_pend, iw0, reg, hreg, kk);
+        int hess_mode = (o.hess == 2 && err_prev < o.hess_switch) ? 1 : 0;
+        bool ok = backward_sweep(A, L, ws, dc, b, lane, ad_pend, iw0, reg, hreg, hess_mode, kk);
         ad_pend = 0.0;
         if (kk.err <= o.tol && kk.dual <= 1.0 && kk.prim <= 1e-4 && kk.compl_ <= 1e-4) { st = 0; break; }
         if (it >= o.max_iter) { st = 1; break; }
+        err_prev = kk.err;
         // monotone Fiacco-McCormick barrier update (oracle: mu_strategy 1)
         {
             double emu = fmax(fmax(kk.dual / kk.sd, kk.prim), fmax(fabs(kk.compl_ - mu), fabs(kk.minc - mu)) / kk.sc);
@@ -732,9 +809,12 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
         for (;;) {
             if (ok) { forward_sweep(A, L, ws, dc, b, lane, mu, iw0, si); ok = si.ok; }
             if (ok) break;
-            hreg = (hreg == 0.0) ? 1e-4 : hreg * 8;
-            if (++tries > 12) { st = 3; break; }
-            ok = backward_sweep(A, L, ws, dc, b, lane, 0.0, iw0, reg, hreg, kk);
+            if (hess_mode) { hess_mode = 0; ++tries; }        // second-order terms not convex here: Gauss-Newton
+            else {
+                hreg = (hreg == 0.0) ? 1e-4 : hreg * 8;       // inertia correction (IPOPT delta_w)
+                if (++tries > 12) { st = 3; break; }
+            }
+            ok = backward_sweep(A, L, ws, dc, b, lane, 0.0, iw0, reg, hreg, hess_mode, kk);
         }
         if (st == 3) break;
         if (tries == 0) hreg = (hreg < 1e-8) ? 0.0 : hreg / 3;

@@ -960,7 +960,7 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
     int nfilt = 0;
     kkt_t kk;
     memset(&kk, 0, sizeof kk);
-    double reg = 1e-9;
+    double reg = 1e-9, err_prev = 1e300;
     for (it = 0;; it++) {
         /* gdual needs current z: assemble with a provisional mu (only H,g depend on mu) */
         for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
@@ -997,7 +997,7 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
         if (o->hess == 2) {
             /* hybrid: Gauss-Newton far from the solution, second-order kinematic terms once the
              * optimality error is small; fall back to Gauss-Newton when that is not convex */
-            int want = (kk.err < o->hess_switch);
+            int want = (err_prev < o->hess_switch);   /* error of the PREVIOUS iterate (fused-sweep friendly) */
             if (want != pb.hess) {
                 pb.hess = want;
                 for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
@@ -1103,6 +1103,7 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
             /* eval_stage rebuilds rows (same order) but must keep t,z */
             eval_stage(&pb, k, 0);
         }
+        err_prev = kk.err;
         if (o->verbose > 1) printf("      alpha_p %.3g (ftb %.3g) alpha_d %.3g ls_ok %d nu %.2e D %.2e th %.2e hreg %.1e tries %d\n", alpha, ap, ad, ls_ok, nu, D, th0, pb.hreg, tries);
     }
 done:
