@@ -16,11 +16,19 @@ using namespace bmpc;
 __global__ __launch_bounds__(64) void bmpc_solve_kernel(KernelArgs A) {
     __shared__ double lds[LDS_DOUBLES];
     Lds L;
-    lds_carve(lds, L);
+    lds_carve((LDSD*)lds, L);
     const int lane = BMPC_LANE();
     double* wsb = A.ws + (size_t)BMPC_BLOCK() * ws_doubles(A.o.N);
-    // one wavefront per instance; instances are dealt round-robin over the resident workgroups
-    for (int b = BMPC_BLOCK(); b < A.B; b += BMPC_NBLOCKS()) solve_instance(A, L, wsb, b, lane);
+    // one wavefront per instance; resident workgroups pull the next instance from a device-scope
+    // counter (iteration counts vary 7..100, so a static deal leaves most CUs idle at the tail)
+    for (;;) {
+        if (lane == 0) L.misc[63] = (double)BMPC_ATOMIC_INC(A.counter);
+        BMPC_SYNC();
+        int b = (int)L.misc[63];
+        BMPC_SYNC();
+        if (b >= A.B) break;
+        solve_instance(A, L, wsb, b, lane);
+    }
 }
 
 __global__ void bmpc_fk_kernel(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
@@ -45,6 +53,7 @@ struct bmpc_handle {
     int n_w, n_g, n_cu, nblocks_max;
     RobotConst* d_rc = nullptr;
     double* d_ws = nullptr;
+    int* d_counter = nullptr;
     size_t ws_blocks = 0;
     // staging for the host-pointer entry
     double *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr, *d_x = nullptr, *d_g = nullptr,
@@ -89,7 +98,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, o->device));
     h->n_cu = prop.multiProcessorCount;
-    int bpc = o->blocks_per_cu > 0 ? o->blocks_per_cu : 2;
+    int bpc = o->blocks_per_cu > 0 ? o->blocks_per_cu : 3;
     h->nblocks_max = h->n_cu * bpc;
     RobotConst rc;
     fill_robot_const(rc);
@@ -97,6 +106,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     HIPCHK(h, hipMemcpy(h->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
     h->ws_blocks = (size_t)h->nblocks_max;
     HIPCHK(h, hipMalloc((void**)&h->d_ws, h->ws_blocks * (size_t)ws_doubles(o->N) * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_counter, sizeof(int)));
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -110,6 +120,7 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_rc) (void)hipFree(h->d_rc);
+    if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -151,8 +162,10 @@ static int launch(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx
     A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
     A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
     A.ws = h->d_ws;
+    A.counter = h->d_counter;
     int nblocks = B < h->nblocks_max ? B : h->nblocks_max;
     if (nblocks < 1) return 0;
+    HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), st));
     HIPCHK(h, hipEventRecord(h->ev0, st));
     hipLaunchKernelGGL(bmpc_solve_kernel, dim3(nblocks), dim3(64), 0, st, A);
     HIPCHK(h, hipGetLastError());

@@ -37,6 +37,9 @@ constexpr int P_SPLIT = 0, P_SLACKS0 = 5, P_IWREF = 11, P_DTAU = 14, P_DTAU_PAR 
               P_PREF = 88, P_DPREF = 112, P_DPN = 136, P_BP1 = 148, P_BP2 = 160, P_BR1 = 172,
               P_BR2 = 184, P_ERB = 196, P_W = 220, P_PHIMAX = 231, P_V1 = 232, P_V2 = 244,
               P_V3 = 256, P_ASET = 275, P_BSET = 455, P_ASETJ = 515, P_BSETJ = 785, NPAR = 875;
+// LDS copy of the parameter vector: [0,275) verbatim, then a_set_joints (270) and b_set_joints (90);
+// the EE sets a_set/b_set stay in global memory (read by two row slots per stage only)
+constexpr int SP_ASETJ = 275, SP_BSETJ = 545, NSP = 635;
 
 // row slots
 constexpr int S_BOX = 0, S_NONNEG = 56, S_RS1 = 60, S_D1 = 62, S_EE = 68, S_ROTU = 83, S_ROTL = 86,
@@ -66,6 +69,7 @@ struct KernelArgs {
     double *x, *f, *viol, *g;           // [B][n_w], [B], [B], [B][n_g] or null
     int *iters, *status;
     double* ws;                         // scratch: nblocks * ws_doubles(N)
+    int* counter;                       // next instance to hand out (zeroed before every launch)
 };
 
 BMPC_HD int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32); }
@@ -74,28 +78,28 @@ BMPC_HD int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32)
 // LDS carve-up (doubles)
 // ------------------------------------------------------------------------------------------
 struct Lds {
-    double *P, *W, *sp, *zeta, *znext, *yz, *g0, *g1, *gz, *lam, *pv0, *pv1, *vt0, *vt1, *rdef,
+    LDSD *P, *W, *sp, *zeta, *znext, *yz, *g0, *g1, *gz, *lam, *pv0, *pv1, *vt0, *vt1, *rdef,
         *J, *G, *Jp, *zax, *pc, *Op, *Ov, *T1, *T2, *Hp, *Hv, *mS, *sS, *bp0, *bp1, *bpz, *bv,
         *bS0, *bS1, *bSz, *M3, *mc, *sc, *b30, *b31, *b3z, *bc0, *bc1, *bcz, *rowS, *rowA, *rowSl,
-        *rc, *Kl, *kf, *Y, *Et, *red, *dx, *dxn, *dloc, *dpt, *x1fix, *r0, *misc;
+        *rc, *Kl, *kf, *Y, *Et, *red, *dx, *dxn, *dloc, *dpt, *x1fix, *r0, *misc, *kin;
 };
 constexpr int LDS_DOUBLES =
-    NX * LDP + NZ * LDW + NPAR + 2 * ZPAD + ZPAD +            // P W sp zeta znext yz
-    3 * ZPAD + 5 * NX + 2 * NX + NX +                         // g0 g1 gz | lam pv0 pv1 vt0 vt1 | rdef..
+    NX * LDP + NZ * LDW + NSP + 2 * ZPAD + ZPAD +             // P W sp zeta znext yz
+    3 * ZPAD + 5 * NX + NX +                                  // g0 g1 gz | lam pv0 pv1 vt0 vt1 | rdef
     42 + 42 + 126 + 21 + 18 +                                 // J G Jp zax pc
     4 * 102 + 36 + 36 + 18 + 3 + 18 + 6 + 9 +                 // Op Ov T1 T2 Hp Hv mS sS bp* bv bS*
     54 + 18 + 6 + 54 + 18 +                                   // M3 mc sc b3* bc*
     4 * NSLOT + NPOSE * 6 + NPOSE +                           // rowS rowA rowSl
-    160 + NU * NX + 32 + NZ * 3 + 3 * NZ + 64 +               // rc Kl kf Y Et red
-    2 * NX + 16 + 24 + 24 + NX + 64;                          // dx dxn dloc dpt x1fix r0 misc
+    160 + 32 + 64 +                                           // rc kf red (Kl aliases Op..T2, Y/Et alias rowA)
+    2 * NX + 16 + 24 + 24 + NX + 64 + 160;                    // dx dxn dloc dpt x1fix r0 misc kin
 
-BMPC_INL void lds_carve(double* b, Lds& L) {
-    auto take = [&](int n) { double* r = b; b += n; return r; };
-    L.P = take(NX * LDP); L.W = take(NZ * LDW); L.sp = take(NPAR);
+BMPC_INL void lds_carve(LDSD* b, Lds& L) {
+    auto take = [&](int n) { LDSD* r = b; b += n; return r; };
+    L.P = take(NX * LDP); L.W = take(NZ * LDW); L.sp = take(NSP);
     L.zeta = take(ZPAD); L.znext = take(ZPAD); L.yz = take(ZPAD);
     L.g0 = take(ZPAD); L.g1 = take(ZPAD); L.gz = take(ZPAD);
     L.lam = take(NX); L.pv0 = take(NX); L.pv1 = take(NX); L.vt0 = take(NX); L.vt1 = take(NX);
-    L.rdef = take(NX); take(2 * NX);
+    L.rdef = take(NX);
     L.J = take(42); L.G = take(42); L.Jp = take(126); L.zax = take(21); L.pc = take(18);
     L.Op = take(102); L.Ov = take(102); L.T1 = take(102); L.T2 = take(102);
     L.Hp = take(36); L.Hv = take(36); L.mS = take(18); L.sS = take(3);
@@ -105,16 +109,19 @@ BMPC_INL void lds_carve(double* b, Lds& L) {
     L.b30 = take(18); L.b31 = take(18); L.b3z = take(18);
     L.bc0 = take(6); L.bc1 = take(6); L.bcz = take(6);
     L.rowS = take(4 * NSLOT); L.rowA = take(NPOSE * 6); L.rowSl = take(NPOSE);
-    L.rc = take(160); L.Kl = take(NU * NX); L.kf = take(32); L.Y = take(NZ * 3); L.Et = take(3 * NZ);
+    L.rc = take(160); L.kf = take(32);
+    L.Kl = L.Op;          // gains are written after the chain phases are done with Op/Ov/T1/T2 (408 >= 288)
+    L.Y = L.rowA;         // coupling scratch reuses the pose-row gradients (301 >= 246)
+    L.Et = L.rowA + NZ * 3;
     L.red = take(64); L.dx = take(NX); L.dxn = take(NX); L.dloc = take(16); L.dpt = take(24);
-    L.x1fix = take(24); L.r0 = take(NX); L.misc = take(64);
+    L.x1fix = take(24); L.r0 = take(NX); L.misc = take(64); L.kin = take(160);
 }
 
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
-BMPC_INL double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-BMPC_INL void cross3(const double* a, const double* b, double* c) {
+template <class PA, class PB> BMPC_INL double dot3(PA a, PB b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class PA, class PB> BMPC_INL void cross3(PA a, PB b, double* c) {
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
     c[2] = a[0] * b[1] - a[1] * b[0];
@@ -128,19 +135,19 @@ BMPC_INL void mat3vec(const double* A, const double* v, double* r) {
 }
 
 // workgroup-wide reductions through LDS (fixed summation order -> reproducible)
-BMPC_DEV double wg_sum(double v, double* red, int lane) {
+BMPC_DEV double wg_sum(double v, LDSD* red, int lane) {
     BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
     double s = 0;
     for (int i = 0; i < 64; i++) s += red[i];
     return s;
 }
-BMPC_DEV double wg_max(double v, double* red, int lane) {
+BMPC_DEV double wg_max(double v, LDSD* red, int lane) {
     BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
     double s = red[0];
     for (int i = 1; i < 64; i++) s = fmax(s, red[i]);
     return s;
 }
-BMPC_DEV double wg_min(double v, double* red, int lane) {
+BMPC_DEV double wg_min(double v, LDSD* red, int lane) {
     BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
     double s = red[0];
     for (int i = 1; i < 64; i++) s = fmin(s, red[i]);
@@ -158,49 +165,6 @@ BMPC_INL int phi_col(int c, const DynC& d, int* idx, double* cf) {
     if (c < Z_DRS) { int j = c - Z_U; idx[0] = Z_Q + j; cf[0] = d.b3; idx[1] = Z_DQ + j; cf[1] = d.b2; idx[2] = Z_DDQ + j; cf[2] = d.b1; return 3; }
     if (c == Z_DRS) { idx[0] = Z_RS; cf[0] = d.dt; return 1; }
     idx[0] = Z_PS; cf[0] = d.dt; return 1;
-}
-
-// ------------------------------------------------------------------------------------------
-// per-stage context computed redundantly by every lane (registers)
-// ------------------------------------------------------------------------------------------
-struct Seg {
-    int s, n;
-    double dp[6], pref[6], phi_start, phi_end_seg;
-    double dpn[3], dpnn[3], bp1[3], bp2[3], br1[3], br2[3], br1n[3], br2n[3];
-    double v1[3], v2[3], v3[3], e_init[3], e_par0[3], e_o10[3], e_o20[3], iwref0[3];
-    double ub[3], lb[3], ubn[3], lbn[3], p_end[3], jl[9], jr[9];
-};
-
-#define TABP(off, seg, c) sp[(off) + (c) * 4 + (seg)]
-
-BMPC_DEV void seg_ctx(int N, const double* sp, int k, Seg& sc) {
-    // bound_mpc_functions.py:49-82 (segment selection), :85-253, :256-390
-    int s = 0;
-    if ((double)k > sp[P_SPLIT + 1]) s = 1;
-    if ((double)k > sp[P_SPLIT + 2]) s = 2;
-    int n = (sp[P_SPLIT + 1] == (double)N) ? 1 : ((sp[P_SPLIT + 2] == (double)N) ? 2 : 3);
-    sc.s = s; sc.n = n;
-    for (int c = 0; c < 6; c++) { sc.dp[c] = TABP(P_DPREF, s, c); sc.pref[c] = TABP(P_PREF, s, c); }
-    sc.phi_start = sp[P_PHISW + s];
-    sc.phi_end_seg = sp[P_PHISW + n];
-    bool iw_param = ((double)k <= sp[P_SPLIT + 1]);
-    for (int c = 0; c < 3; c++) {
-        sc.dpn[c] = TABP(P_DPN, s, c);   sc.dpnn[c] = TABP(P_DPN, s + 1, c);
-        sc.bp1[c] = TABP(P_BP1, s, c);   sc.bp2[c] = TABP(P_BP2, s, c);
-        sc.br1[c] = TABP(P_BR1, s, c);   sc.br2[c] = TABP(P_BR2, s, c);
-        sc.br1n[c] = TABP(P_BR1, s + 1, c); sc.br2n[c] = TABP(P_BR2, s + 1, c);
-        sc.v1[c] = TABP(P_V1, s, c); sc.v2[c] = TABP(P_V2, s, c); sc.v3[c] = TABP(P_V3, s, c);
-        sc.e_init[c] = sp[P_DTAU + 3 * s + c];
-        sc.e_par0[c] = sp[P_DTAU_PAR + 3 * s + c];
-        sc.e_o10[c] = sp[P_DTAU_O1 + 3 * s + c];
-        sc.e_o20[c] = sp[P_DTAU_O2 + 3 * s + c];
-        sc.ub[c] = TABP(P_ERB, s, c);     sc.lb[c] = TABP(P_ERB, s, 3 + c);
-        sc.ubn[c] = TABP(P_ERB, s + 1, c); sc.lbn[c] = TABP(P_ERB, s + 1, 3 + c);
-        sc.p_end[c] = TABP(P_PREF, s + 1, c);
-        sc.iwref0[c] = iw_param ? sp[P_IWREF + c] : sc.pref[3 + c];
-    }
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) { sc.jr[3 * r + c] = sp[P_JACR + 3 * c + r]; sc.jl[3 * r + c] = sp[P_JACL + 3 * c + r]; }
 }
 
 struct Kin {
@@ -261,149 +225,22 @@ BMPC_DEV void kin_jac(const Kin& k, const double* dq, double J[6][7], double G[6
     }
 }
 
-struct Pose {   // bound_mpc_functions.error_function + reference_function at one stage
-    double phi, dphi, sig, dsig, ep[3], er[3], epar[3], eo1[3], eo2[3];
-    double proj[3], projn[3];
-    double Dep[3][3], Der[3][6], gs[3][6];
-};
-
-BMPC_DEV void pose_eval(const Seg& sc, const double* pose, const double* v, const double* iw0, double phi_max, Pose& pe) {
-    const double* dpp = sc.dp;
-    const double* dpr = sc.dp + 3;
-    double d[3], pdr[3], tmp[3], delta[3], jrdpr[3];
-    for (int a = 0; a < 3; a++) d[a] = pose[a] - sc.pref[a];
-    double phil = dot3(d, dpp);
-    pe.phi = phil + sc.phi_start;
-    pe.dphi = dot3(v, dpp);
-    for (int a = 0; a < 3; a++) { pe.ep[a] = d[a] - dpp[a] * phil; pdr[a] = dpr[a] * phil + sc.pref[3 + a]; }
-    for (int a = 0; a < 3; a++) tmp[a] = pose[3 + a] - iw0[a];
-    for (int a = 0; a < 3; a++) delta[a] = dot3(sc.jl + 3 * a, tmp);
-    for (int a = 0; a < 3; a++) tmp[a] = pdr[a] - sc.iwref0[a];
-    for (int a = 0; a < 3; a++) delta[a] -= dot3(sc.jr + 3 * a, tmp);
-    for (int a = 0; a < 3; a++) { pe.er[a] = sc.e_init[a] + delta[a]; jrdpr[a] = dot3(sc.jr + 3 * a, dpr); }
-    double sc1 = dot3(delta, sc.v1), scp = dot3(delta, sc.v2), sc2 = dot3(delta, sc.v3);
-    for (int a = 0; a < 3; a++) {
-        pe.eo1[a] = sc.e_o10[a] + sc1 * sc.br1[a];
-        pe.epar[a] = sc.e_par0[a] + scp * sc.dpn[a];
-        pe.eo2[a] = sc.e_o20[a] + sc2 * sc.br2[a];
-    }
-    pe.proj[0] = dot3(sc.br1, pe.eo1); pe.proj[1] = dot3(sc.dpn, pe.epar); pe.proj[2] = dot3(sc.br2, pe.eo2);
-    pe.projn[0] = dot3(sc.br1n, pe.eo1); pe.projn[1] = dot3(sc.dpnn, pe.epar); pe.projn[2] = dot3(sc.br2n, pe.eo2);
-    double e = exp(-60.0 * (pe.phi - (phi_max - 0.05)));
-    pe.sig = 1.0 / (1.0 + e);
-    pe.dsig = 60.0 * pe.sig * (1.0 - pe.sig);
-    for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
-            pe.Dep[a][b] = (a == b ? 1.0 : 0.0) - dpp[a] * dpp[b];
-            pe.Der[a][b] = -jrdpr[a] * dpp[b];
-            pe.Der[a][3 + b] = sc.jl[3 * a + b];
-        }
-    const double* vv[3] = {sc.v1, sc.v2, sc.v3};
-    for (int m = 0; m < 3; m++) {
-        double c = dot3(vv[m], jrdpr);
-        for (int b = 0; b < 3; b++) {
-            pe.gs[m][b] = -c * dpp[b];
-            pe.gs[m][3 + b] = sc.jl[b] * vv[m][0] + sc.jl[3 + b] * vv[m][1] + sc.jl[6 + b] * vv[m][2];
-        }
-    }
-}
-
-// stage cost in output space (pose6, v6): value, gradient, Gauss-Newton/convex Hessian blocks
-BMPC_DEV double stage_cost_o(const Seg& sc, const Pose& pe, const double* v, const double* wts, const double* xphid,
-                             bool terminal, double* g12, double* Hp, double* Hv, bool want_h) {
-    const double* dpp = sc.dp;
-    double w_p = wts[0], w_r = wts[1], w_vp = wts[2], w_vr = wts[3], w_phi = wts[4], w_dphi = wts[5];
-    double sig = pe.sig;
-    double er2 = dot3(pe.er, pe.er), ep2 = dot3(pe.ep, pe.ep);
-    double vo[6], Wvo[6];
-    for (int a = 0; a < 6; a++) { vo[a] = v[a] - pe.dphi * sc.dp[a]; Wvo[a] = (a < 3 ? w_vp : w_vr) * vo[a]; }
-    double dphid = xphid[0] - pe.phi;
-    double rt = sqrt(dphid * dphid + 0.01);
-    double val = sig * sig * (er2 + ep2) + w_r * dot3(pe.epar, pe.epar);
-    val += w_vp * (vo[0] * vo[0] + vo[1] * vo[1] + vo[2] * vo[2]) + w_vr * (vo[3] * vo[3] + vo[4] * vo[4] + vo[5] * vo[5]);
-    val += w_phi * (rt - 0.1) + w_dphi * (xphid[1] - pe.dphi) * (xphid[1] - pe.dphi);
-    val += w_p * ep2 + w_r / 50.0 * (dot3(pe.eo1, pe.eo1) + dot3(pe.eo2, pe.eo2));
-    if (terminal)
-        for (int a = 0; a < 6; a++) val += 100.0 * v[a] * v[a];
-    double dpsi = -w_phi * dphid / rt, ddpsi = w_phi * 0.01 / (rt * rt * rt);
-    for (int b = 0; b < 6; b++) {
-        double s1 = 0;
-        for (int a = 0; a < 3; a++) s1 += pe.Der[a][b] * pe.er[a];
-        double gp = 2 * sig * sig * s1;
-        if (b < 3) {
-            double s2 = 0;
-            for (int a = 0; a < 3; a++) s2 += pe.Dep[a][b] * pe.ep[a];
-            gp += 2 * (sig * sig + w_p) * s2 + (2 * sig * pe.dsig * (er2 + ep2) + dpsi) * dpp[b];
-        }
-        gp += 2 * w_r * pe.proj[1] * pe.gs[1][b] + 2 * (w_r / 50.0) * (pe.proj[0] * pe.gs[0][b] + pe.proj[2] * pe.gs[2][b]);
-        g12[b] = gp;
-    }
-    double dWvo = 0;
-    for (int a = 0; a < 6; a++) dWvo += sc.dp[a] * Wvo[a];
-    for (int b = 0; b < 6; b++) {
-        double gv = 2 * Wvo[b];
-        if (b < 3) gv += (-2 * dWvo - 2 * w_dphi * (xphid[1] - pe.dphi)) * dpp[b];
-        if (terminal) gv += 200.0 * v[b];
-        g12[6 + b] = gv;
-    }
-    if (want_h) {
-        double R1[3][6], R2[3][6];
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 6; b++) {
-                double dphib = (b < 3) ? dpp[b] : 0.0;
-                R1[a][b] = sig * pe.Der[a][b] + pe.er[a] * pe.dsig * dphib;
-                R2[a][b] = (b < 3 ? sig * pe.Dep[a][b] : 0.0) + pe.ep[a] * pe.dsig * dphib;
-            }
-        double n_dpn = dot3(sc.dpn, sc.dpn), n_b1 = dot3(sc.br1, sc.br1), n_b2 = dot3(sc.br2, sc.br2);
-        for (int i = 0; i < 6; i++)
-            for (int j = 0; j < 6; j++) {
-                double h = 0;
-                for (int a = 0; a < 3; a++) h += R1[a][i] * R1[a][j] + R2[a][i] * R2[a][j];
-                h *= 2;
-                h += 2 * w_r * n_dpn * pe.gs[1][i] * pe.gs[1][j];
-                h += 2 * (w_r / 50.0) * (n_b1 * pe.gs[0][i] * pe.gs[0][j] + n_b2 * pe.gs[2][i] * pe.gs[2][j]);
-                if (i < 3 && j < 3) {
-                    double dd = 0;
-                    for (int a = 0; a < 3; a++) dd += pe.Dep[a][i] * pe.Dep[a][j];
-                    h += 2 * w_p * dd + ddpsi * dpp[i] * dpp[j];
-                }
-                Hp[6 * i + j] = h;
-            }
-        double dWd = 0;
-        for (int a = 0; a < 6; a++) dWd += sc.dp[a] * sc.dp[a] * (a < 3 ? w_vp : w_vr);
-        for (int i = 0; i < 6; i++)
-            for (int j = 0; j < 6; j++) {
-                double wi = (i < 3 ? w_vp : w_vr), wj = (j < 3 ? w_vp : w_vr);
-                double di = (i < 3) ? dpp[i] : 0.0, dj = (j < 3) ? dpp[j] : 0.0;
-                double h = (i == j ? wi : 0.0) - wi * sc.dp[i] * dj - di * wj * sc.dp[j] + di * dj * dWd;
-                h = 2 * h + 2 * w_dphi * di * dj;
-                if (terminal && i == j) h += 200.0;
-                Hv[6 * i + j] = h;
-            }
-    }
-    return val;
-}
-
 // ------------------------------------------------------------------------------------------
-// stage evaluation shared by every pass
+// stage evaluation shared by every pass: short lane-parallel phases, all results in LDS
 // ------------------------------------------------------------------------------------------
-// rc[] layout (per-stage row context in LDS, written by lane 0)
+// rc[] layout (per-stage context in LDS)
 constexpr int RC_POSE = 0, RC_PROJ = 6, RC_PROJN = 9, RC_GS = 12, RC_GSN = 30, RC_PHI = 48,
               RC_UB = 49, RC_LB = 52, RC_UBN = 55, RC_LBN = 58, RC_DPP = 61, RC_PHIEND = 64,
               RC_TZ = 65 /*z1,z2*/, RC_BP1 = 67, RC_BP2 = 70, RC_DEP = 73, RC_PEND = 82,
-              RC_SL = 85 /*sl0+d (6)*/, RC_FVAL = 91, RC_V = 92 /*v6*/, RC_PROT = 98, RC_SEG = 101 /*s,n*/;
+              RC_SL = 85 /*sl0+d (6)*/, RC_FVAL = 91, RC_V = 92 /*v6*/, RC_PROT = 98, RC_SEG = 101 /*s,n*/,
+              RC_ER = 103, RC_EP = 106, RC_SIG = 109, RC_DSIG = 110, RC_DPHI = 111, RC_VO = 112 /*6*/,
+              RC_DPSI = 118, RC_DDPSI = 119, RC_ER2EP2 = 120, RC_DWVO = 121, RC_DER = 122 /*18*/,
+              RC_GSR = 140 /*raw gs 18*/;
+// kin[] layout
+constexpr int KN_O = 0 /*7x3*/, KN_PEE = 21, KN_CS = 24 /*cos7,sin7*/, KN_SUFC = 38 /*8x3*/, KN_SUFZ = 62,
+              KN_PREZ = 86, KN_R1 = 110 /*3x6*/, KN_R2 = 128, KN_G12 = 146 /*12*/, KN_END = 158;
 
-struct StageEval {
-    Seg sc;
-    Kin kin;
-    Pose pe;
-    double J[6][7], G[6][7], v[6], pose[6];
-    double g12[12];
-    double fval;
-};
-
-// natural values (in zeta index positions) from zeta
-BMPC_INL double nat_from_zeta(const double* z, int i, const DynC& d) {
+BMPC_INL double nat_from_zeta(const LDSD* z, int i, const DynC& d) {
     if (i < Z_DQ) return z[i] + d.c3 * z[Z_U + i];
     if (i < Z_DDQ) return z[i] + d.c2 * z[Z_U + i - 7];
     if (i < Z_PI) return z[i] + d.c1 * z[Z_U + i - 14];
@@ -412,81 +249,281 @@ BMPC_INL double nat_from_zeta(const double* z, int i, const DynC& d) {
     return z[i];
 }
 
-// Phase 1 of every pass: lanes fill yz; every lane evaluates kinematics/pose/cost redundantly;
-// lane 0 publishes the row context and the Jacobians to LDS.
-BMPC_DEV void stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, int k, int lane, bool want_h,
-                         const double* iw0, StageEval& E) {
+#define TABP(off, seg, c) sp[(off) + (c) * 4 + (seg)]
+
+// Returns the stage cost value (same on every lane).  Publishes to LDS: yz, kinematics (J, G, Jp,
+// zax, pc), the row context rc[], the output-space cost gradient kin[KN_G12..] and, when want_h,
+// the Gauss-Newton/convex cost Hessian blocks Hp/Hv plus the initial group gradients bp0/bpz/bp1/bv.
+BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, int k, int lane, bool want_h,
+                           const double* iw0) {
     const int N = A.o.N;
-    const double* sp = L.sp;
+    const LDSD* sp = L.sp;
+    const RobotConst* rcn = A.rc;
+    LDSD* rc = L.rc;
+    LDSD* kn = L.kin;
+    const bool term = (k == N - 1);
+    // ---- E0: natural variables, sin/cos ----
     if (lane < NZ) L.yz[lane] = nat_from_zeta(L.zeta, lane, dc);
+    if (lane < 7) { double q = nat_from_zeta(L.zeta, lane, dc); kn[KN_CS + lane] = cos(q); kn[KN_CS + 7 + lane] = sin(q); }
     BMPC_SYNC();
-    double q[7], dq[7];
-    for (int j = 0; j < 7; j++) { q[j] = L.yz[Z_Q + j]; dq[j] = L.yz[Z_DQ + j]; }
-    kin_eval(A.rc, q, E.kin);
-    kin_jac(E.kin, dq, E.J, E.G, E.v);
-    for (int a = 0; a < 3; a++) {
-        E.pose[a] = E.kin.pee[a];
-        E.pose[3 + a] = L.yz[Z_PI + a] + 0.5 * dc.dt * E.v[3 + a];
-    }
-    seg_ctx(N, sp, k, E.sc);
-    pose_eval(E.sc, E.pose, E.v, iw0, sp[P_PHIMAX], E.pe);
-    bool term = (k == N - 1);
-    double Hp[36], Hv[36];
-    double fv = stage_cost_o(E.sc, E.pe, E.v, sp + P_W, sp + P_XPHID, term, E.g12, Hp, Hv, want_h);
-    const double* wts = sp + P_W;
-    for (int j = 2; j <= 4; j++) fv += wts[6] * dq[j] * dq[j];
-    for (int j = 0; j < 7; j++) fv += wts[7] * L.yz[Z_U + j] * L.yz[Z_U + j];
-    fv += wts[9] * L.yz[Z_RS] * L.yz[Z_RS] + wts[10] * L.yz[Z_DRS] * L.yz[Z_DRS] +
-          wts[9] * L.yz[Z_PS] * L.yz[Z_PS] + wts[10] * L.yz[Z_DPS] * L.yz[Z_DPS];
-    if (term)
-        for (int i = 0; i < 6; i++) {
-            double sl = sp[P_SLACKS0 + i] + L.yz[Z_D + i];
-            if (i != 4) fv += wts[8] * sl * sl;
-            fv += wts[10] * L.yz[Z_D + i] * L.yz[Z_D + i];
-        }
-    E.fval = fv;
-    BMPC_SYNC();
-    if (lane == 0) {
-        double* rc = L.rc;
-        double nb[3] = {dot3(E.sc.br1, E.sc.br1), dot3(E.sc.dpn, E.sc.dpn), dot3(E.sc.br2, E.sc.br2)};
-        double cc[3] = {dot3(E.sc.br1n, E.sc.br1), dot3(E.sc.dpnn, E.sc.dpn), dot3(E.sc.br2n, E.sc.br2)};
-        for (int a = 0; a < 6; a++) rc[RC_POSE + a] = E.pose[a];
-        for (int m = 0; m < 3; m++) {
-            rc[RC_PROJ + m] = E.pe.proj[m]; rc[RC_PROJN + m] = E.pe.projn[m];
-            for (int c = 0; c < 6; c++) { rc[RC_GS + 6 * m + c] = nb[m] * E.pe.gs[m][c]; rc[RC_GSN + 6 * m + c] = cc[m] * E.pe.gs[m][c]; }
-            rc[RC_UB + m] = E.sc.ub[m]; rc[RC_LB + m] = E.sc.lb[m]; rc[RC_UBN + m] = E.sc.ubn[m]; rc[RC_LBN + m] = E.sc.lbn[m];
-            rc[RC_DPP + m] = E.sc.dp[m]; rc[RC_BP1 + m] = E.sc.bp1[m]; rc[RC_BP2 + m] = E.sc.bp2[m];
-            rc[RC_PEND + m] = E.sc.p_end[m];
-            for (int c = 0; c < 3; c++) rc[RC_DEP + 3 * m + c] = E.pe.Dep[m][c];
-        }
-        rc[RC_PHI] = E.pe.phi; rc[RC_PHIEND] = E.sc.phi_end_seg;
-        rc[RC_TZ] = dot3(E.sc.bp1, E.pe.ep); rc[RC_TZ + 1] = dot3(E.sc.bp2, E.pe.ep);
-        for (int i = 0; i < 6; i++) rc[RC_SL + i] = sp[P_SLACKS0 + i] + L.yz[Z_D + i];
-        rc[RC_FVAL] = fv;
-        for (int a = 0; a < 6; a++) rc[RC_V + a] = E.v[a];
-        for (int a = 0; a < 3; a++) rc[RC_PROT + a] = E.pose[3 + a];
-        rc[RC_SEG] = (double)E.sc.s; rc[RC_SEG + 1] = (double)E.sc.n;
-        for (int c = 0; c < 6; c++)
-            for (int a = 0; a < 3; a++) L.pc[3 * c + a] = E.kin.pc[c][a];
-        for (int a = 0; a < 6; a++)
-            for (int j = 0; j < 7; j++) { L.J[7 * a + j] = E.J[a][j]; L.G[7 * a + j] = E.G[a][j]; }
-        for (int i = 0; i < 7; i++)
-            for (int a = 0; a < 3; a++) L.zax[3 * i + a] = E.kin.z[i][a];
-        const int nj[6] = {2, 3, 4, 5, 6, 4};
-        for (int c = 0; c < 6; c++)
-            for (int i = 0; i < 7; i++) {
-                double r[3], cr[3] = {0, 0, 0};
-                if (i < nj[c]) {
-                    for (int a = 0; a < 3; a++) r[a] = E.kin.pc[c][a] - E.kin.o[i][a];
-                    cross3(E.kin.z[i], r, cr);
-                }
-                for (int a = 0; a < 3; a++) L.Jp[21 * c + 7 * a + i] = cr[a];
+    // ---- E1: kinematic chain (every lane, small live set; lane 0 publishes) ----
+    {
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}, Rn[9], tmp[3];
+        for (int i = 0; i < 7; i++) {
+            mat3vec(R, rcn->jxyz[i], tmp);
+            for (int a = 0; a < 3; a++) t[a] += tmp[a];
+            mat3mul(R, rcn->jrot[i], Rn);
+            if (lane == 0)
+                for (int a = 0; a < 3; a++) { kn[KN_O + 3 * i + a] = t[a]; L.zax[3 * i + a] = Rn[3 * a + 2]; }
+            double c = kn[KN_CS + i], s = kn[KN_CS + 7 + i];
+            for (int a = 0; a < 3; a++) {
+                R[3 * a] = Rn[3 * a] * c + Rn[3 * a + 1] * s;
+                R[3 * a + 1] = Rn[3 * a + 1] * c - Rn[3 * a] * s;
+                R[3 * a + 2] = Rn[3 * a + 2];
             }
-        if (want_h)
-            for (int i = 0; i < 36; i++) { L.Hp[i] = Hp[i]; L.Hv[i] = Hv[i]; }
-        for (int a = 0; a < 6; a++) { L.bp0[a] = E.g12[a]; L.bpz[a] = E.g12[a]; L.bp1[a] = 0; L.bv[a] = E.g12[6 + a]; }
+            if (i == 3) {
+                mat3vec(R, rcn->l4c_xyz, tmp);
+                if (lane == 0) for (int a = 0; a < 3; a++) L.pc[15 + a] = t[a] + tmp[a];
+            }
+        }
+        mat3vec(R, rcn->ee_xyz, tmp);
+        if (lane == 0) for (int a = 0; a < 3; a++) kn[KN_PEE + a] = t[a] + tmp[a];
     }
     BMPC_SYNC();
+    // ---- E2: Jacobian columns, collision points and their Jacobians ----
+    {
+        if (lane < 42) {
+            int a = lane / 7, i = lane % 7;
+            double v;
+            if (a < 3) {
+                int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+                double r1 = kn[KN_PEE + a1] - kn[KN_O + 3 * i + a1], r2 = kn[KN_PEE + a2] - kn[KN_O + 3 * i + a2];
+                v = L.zax[3 * i + a1] * r2 - L.zax[3 * i + a2] * r1;
+            } else v = L.zax[3 * i + a - 3];
+            L.J[lane] = v;
+        } else if (lane < 57) {
+            int e = lane - 42;
+            L.pc[e] = kn[KN_O + 6 + e];     // pc[c] = o[c+2], c < 5
+        }
+        const int nj[6] = {2, 3, 4, 5, 6, 4};
+        for (int e = lane; e < 126; e += 64) {
+            int c = e / 21, a = (e % 21) / 7, i = e % 7;
+            double v = 0;
+            if (i < nj[c]) {
+                int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+                double p1 = (c < 5) ? kn[KN_O + 3 * (c + 2) + a1] : L.pc[15 + a1];
+                double p2 = (c < 5) ? kn[KN_O + 3 * (c + 2) + a2] : L.pc[15 + a2];
+                double r1 = p1 - kn[KN_O + 3 * i + a1], r2 = p2 - kn[KN_O + 3 * i + a2];
+                v = L.zax[3 * i + a1] * r2 - L.zax[3 * i + a2] * r1;
+            }
+            L.Jp[e] = v;
+        }
+    }
+    BMPC_SYNC();
+    // ---- E3: v = J dq, prefix/suffix sums for G ----
+    if (lane < 6) {
+        double s = 0;
+        for (int j = 0; j < 7; j++) s += L.J[7 * lane + j] * L.yz[Z_DQ + j];
+        rc[RC_V + lane] = s;
+    } else if (lane < 9) {
+        int a = lane - 6;
+        double sc = 0, sz = 0, pz = 0;
+        kn[KN_SUFC + 21 + a] = 0; kn[KN_SUFZ + 21 + a] = 0; kn[KN_PREZ + a] = 0;
+        for (int j = 6; j >= 0; j--) {
+            sc += L.J[7 * a + j] * L.yz[Z_DQ + j]; sz += L.zax[3 * j + a] * L.yz[Z_DQ + j];
+            kn[KN_SUFC + 3 * j + a] = sc; kn[KN_SUFZ + 3 * j + a] = sz;
+        }
+        for (int j = 0; j < 7; j++) { pz += L.zax[3 * j + a] * L.yz[Z_DQ + j]; kn[KN_PREZ + 3 * (j + 1) + a] = pz; }
+    }
+    BMPC_SYNC();
+    // ---- E4: G = d(J dq)/dq, pose ----
+    if (lane < 42) {
+        int a = lane / 7, i = lane % 7;
+        double v;
+        if (a < 3) {
+            int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+            // (z_i x sufc_i)[a] + (prez_i x c_i)[a]
+            v = L.zax[3 * i + a1] * kn[KN_SUFC + 3 * i + a2] - L.zax[3 * i + a2] * kn[KN_SUFC + 3 * i + a1];
+            v += kn[KN_PREZ + 3 * i + a1] * L.J[7 * a2 + i] - kn[KN_PREZ + 3 * i + a2] * L.J[7 * a1 + i];
+        } else {
+            int b = a - 3, a1 = (b + 1) % 3, a2 = (b + 2) % 3;
+            v = L.zax[3 * i + a1] * kn[KN_SUFZ + 3 * (i + 1) + a2] - L.zax[3 * i + a2] * kn[KN_SUFZ + 3 * (i + 1) + a1];
+        }
+        L.G[lane] = v;
+    } else if (lane < 48) {
+        int a = lane - 42;
+        double v = (a < 3) ? kn[KN_PEE + a] : L.yz[Z_PI + a - 3] + 0.5 * dc.dt * rc[RC_V + a];
+        rc[RC_POSE + a] = v;
+        if (a >= 3) rc[RC_PROT + a - 3] = v;
+    }
+    BMPC_SYNC();
+    // ---- E5: reference / error scalars (bound_mpc_functions.py:85-390), every lane ----
+    int s = 0;
+    if ((double)k > sp[P_SPLIT + 1]) s = 1;
+    if ((double)k > sp[P_SPLIT + 2]) s = 2;
+    const int n = (sp[P_SPLIT + 1] == (double)N) ? 1 : ((sp[P_SPLIT + 2] == (double)N) ? 2 : 3);
+    double fv;
+    {
+        const bool iw_param = ((double)k <= sp[P_SPLIT + 1]);
+        double dpp[3], dpr[3], d[3], tmp[3], delta[3], er[3], ep[3], jrdpr[3], vv[6];
+        for (int a = 0; a < 3; a++) { dpp[a] = TABP(P_DPREF, s, a); dpr[a] = TABP(P_DPREF, s, 3 + a); d[a] = rc[RC_POSE + a] - TABP(P_PREF, s, a); }
+        for (int a = 0; a < 6; a++) vv[a] = rc[RC_V + a];
+        double phil = dot3(d, dpp);
+        double phi = phil + sp[P_PHISW + s];
+        double dphi = dot3(vv, dpp);
+        for (int a = 0; a < 3; a++) ep[a] = d[a] - dpp[a] * phil;
+        for (int a = 0; a < 3; a++) tmp[a] = rc[RC_POSE + 3 + a] - iw0[a];
+        for (int a = 0; a < 3; a++) delta[a] = sp[P_JACL + a] * tmp[0] + sp[P_JACL + 3 + a] * tmp[1] + sp[P_JACL + 6 + a] * tmp[2];
+        for (int a = 0; a < 3; a++) tmp[a] = dpr[a] * phil + TABP(P_PREF, s, 3 + a) - (iw_param ? sp[P_IWREF + a] : TABP(P_PREF, s, 3 + a));
+        for (int a = 0; a < 3; a++) delta[a] -= sp[P_JACR + a] * tmp[0] + sp[P_JACR + 3 + a] * tmp[1] + sp[P_JACR + 6 + a] * tmp[2];
+        for (int a = 0; a < 3; a++) {
+            er[a] = sp[P_DTAU + 3 * s + a] + delta[a];
+            jrdpr[a] = sp[P_JACR + a] * dpr[0] + sp[P_JACR + 3 + a] * dpr[1] + sp[P_JACR + 6 + a] * dpr[2];
+        }
+        double br1[3], br2[3], dpn[3], v1[3], v2[3], v3[3];
+        for (int a = 0; a < 3; a++) {
+            br1[a] = TABP(P_BR1, s, a); br2[a] = TABP(P_BR2, s, a); dpn[a] = TABP(P_DPN, s, a);
+            v1[a] = TABP(P_V1, s, a); v2[a] = TABP(P_V2, s, a); v3[a] = TABP(P_V3, s, a);
+        }
+        double sc1 = dot3(delta, v1), scp = dot3(delta, v2), sc2 = dot3(delta, v3);
+        double eo1[3], epar[3], eo2[3];
+        for (int a = 0; a < 3; a++) {
+            eo1[a] = sp[P_DTAU_O1 + 3 * s + a] + sc1 * br1[a];
+            epar[a] = sp[P_DTAU_PAR + 3 * s + a] + scp * dpn[a];
+            eo2[a] = sp[P_DTAU_O2 + 3 * s + a] + sc2 * br2[a];
+        }
+        double proj[3] = {dot3(br1, eo1), dot3(dpn, epar), dot3(br2, eo2)};
+        double br1n[3], br2n[3], dpnn[3];
+        for (int a = 0; a < 3; a++) { br1n[a] = TABP(P_BR1, s + 1, a); br2n[a] = TABP(P_BR2, s + 1, a); dpnn[a] = TABP(P_DPN, s + 1, a); }
+        double projn[3] = {dot3(br1n, eo1), dot3(dpnn, epar), dot3(br2n, eo2)};
+        double e = exp(-60.0 * (phi - (sp[P_PHIMAX] - 0.05)));
+        double sig = 1.0 / (1.0 + e), dsig = 60.0 * sig * (1.0 - sig);
+        // stage cost value (ocp :268-299, 360; objective_function :393-428)
+        const LDSD* wts = sp + P_W;
+        double er2 = dot3(er, er), ep2 = dot3(ep, ep);
+        double vo[6], dWvo = 0;
+        for (int a = 0; a < 6; a++) { vo[a] = vv[a] - dphi * TABP(P_DPREF, s, a); dWvo += TABP(P_DPREF, s, a) * (a < 3 ? wts[2] : wts[3]) * vo[a]; }
+        double dphid = sp[P_XPHID] - phi;
+        double rt = sqrt(dphid * dphid + 0.01);
+        fv = sig * sig * (er2 + ep2) + wts[1] * dot3(epar, epar);
+        fv += wts[2] * (vo[0] * vo[0] + vo[1] * vo[1] + vo[2] * vo[2]) + wts[3] * (vo[3] * vo[3] + vo[4] * vo[4] + vo[5] * vo[5]);
+        fv += wts[4] * (rt - 0.1) + wts[5] * (sp[P_XPHID + 1] - dphi) * (sp[P_XPHID + 1] - dphi);
+        fv += wts[0] * ep2 + wts[1] / 50.0 * (dot3(eo1, eo1) + dot3(eo2, eo2));
+        if (term)
+            for (int a = 0; a < 6; a++) fv += 100.0 * vv[a] * vv[a];
+        for (int j = 2; j <= 4; j++) fv += wts[6] * L.yz[Z_DQ + j] * L.yz[Z_DQ + j];
+        for (int j = 0; j < 7; j++) fv += wts[7] * L.yz[Z_U + j] * L.yz[Z_U + j];
+        fv += wts[9] * L.yz[Z_RS] * L.yz[Z_RS] + wts[10] * L.yz[Z_DRS] * L.yz[Z_DRS] +
+              wts[9] * L.yz[Z_PS] * L.yz[Z_PS] + wts[10] * L.yz[Z_DPS] * L.yz[Z_DPS];
+        if (term)
+            for (int i = 0; i < 6; i++) {
+                double sl = sp[P_SLACKS0 + i] + L.yz[Z_D + i];
+                if (i != 4) fv += wts[8] * sl * sl;
+                fv += wts[10] * L.yz[Z_D + i] * L.yz[Z_D + i];
+            }
+        if (lane == 0) {
+            double bp1[3], bp2[3];
+            for (int m = 0; m < 3; m++) {
+                bp1[m] = TABP(P_BP1, s, m); bp2[m] = TABP(P_BP2, s, m);
+                rc[RC_PROJ + m] = proj[m]; rc[RC_PROJN + m] = projn[m];
+                rc[RC_UB + m] = TABP(P_ERB, s, m); rc[RC_LB + m] = TABP(P_ERB, s, 3 + m);
+                rc[RC_UBN + m] = TABP(P_ERB, s + 1, m); rc[RC_LBN + m] = TABP(P_ERB, s + 1, 3 + m);
+                rc[RC_DPP + m] = dpp[m]; rc[RC_BP1 + m] = bp1[m]; rc[RC_BP2 + m] = bp2[m];
+                rc[RC_PEND + m] = TABP(P_PREF, s + 1, m);
+                rc[RC_ER + m] = er[m]; rc[RC_EP + m] = ep[m];
+            }
+            rc[RC_PHI] = phi; rc[RC_PHIEND] = sp[P_PHISW + n];
+            rc[RC_TZ] = dot3(bp1, ep); rc[RC_TZ + 1] = dot3(bp2, ep);
+            for (int i = 0; i < 6; i++) { rc[RC_SL + i] = sp[P_SLACKS0 + i] + L.yz[Z_D + i]; rc[RC_VO + i] = vo[i]; }
+            rc[RC_FVAL] = fv; rc[RC_SEG] = (double)s; rc[RC_SEG + 1] = (double)n;
+            rc[RC_SIG] = sig; rc[RC_DSIG] = dsig; rc[RC_DPHI] = dphi;
+            rc[RC_DPSI] = -wts[4] * dphid / rt; rc[RC_DDPSI] = wts[4] * 0.01 / (rt * rt * rt);
+            rc[RC_ER2EP2] = er2 + ep2; rc[RC_DWVO] = dWvo;
+        }
+        // ---- E6 (same phase, disjoint outputs): Dep, Der, raw/scaled gs ----
+        if (lane < 9) { int a = lane / 3, b = lane % 3; rc[RC_DEP + lane] = (a == b ? 1.0 : 0.0) - dpp[a] * dpp[b]; }
+        else if (lane < 27) {
+            int e = lane - 9, a = e / 6, b = e % 6;
+            rc[RC_DER + e] = (b < 3) ? -jrdpr[a] * dpp[b] : sp[P_JACL + 3 * (b - 3) + a];
+        } else if (lane < 45) {
+            int e = lane - 27, m = e / 6, b = e % 6;
+            const double* vm = (m == 0) ? v1 : (m == 1 ? v2 : v3);
+            double g;
+            if (b < 3) g = -dot3(vm, jrdpr) * dpp[b];
+            else { int bb = b - 3; g = sp[P_JACL + 3 * bb] * vm[0] + sp[P_JACL + 3 * bb + 1] * vm[1] + sp[P_JACL + 3 * bb + 2] * vm[2]; }
+            double nb = (m == 0) ? dot3(br1, br1) : (m == 1 ? dot3(dpn, dpn) : dot3(br2, br2));
+            double cc = (m == 0) ? dot3(br1n, br1) : (m == 1 ? dot3(dpnn, dpn) : dot3(br2n, br2));
+            rc[RC_GSR + e] = g; rc[RC_GS + e] = nb * g; rc[RC_GSN + e] = cc * g;
+        }
+    }
+    BMPC_SYNC();
+    // ---- E7: output-space cost gradient g12 and the residual Jacobians R1, R2 ----
+    {
+        const LDSD* wts = sp + P_W;
+        const double sig = rc[RC_SIG], dsig = rc[RC_DSIG];
+        if (lane < 6) {
+            int b = lane;
+            double s1 = 0;
+            for (int a = 0; a < 3; a++) s1 += rc[RC_DER + 6 * a + b] * rc[RC_ER + a];
+            double gp = 2 * sig * sig * s1;
+            if (b < 3) {
+                double s2 = 0;
+                for (int a = 0; a < 3; a++) s2 += rc[RC_DEP + 3 * a + b] * rc[RC_EP + a];
+                gp += 2 * (sig * sig + wts[0]) * s2 + (2 * sig * dsig * rc[RC_ER2EP2] + rc[RC_DPSI]) * rc[RC_DPP + b];
+            }
+            gp += 2 * wts[1] * rc[RC_PROJ + 1] * rc[RC_GSR + 6 + b] +
+                  2 * (wts[1] / 50.0) * (rc[RC_PROJ] * rc[RC_GSR + b] + rc[RC_PROJ + 2] * rc[RC_GSR + 12 + b]);
+            kn[KN_G12 + b] = gp;
+        } else if (lane < 12) {
+            int b = lane - 6;
+            double gv = 2 * (b < 3 ? wts[2] : wts[3]) * rc[RC_VO + b];
+            if (b < 3) gv += (-2 * rc[RC_DWVO] - 2 * wts[5] * (sp[P_XPHID + 1] - rc[RC_DPHI])) * rc[RC_DPP + b];
+            if (term) gv += 200.0 * rc[RC_V + b];
+            kn[KN_G12 + 6 + b] = gv;
+        } else if (want_h && lane < 48) {
+            int e = lane - 12, which = e / 18, a = (e % 18) / 6, b = e % 6;
+            double dphib = (b < 3) ? rc[RC_DPP + b] : 0.0, v;
+            if (which == 0) v = sig * rc[RC_DER + 6 * a + b] + rc[RC_ER + a] * dsig * dphib;
+            else v = (b < 3 ? sig * rc[RC_DEP + 3 * a + b] : 0.0) + rc[RC_EP + a] * dsig * dphib;
+            kn[(which ? KN_R2 : KN_R1) + 6 * a + b] = v;
+        }
+    }
+    BMPC_SYNC();
+    // ---- E8: Hessian blocks Hp, Hv and initial group gradients ----
+    if (want_h) {
+        const LDSD* wts = sp + P_W;
+        double w_vp = wts[2], w_vr = wts[3];
+        for (int e = lane; e < 72; e += 64) {
+            if (e < 36) {
+                int i = e / 6, j = e % 6;
+                double h = 0;
+                for (int a = 0; a < 3; a++) h += kn[KN_R1 + 6 * a + i] * kn[KN_R1 + 6 * a + j] + kn[KN_R2 + 6 * a + i] * kn[KN_R2 + 6 * a + j];
+                h *= 2;
+                // RC_GS = |b|^2 gs: 2 w |b|^2 gs_i gs_j = 2 w RC_GS_i * raw_j
+                h += 2 * wts[1] * rc[RC_GS + 6 + i] * rc[RC_GSR + 6 + j];
+                h += 2 * (wts[1] / 50.0) * (rc[RC_GS + i] * rc[RC_GSR + j] + rc[RC_GS + 12 + i] * rc[RC_GSR + 12 + j]);
+                if (i < 3 && j < 3) {
+                    double dd = 0;
+                    for (int a = 0; a < 3; a++) dd += rc[RC_DEP + 3 * a + i] * rc[RC_DEP + 3 * a + j];
+                    h += 2 * wts[0] * dd + rc[RC_DDPSI] * rc[RC_DPP + i] * rc[RC_DPP + j];
+                }
+                L.Hp[e] = h;
+            } else {
+                int i = (e - 36) / 6, j = (e - 36) % 6;
+                double dWd = 0;
+                for (int a = 0; a < 6; a++) { double da = TABP(P_DPREF, s, a); dWd += da * da * (a < 3 ? w_vp : w_vr); }
+                double wi = (i < 3 ? w_vp : w_vr), wj = (j < 3 ? w_vp : w_vr);
+                double di = (i < 3) ? rc[RC_DPP + i] : 0.0, dj = (j < 3) ? rc[RC_DPP + j] : 0.0;
+                double h = (i == j ? wi : 0.0) - wi * TABP(P_DPREF, s, i) * dj - di * wj * TABP(P_DPREF, s, j) + di * dj * dWd;
+                h = 2 * h + 2 * wts[5] * di * dj;
+                if (term && i == j) h += 200.0;
+                L.Hv[e - 36] = h;
+            }
+        }
+        if (lane < 6) { double g = kn[KN_G12 + lane]; L.bp0[lane] = g; L.bpz[lane] = g; L.bp1[lane] = 0; L.bv[lane] = kn[KN_G12 + 6 + lane]; }
+    }
+    BMPC_SYNC();
+    return fv;
 }
 
 // One inequality row (slot) of stage k: h value, and a compact description of its gradient.
@@ -496,8 +533,9 @@ struct Row { int kind, pos, sel; double coef, h, a[6]; };
 
 BMPC_DEV void row_eval(const KernelArgs& A, const Lds& L, int b, int k, int s, Row& r) {
     const int N = A.o.N;
-    const double* sp = L.sp;
-    const double* rc = L.rc;
+    const LDSD* sp = L.sp;
+    const double* pg = A.p + (size_t)b * NPAR;   // EE sets live in global memory
+    const LDSD* rc = L.rc;
     r.kind = 0; r.pos = 0; r.sel = 0; r.coef = 0; r.h = 0;
     for (int c = 0; c < 6; c++) r.a[c] = 0;
     size_t xb = (size_t)b * (44 * N + 6);
@@ -522,8 +560,8 @@ BMPC_DEV void row_eval(const KernelArgs& A, const Lds& L, int b, int k, int s, R
         if (k == 1) { int pos = Z_D + (s - S_D1); r.kind = 1; r.pos = pos; r.coef = -1.0; r.h = -L.yz[pos]; }
     } else if (s < S_ROTU) {                  // EE in current set (ocp :304)
         int rr = s - S_EE, sg = (int)rc[RC_SEG];
-        const double* a = sp + P_ASET + 45 * sg;
-        double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = sp[P_BSET + rr * 4 + sg];
+        const double* a = pg + P_ASET + 45 * sg;
+        double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = pg[P_BSET + rr * 4 + sg];
         if (!(a0 == 0 && a1 == 0 && a2 == 0 && bb > 0)) {
             r.kind = 3; r.sel = 1; r.a[0] = a0; r.a[1] = a1; r.a[2] = a2;
             r.h = a0 * rc[RC_POSE] + a1 * rc[RC_POSE + 1] + a2 * rc[RC_POSE + 2] - bb - L.yz[Z_PS];
@@ -538,8 +576,8 @@ BMPC_DEV void row_eval(const KernelArgs& A, const Lds& L, int b, int k, int s, R
         r.h = lower ? -(rc[RC_PROJ + m] - rc[RC_LB + m] + L.yz[Z_RS]) : (rc[RC_PROJ + m] - rc[RC_UB + m] - L.yz[Z_RS]);
     } else if (s < S_PHI) {                   // collision points (ocp :323-330)
         int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c;
-        const double* a = sp + P_ASETJ + 45 * c;
-        double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = sp[P_BSETJ + rr * 6 + c];
+        const LDSD* a = sp + SP_ASETJ + 45 * c;
+        double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = sp[SP_BSETJ + rr * 6 + c];
         if (!(a0 == 0 && a1 == 0 && a2 == 0 && bb + sp[P_SLACKS0 + c] > 0)) {
             r.kind = 4; r.pos = c; r.a[0] = a0; r.a[1] = a1; r.a[2] = a2;
             r.h = a0 * L.pc[3 * c] + a1 * L.pc[3 * c + 1] + a2 * L.pc[3 * c + 2] - bb - rc[RC_SL + c];
@@ -551,9 +589,9 @@ BMPC_DEV void row_eval(const KernelArgs& A, const Lds& L, int b, int k, int s, R
     } else if (s < S_TROTU) {                 // terminal next-set rows (ocp :346-358)
         if (k == N - 1) {
             int rr = s - S_TSET, nn = (int)rc[RC_SEG + 1];
-            const double* a = sp + P_ASET + 45 * nn;
+            const double* a = pg + P_ASET + 45 * nn;
             double an[3] = {a[rr], a[rr + 15], a[rr + 30]};
-            double bn = sp[P_BSET + rr * 4 + nn];
+            double bn = pg[P_BSET + rr * 4 + nn];
             if (!(an[0] == 0 && an[1] == 0 && an[2] == 0 && bn + sp[P_SLACKS0 + 5] > 0)) {
                 double a1 = dot3(an, rc + RC_BP1), a2 = dot3(an, rc + RC_BP2);
                 double bnew = bn - dot3(an, rc + RC_PEND);

@@ -11,3 +11,7 @@
 #define BMPC_BLOCK() ((int)blockIdx.x)
 #define BMPC_NBLOCKS() ((int)gridDim.x)
 #define BMPC_HD __host__ __device__ inline
+#define BMPC_ATOMIC_INC(ptr) atomicAdd((ptr), 1)
+// doubles that live in LDS: address-space-qualified so that every access is a ds_* instruction
+// (generic pointers to __shared__ memory compile to flat_* loads through the vector-memory path)
+typedef __attribute__((address_space(3))) double LDSD;

@@ -28,7 +28,7 @@ BMPC_INL double sp_b(const double* sp, int off, int row, int stride, int col) { 
 
 // dynamics defect of stage k (needs zeta_k in L.zeta, zeta_{k+1} in L.znext, v in rc)
 BMPC_INL double defect_row(const Lds& L, const DynC& d, int i) {
-    const double* z = L.zeta;
+    const LDSD* z = L.zeta;
     double v;
     if (i < Z_DQ) v = z[i] + d.dt * z[i + 7] + 0.5 * d.dt * d.dt * z[i + 14] + d.b3 * z[Z_U + i];
     else if (i < Z_DDQ) v = z[i] + d.dt * z[i + 7] + d.b2 * z[Z_U + i - 7];
@@ -41,31 +41,39 @@ BMPC_INL double defect_row(const Lds& L, const DynC& d, int i) {
 }
 
 // 9x9 Cholesky in registers (every lane redundantly); returns false when not positive definite
-BMPC_DEV bool chol9(const double* W, double reg, double* Lc /*45 packed lower*/) {
+BMPC_INL bool chol9(const LDSD* W, double reg, double* Lc /*45 packed lower*/) {
     bool ok = true;
 #define LI(i, j) Lc[(i) * ((i) + 1) / 2 + (j)]
+#pragma unroll
     for (int j = 0; j < NU; j++) {
         double d = W[(NX + j) * LDW + NX + j] + reg;
+#pragma unroll
         for (int l = 0; l < j; l++) d -= LI(j, l) * LI(j, l);
         if (!(d > 0)) { ok = false; d = 1.0; }
         d = sqrt(d);
         LI(j, j) = d;
+#pragma unroll
         for (int i = j + 1; i < NU; i++) {
             double s = W[(NX + i) * LDW + NX + j];
+#pragma unroll
             for (int l = 0; l < j; l++) s -= LI(i, l) * LI(j, l);
             LI(i, j) = s / d;
         }
     }
     return ok;
 }
-BMPC_DEV void chol9_solve(const double* Lc, double* b) {
+BMPC_INL void chol9_solve(const double* Lc, double* b) {
+#pragma unroll
     for (int i = 0; i < NU; i++) {
         double s = b[i];
+#pragma unroll
         for (int l = 0; l < i; l++) s -= LI(i, l) * b[l];
         b[i] = s / LI(i, i);
     }
+#pragma unroll
     for (int i = NU - 1; i >= 0; i--) {
         double s = b[i];
+#pragma unroll
         for (int l = i + 1; l < NU; l++) s -= LI(l, i) * b[l];
         b[i] = s / LI(i, i);
     }
@@ -79,23 +87,21 @@ BMPC_DEV void chol9_solve(const double* Lc, double* b) {
 BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
                              double ad_pend, const double* iw0, double reg, double hreg, int hess_mode, Kkt& kk) {
     const int N = A.o.N;
-    const double* sp = L.sp;
-    const double* wts = sp + P_W;
+    const LDSD* sp = L.sp;
+    const LDSD* wts = sp + P_W;
     KktAcc ac;
     ac.cmax = 0; ac.csum = 0; ac.cmin = 1e300; ac.zsum = 0; ac.prim = 0; ac.theta = 0; ac.logs = 0;
     ac.lamsum = 0; ac.dual = 0; ac.nrows = 0;
     double fsum = 0;
     bool ok = true;
     if (lane < NX) { L.lam[lane] = 0; L.pv0[lane] = 0; L.pv1[lane] = 0; }
-    StageEval E;
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
         if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
         for (int e = lane; e < NZ * LDW; e += 64) L.W[e] = (e / LDW == e % LDW) ? hreg : 0.0;
         if (lane < ZPAD) { L.g0[lane] = 0; L.g1[lane] = 0; L.gz[lane] = 0; }
         BMPC_SYNC();
-        stage_eval(A, L, dc, k, lane, true, iw0, E);
-        fsum += E.fval;
+        fsum += stage_eval(A, L, dc, k, lane, true, iw0);
         // ---- rows: slack/multiplier data, KKT partial sums ----
         for (int m = 0; m < 4; m++) {
             int s = lane + 64 * m;
@@ -146,13 +152,13 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 if (o < 21) { L.Hp[6 * ia + ib] += acc; if (ia != ib) L.Hp[6 * ib + ia] += acc; }
                 else if (o < 39) L.mS[(sel - 1) * 6 + ia] = acc;
                 else if (o < 42) L.sS[sel - 1] = acc;
-                else if (o < 60) { double* dst = vecsel == 0 ? L.bp0 : vecsel == 1 ? L.bp1 : L.bpz; dst[ia] += acc; }
-                else { double* dst = vecsel == 0 ? L.bS0 : vecsel == 1 ? L.bS1 : L.bSz; dst[sel - 1] = acc; }
+                else if (o < 60) { LDSD* dst = vecsel == 0 ? L.bp0 : vecsel == 1 ? L.bp1 : L.bpz; dst[ia] += acc; }
+                else { LDSD* dst = vecsel == 0 ? L.bS0 : vecsel == 1 ? L.bS1 : L.bSz; dst[sel - 1] = acc; }
             }
             for (int o = lane; o < 132; o += 64) {
                 // per point c: 0..5 M3 sym, 6..8 mc, 9 sc, 10..18 b3{0,1,z}[3], 19..21 bc{0,1,z}
                 int c = o / 22, q = o - 22 * c;
-                const double* a = sp + P_ASETJ + 45 * c;
+                const LDSD* a = sp + SP_ASETJ + 45 * c;
                 double acc = 0;
                 int ia = 0, ib = 0, vs = 0;
                 if (q < 6) { int e = q, i = 0; while (e >= 3 - i) { e -= 3 - i; i++; } ia = i; ib = i + e; }
@@ -172,8 +178,8 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 if (q < 6) { L.M3[9 * c + 3 * ia + ib] = acc; L.M3[9 * c + 3 * ib + ia] = acc; }
                 else if (q < 9) L.mc[3 * c + ia] = acc;
                 else if (q == 9) L.sc[c] = acc;
-                else if (q < 19) { double* dst = vs == 0 ? L.b30 : vs == 1 ? L.b31 : L.b3z; dst[3 * c + ia] = acc; }
-                else { double* dst = vs == 0 ? L.bc0 : vs == 1 ? L.bc1 : L.bcz; dst[c] = acc; }
+                else if (q < 19) { LDSD* dst = vs == 0 ? L.b30 : vs == 1 ? L.b31 : L.b3z; dst[3 * c + ia] = acc; }
+                else { LDSD* dst = vs == 0 ? L.bc0 : vs == 1 ? L.bc1 : L.bcz; dst[c] = acc; }
             }
             // natural-diagonal rows straight into W / g
             if (lane < 38) {
@@ -206,8 +212,8 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         BMPC_SYNC();
         for (int e = lane; e < 204; e += 64) {
             int mat = e / 102, rr = (e % 102) / 17, cc = e % 17;
-            const double* H = mat ? L.Hv : L.Hp;
-            const double* O = mat ? L.Ov : L.Op;
+            const LDSD* H = mat ? L.Hv : L.Hp;
+            const LDSD* O = mat ? L.Ov : L.Op;
             double v = 0;
             for (int a = 0; a < 6; a++) v += H[6 * rr + a] * O[17 * a + cc];
             (mat ? L.T2 : L.T1)[17 * rr + cc] = v;
@@ -294,7 +300,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             BMPC_SYNC();
             const int njc[6] = {2, 3, 4, 5, 6, 4};
             for (int e = lane; e < 98; e += 64) {
-                const double* Fp = L.misc; const double* Fv = L.misc + 3; const double* Fc = L.misc + 9;
+                const LDSD* Fp = L.misc; const LDSD* Fv = L.misc + 3; const LDSD* Fc = L.misc + 9;
                 if (e < 49) {          // q_a x q_b
                     int a = e / 7, bq = e % 7, m = a < bq ? a : bq, M = a < bq ? bq : a;
                     double zm[3] = {L.zax[3 * m], L.zax[3 * m + 1], L.zax[3 * m + 2]};
@@ -367,7 +373,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         // ---- natural -> zeta coordinates: H = T^T Hy T (column pass, then row pass + vectors) ----
         for (int e = lane; e < NZ * 9; e += 64) {
             int i = e / 9, t = e % 9;
-            double* row = L.W + i * LDW;
+            LDSD* row = L.W + i * LDW;
             if (t < 7) row[Z_U + t] += dc.c3 * row[Z_Q + t] + dc.c2 * row[Z_DQ + t] + dc.c1 * row[Z_DDQ + t];
             else if (t == 7) row[Z_DRS] += 0.5 * dc.dt * row[Z_RS];
             else row[Z_DPS] += 0.5 * dc.dt * row[Z_PS];
@@ -376,13 +382,13 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         for (int e = lane; e < NZ * 9 + 27; e += 64) {
             if (e < NZ * 9) {
                 int j = e / 9, t = e % 9;
-                double* W = L.W;
+                LDSD* W = L.W;
                 if (t < 7) W[(Z_U + t) * LDW + j] += dc.c3 * W[(Z_Q + t) * LDW + j] + dc.c2 * W[(Z_DQ + t) * LDW + j] + dc.c1 * W[(Z_DDQ + t) * LDW + j];
                 else if (t == 7) W[Z_DRS * LDW + j] += 0.5 * dc.dt * W[Z_RS * LDW + j];
                 else W[Z_DPS * LDW + j] += 0.5 * dc.dt * W[Z_PS * LDW + j];
             } else {
                 int vsel = (e - NZ * 9) / 9, t = (e - NZ * 9) % 9;
-                double* g = vsel == 0 ? L.g0 : vsel == 1 ? L.g1 : L.gz;
+                LDSD* g = vsel == 0 ? L.g0 : vsel == 1 ? L.g1 : L.gz;
                 if (t < 7) g[Z_U + t] += dc.c3 * g[Z_Q + t] + dc.c2 * g[Z_DQ + t] + dc.c1 * g[Z_DDQ + t];
                 else if (t == 7) g[Z_DRS] += 0.5 * dc.dt * g[Z_RS];
                 else g[Z_DPS] += 0.5 * dc.dt * g[Z_PS];
@@ -466,9 +472,11 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         if (!chol9(L.W, reg, Lc)) ok = false;
         if (lane < NX + 2) {
             double rhs[NU];
+#pragma unroll
             for (int l = 0; l < NU; l++)
                 rhs[l] = (lane < NX) ? L.W[(NX + l) * LDW + lane] : (lane == NX ? L.g0[NX + l] : L.g1[NX + l]);
             chol9_solve(Lc, rhs);
+#pragma unroll
             for (int l = 0; l < NU; l++) {
                 if (lane < NX) { L.Kl[l * NX + lane] = -rhs[l]; ws.K[(size_t)k * NU * NX + l * NX + lane] = -rhs[l]; }
                 else { L.kf[(lane - NX) * 16 + l] = -rhs[l]; ws.kf[k * 32 + (lane - NX) * 16 + l] = -rhs[l]; }
@@ -485,8 +493,8 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         }
         {
             int i = lane & (NX - 1);
-            const double* g = (lane < NX) ? L.g0 : L.g1;
-            const double* kf = L.kf + ((lane < NX) ? 0 : 16);
+            const LDSD* g = (lane < NX) ? L.g0 : L.g1;
+            const LDSD* kf = L.kf + ((lane < NX) ? 0 : 16);
             double v = g[i];
             for (int l = 0; l < NU; l++) v += L.W[(NX + l) * LDW + i] * kf[l];
             ((lane < NX) ? L.pv0 : L.pv1)[i] = v;
@@ -521,8 +529,8 @@ struct StepInfo { double ap, ad, dphi_f, dphi_bar; bool ok; };
 BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
                             double mu, const double* iw0, StepInfo& si) {
     const int N = A.o.N;
-    const double* sp = L.sp;
-    const double* wts = sp + P_W;
+    const LDSD* sp = L.sp;
+    const LDSD* wts = sp + P_W;
     double tau = fmax(0.99, 1.0 - mu);
     double ap_l = 1.0, ad_l = 1.0, dbar_l = 0.0, dphi_f = 0.0;
     si.ok = true;
@@ -555,7 +563,6 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
         if (lane == 0) for (int i = 0; i < 8; i++) L.dx[24 + i] = rhs[i];
         BMPC_SYNC();
     }
-    StageEval E;
     for (int k = 1; k < N; k++) {
         if (lane < NZ) {
             double z = ws.zeta[k * ZPAD + lane];
@@ -566,7 +573,7 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
         for (int e = lane; e < NU * NX; e += 64) L.Kl[e] = ws.K[(size_t)k * NU * NX + e];
         if (lane < 32) L.kf[lane] = ws.kf[k * 32 + lane];
         BMPC_SYNC();
-        stage_eval(A, L, dc, k, lane, false, iw0, E);
+        stage_eval(A, L, dc, k, lane, false, iw0);
         // g0 := dzeta, g1 := dy (natural)
         if (lane < NX) L.g0[lane] = L.dx[lane];
         else if (lane < NZ) {
@@ -594,11 +601,11 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
         // directional derivative of f (every lane, registers)
         {
             double s = 0;
-            for (int a = 0; a < 6; a++) s += E.g12[a] * L.dloc[a];
+            for (int a = 0; a < 6; a++) s += L.kin[KN_G12 + a] * L.dloc[a];
             for (int a = 0; a < 6; a++) {
                 double dv = 0;
-                for (int j = 0; j < 7; j++) dv += E.G[a][j] * L.g1[Z_Q + j] + E.J[a][j] * L.g1[Z_DQ + j];
-                s += E.g12[6 + a] * dv;
+                for (int j = 0; j < 7; j++) dv += L.G[7 * a + j] * L.g1[Z_Q + j] + L.J[7 * a + j] * L.g1[Z_DQ + j];
+                s += L.kin[KN_G12 + 6 + a] * dv;
             }
             for (int j = 2; j <= 4; j++) s += 2 * wts[6] * L.yz[Z_DQ + j] * L.g1[Z_DQ + j];
             for (int j = 0; j < 7; j++) s += 2 * wts[7] * L.yz[Z_U + j] * L.g1[Z_U + j];
@@ -641,7 +648,7 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
         // next dx = A dx + B dw + defect
         if (k < N - 1) {
             if (lane < NX) {
-                const double* d = L.g0;
+                const LDSD* d = L.g0;
                 int i = lane;
                 double v;
                 if (i < Z_DQ) v = d[i] + dc.dt * d[i + 7] + 0.5 * dc.dt * dc.dt * d[i + 14] + dc.b3 * d[Z_U + i];
@@ -673,7 +680,6 @@ BMPC_DEV void trial_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, co
                           double alpha, const double* iw0, double& f1, double& th1, double& ls1) {
     const int N = A.o.N;
     double th_l = 0, ls_l = 0, fs = 0;
-    StageEval E;
     for (int k = N - 1; k >= 1; k--) {
         if (lane < NZ) {
             double z = ws.zsave[k * ZPAD + lane] + alpha * ws.dz[k * ZPAD + lane];
@@ -681,8 +687,7 @@ BMPC_DEV void trial_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, co
             ws.zeta[k * ZPAD + lane] = z;
         }
         BMPC_SYNC();
-        stage_eval(A, L, dc, k, lane, false, iw0, E);
-        fs += E.fval;
+        fs += stage_eval(A, L, dc, k, lane, false, iw0);
         for (int m = 0; m < 4; m++) {
             int s = lane + 64 * m;
             if (s >= NSLOT) break;
@@ -719,7 +724,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
     ws_carve(wsbase, N, ws);
     const double* x0 = A.x0 + (size_t)b * n_w;
     const double* lbx = A.lbx + (size_t)b * n_w;
-    for (int e = lane; e < NPAR; e += 64) L.sp[e] = A.p[(size_t)b * NPAR + e];
+    for (int e = lane; e < NSP; e += 64) L.sp[e] = A.p[(size_t)b * NPAR + (e < SP_ASETJ ? e : e + (P_ASETJ - SP_ASETJ))];
     // stage-0 pins (BoundMPC.py:551-556): lbx == ubx there
     double iw0[3];
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
@@ -734,41 +739,41 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
         L.x1fix[Z_PI + c] = lbx[28 * N + (3 + c) * N] + dt / 2 * lbx[34 * N + (3 + c) * N];
     }
     BMPC_SYNC();
-    // ---- initial iterate from x0 (natural -> zeta) ----
+    // ---- initial iterate from x0 (natural -> zeta); pi_k = p_rot_k - dt/2 w(q_k, dq_k) ----
     for (int k = 1; k < N; k++) {
-        double q[7], dq[7];
-        for (int j = 0; j < 7; j++) { q[j] = x0[j * N + k]; dq[j] = x0[7 * N + j * N + k]; }
-        Kin kin;
-        double J[6][7], G[6][7], v[6];
-        kin_eval(A.rc, q, kin);
-        kin_jac(kin, dq, J, G, v);
         if (lane < 7) {
             int j = lane;
             double uu = x0[21 * N + j * N + k];
-            ws.zeta[k * ZPAD + Z_Q + j] = q[j] - dc.c3 * uu;
-            ws.zeta[k * ZPAD + Z_DQ + j] = dq[j] - dc.c2 * uu;
-            ws.zeta[k * ZPAD + Z_DDQ + j] = x0[14 * N + j * N + k] - dc.c1 * uu;
-            ws.zeta[k * ZPAD + Z_U + j] = uu;
+            L.zeta[Z_Q + j] = x0[j * N + k] - dc.c3 * uu;
+            L.zeta[Z_DQ + j] = x0[7 * N + j * N + k] - dc.c2 * uu;
+            L.zeta[Z_DDQ + j] = x0[14 * N + j * N + k] - dc.c1 * uu;
+            L.zeta[Z_U + j] = uu;
         } else if (lane < 10) {
             int c = lane - 7;
-            ws.zeta[k * ZPAD + Z_PI + c] = x0[28 * N + (3 + c) * N + k] - dt / 2 * v[3 + c];
+            L.zeta[Z_PI + c] = x0[28 * N + (3 + c) * N + k];      // p_rot for now
         } else if (lane == 10) {
             double rs = x0[40 * N + 6 + k], drs = x0[41 * N + 6 + k], ps = x0[42 * N + 6 + k], dps = x0[43 * N + 6 + k];
-            ws.zeta[k * ZPAD + Z_RS] = rs - dt / 2 * drs; ws.zeta[k * ZPAD + Z_PS] = ps - dt / 2 * dps;
-            ws.zeta[k * ZPAD + Z_DRS] = drs; ws.zeta[k * ZPAD + Z_DPS] = dps;
+            L.zeta[Z_RS] = rs - dt / 2 * drs; L.zeta[Z_PS] = ps - dt / 2 * dps;
+            L.zeta[Z_DRS] = drs; L.zeta[Z_DPS] = dps;
         } else if (lane < 17) {
             int i = lane - 11;
-            ws.zeta[k * ZPAD + Z_D + i] = x0[40 * N + i];
+            L.zeta[Z_D + i] = x0[40 * N + i];
         }
+        BMPC_SYNC();
+        stage_eval(A, L, dc, k, lane, false, iw0);
+        if (lane < NZ) {
+            double z = L.zeta[lane];
+            if (lane >= Z_PI && lane < Z_RS) z -= dt / 2 * L.rc[RC_V + 3 + lane - Z_PI];
+            ws.zeta[k * ZPAD + lane] = z;
+        }
+        BMPC_SYNC();
     }
-    BMPC_SYNC();
     // ---- row slacks / multipliers: t = max(-h, 1e-2), z = 1 ----
     {
-        StageEval E;
-        for (int k = N - 1; k >= 1; k--) {
+            for (int k = N - 1; k >= 1; k--) {
             if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
             BMPC_SYNC();
-            stage_eval(A, L, dc, k, lane, false, iw0, E);
+            stage_eval(A, L, dc, k, lane, false, iw0);
             for (int m = 0; m < 4; m++) {
                 int s = lane + 64 * m;
                 if (s >= NSLOT) break;
@@ -862,11 +867,10 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
             x[28 * N + c * N] = lbx[28 * N + c * N];
             x[34 * N + c * N] = lbx[34 * N + c * N];
         }
-        StageEval E;
-        for (int k = N - 1; k >= 1; k--) {
+            for (int k = N - 1; k >= 1; k--) {
             if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
             BMPC_SYNC();
-            stage_eval(A, L, dc, k, lane, false, iw0, E);
+            stage_eval(A, L, dc, k, lane, false, iw0);
             if (lane < 28) {
                 int blk = lane / 7, j = lane - 7 * blk;
                 int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + j;
@@ -914,9 +918,9 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
                     double v;
                     bool lower = (s >= S_ROTL && s < S_COL) || (s >= S_TROTL);
                     if (r.kind) v = lower ? -r.h : r.h;
-                    else if (s < S_ROTU) v = -sp_b(L.sp, P_BSET, s - S_EE, 4, (int)L.rc[RC_SEG]) - L.yz[Z_PS];
-                    else if (s < S_PHI) { int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c; v = -L.sp[P_BSETJ + rr * 6 + c] - L.rc[RC_SL + c]; }
-                    else v = -sp_b(L.sp, P_BSET, s - S_TSET, 4, (int)L.rc[RC_SEG + 1]) - L.rc[RC_SL + 5];
+                    else if (s < S_ROTU) v = -sp_b(A.p + (size_t)b * NPAR, P_BSET, s - S_EE, 4, (int)L.rc[RC_SEG]) - L.yz[Z_PS];
+                    else if (s < S_PHI) { int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c; v = -L.sp[SP_BSETJ + rr * 6 + c] - L.rc[RC_SL + c]; }
+                    else v = -sp_b(A.p + (size_t)b * NPAR, P_BSET, s - S_TSET, 4, (int)L.rc[RC_SEG + 1]) - L.rc[RC_SL + 5];
                     gi[s - S_EE] = v;
                 }
             }

@@ -37,7 +37,7 @@ typedef struct {
     double hess_switch; /* hess==2: KKT error below which second-order terms are used */
     double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule */
     int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
-    int blocks_per_cu;  /* resident workgroups per CU (0 = default 2) */
+    int blocks_per_cu;  /* resident workgroups per CU (0 = default 3) */
 } bmpc_opts;
 
 void bmpc_default_opts(bmpc_opts* o, int N);

@@ -16,10 +16,12 @@ static thread_local int t_lane = 0;
 #define BMPC_DEV
 #define BMPC_INL inline
 #define BMPC_HD inline
+typedef double LDSD;
 #define BMPC_SYNC() g_bar->arrive_and_wait()
 #define BMPC_LANE() t_lane
 #define BMPC_BLOCK() 0
 #define BMPC_NBLOCKS() 1
+#define BMPC_ATOMIC_INC(ptr) __atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED)
 using std::fmax;
 using std::fmin;
 
@@ -41,6 +43,8 @@ extern "C" int emu_solve(int N, double dt, double tol, int max_iter, int hess, d
     A.x = x; A.f = f; A.viol = viol; A.g = nullptr; A.iters = iters; A.status = status;
     std::vector<double> ws(ws_doubles(N), 0.0), lds(LDS_DOUBLES + 64, 0.0);
     A.ws = ws.data();
+    int counter = 0;
+    A.counter = &counter;
     Lds L;
     lds_carve(lds.data(), L);
     if (L.misc + 64 - lds.data() > LDS_DOUBLES) { fprintf(stderr, "LDS carve overflow %ld > %d\n", (long)(L.misc + 64 - lds.data()), LDS_DOUBLES); return -2; }
