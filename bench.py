@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=HORIZON)
     ap.add_argument("--hess", type=int, default=None)
+    ap.add_argument("--wpi", type=int, default=None, help="wavefronts per instance (1, 2, 4)")
+    ap.add_argument("--bpc", type=int, default=None, help="resident workgroups per CU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -67,6 +69,10 @@ def main():
 
     N, B = args.horizon, args.batch
     kw = {} if args.hess is None else {"hess": args.hess}
+    if args.wpi is not None:
+        kw["waves_per_instance"] = args.wpi
+    if args.bpc is not None:
+        kw["blocks_per_cu"] = args.bpc
     be = HipBoundMPC(N, device=local_rank, **kw)
     t0 = time.time()
     batch = scenes.make_batch(B, N, 8192 + rank, be.fk, randomize_sets=True)
@@ -131,7 +137,7 @@ def main():
         "config": {"workload": f"BASELINE configs[2]: {B}-batch per GPU, randomized convex-set obstacles, N={N}, "
                                "cold start, tol 1e-5, max_iter 100", "batch_per_gpu": B, "horizon": N,
                    "sharding": "independent instances per rank + RCCL all-gather of x" if world > 1 else "single GPU",
-                   "hess": int(be.opts.hess)},
+                   "hess": int(be.opts.hess), "waves_per_instance": int(be.opts.waves_per_instance)},
         "solver": {"iters_mean": mean_it, "iters_p50": float(np.median(it_np)), "iters_p99": float(np.percentile(it_np, 99)),
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
                    "accepted_frac": float(ok.mean()), "gen_s": t_gen},

@@ -1,7 +1,8 @@
 // libboundmpc_hip.so: C ABI (include/boundmpc.h) + kernel launches for gfx950.
 #include "bmpc_platform_hip.hpp"
 
-#include "bmpc_solver.hpp"
+#define BMPC_NT 64
+#include "bmpc_device.hpp"
 #include "bmpc_robot.hpp"
 
 #include <cstdio>
@@ -13,40 +14,11 @@
 
 using namespace bmpc;
 
-__global__ __launch_bounds__(64) void bmpc_solve_kernel(KernelArgs A) {
-    __shared__ double lds[LDS_DOUBLES];
-    Lds L;
-    lds_carve((LDSD*)lds, L);
-    const int lane = BMPC_LANE();
-    double* wsb = A.ws + (size_t)BMPC_BLOCK() * ws_doubles(A.o.N);
-    // one wavefront per instance; resident workgroups pull the next instance from a device-scope
-    // counter (iteration counts vary 7..100, so a static deal leaves most CUs idle at the tail)
-    for (;;) {
-        if (lane == 0) L.misc[63] = (double)BMPC_ATOMIC_INC(A.counter);
-        BMPC_SYNC();
-        int b = (int)L.misc[63];
-        BMPC_SYNC();
-        if (b >= A.B) break;
-        solve_instance(A, L, wsb, b, lane);
-    }
-}
-
-__global__ void bmpc_fk_kernel(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
-                               double* ee_rot, double* col_pts, double* jac, double* dvdq) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double qq[7], dd[7];
-    for (int j = 0; j < 7; j++) { qq[j] = q[(size_t)b * 7 + j]; dd[j] = dq ? dq[(size_t)b * 7 + j] : 0.0; }
-    Kin k;
-    double J[6][7], G[6][7], v[6];
-    kin_eval(rc, qq, k);
-    kin_jac(k, dd, J, G, v);
-    if (ee_pos) for (int a = 0; a < 3; a++) ee_pos[(size_t)b * 3 + a] = k.pee[a];
-    if (ee_rot) for (int a = 0; a < 9; a++) ee_rot[(size_t)b * 9 + a] = k.Ree[a];
-    if (col_pts) for (int c = 0; c < 6; c++) for (int a = 0; a < 3; a++) col_pts[(size_t)b * 18 + 3 * c + a] = k.pc[c][a];
-    if (jac) for (int a = 0; a < 6; a++) for (int j = 0; j < 7; j++) jac[(size_t)b * 42 + 7 * a + j] = J[a][j];
-    if (dvdq) for (int a = 0; a < 6; a++) for (int j = 0; j < 7; j++) dvdq[(size_t)b * 42 + 7 * a + j] = G[a][j];
-}
+extern "C" hipError_t bmpc_launch_solve_nt64(const KernelArgs* A, int nblocks, hipStream_t st);
+extern "C" hipError_t bmpc_launch_solve_nt128(const KernelArgs* A, int nblocks, hipStream_t st);
+extern "C" hipError_t bmpc_launch_solve_nt256(const KernelArgs* A, int nblocks, hipStream_t st);
+extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
+                                     double* ee_rot, double* col_pts, double* jac, double* dvdq, hipStream_t st);
 
 struct bmpc_handle {
     bmpc_opts o;
@@ -54,6 +26,7 @@ struct bmpc_handle {
     RobotConst* d_rc = nullptr;
     double* d_ws = nullptr;
     int* d_counter = nullptr;
+    double* d_prof = nullptr;   // diagnostic builds only
     size_t ws_blocks = 0;
     // staging for the host-pointer entry
     double *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr, *d_x = nullptr, *d_g = nullptr,
@@ -79,13 +52,14 @@ struct bmpc_handle {
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
     o->hess = 2; o->hess_switch = 0.1; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->max_batch = 0; o->blocks_per_cu = 0;
+    o->max_batch = 0; o->blocks_per_cu = 0; o->waves_per_instance = 1;
 }
 
 extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     if (!o || !out) return 1;
     *out = nullptr;
     if (o->N < 3 || o->N > 64 || o->nr_segs != 4 || !(o->dt > 0)) return 1;
+    if (o->waves_per_instance != 1 && o->waves_per_instance != 2 && o->waves_per_instance != 4) return 1;
     bmpc_handle* h = new bmpc_handle();
     h->o = *o;
     h->n_w = 44 * o->N + 6;
@@ -107,6 +81,8 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     h->ws_blocks = (size_t)h->nblocks_max;
     HIPCHK(h, hipMalloc((void**)&h->d_ws, h->ws_blocks * (size_t)ws_doubles(o->N) * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_counter, sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&h->d_prof, (size_t)h->nblocks_max * 16 * sizeof(double)));
+    HIPCHK(h, hipMemset(h->d_prof, 0, (size_t)h->nblocks_max * 16 * sizeof(double)));
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -121,6 +97,7 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_rc) (void)hipFree(h->d_rc);
     if (h->d_counter) (void)hipFree(h->d_counter);
+    if (h->d_prof) (void)hipFree(h->d_prof);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -163,12 +140,15 @@ static int launch(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx
     A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
     A.ws = h->d_ws;
     A.counter = h->d_counter;
+    A.prof = h->d_prof;
     int nblocks = B < h->nblocks_max ? B : h->nblocks_max;
     if (nblocks < 1) return 0;
     HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), st));
     HIPCHK(h, hipEventRecord(h->ev0, st));
-    hipLaunchKernelGGL(bmpc_solve_kernel, dim3(nblocks), dim3(64), 0, st, A);
-    HIPCHK(h, hipGetLastError());
+    int wpi = h->o.waves_per_instance;
+    hipError_t le = (wpi == 4) ? bmpc_launch_solve_nt256(&A, nblocks, st)
+                  : (wpi == 2) ? bmpc_launch_solve_nt128(&A, nblocks, st) : bmpc_launch_solve_nt64(&A, nblocks, st);
+    HIPCHK(h, le);
     HIPCHK(h, hipEventRecord(h->ev1, st));
     return 0;
 }
@@ -263,9 +243,7 @@ extern "C" int bmpc_fk(bmpc_handle* h, int B, const double* q, const double* dq,
     else HIPCHK(h, hipMemset(d_dq, 0, (size_t)B * 7 * sizeof(double)));
     double* o_pos = d_out; double* o_rot = o_pos + (size_t)B * 3; double* o_col = o_rot + (size_t)B * 9;
     double* o_jac = o_col + (size_t)B * 18; double* o_dv = o_jac + (size_t)B * 42;
-    hipLaunchKernelGGL(bmpc_fk_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, B, h->d_rc, d_q, d_dq, o_pos,
-                       o_rot, o_col, o_jac, o_dv);
-    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, bmpc_launch_fk(B, h->d_rc, d_q, d_dq, o_pos, o_rot, o_col, o_jac, o_dv, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (ee_pos) HIPCHK(h, hipMemcpy(ee_pos, o_pos, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost));
     if (ee_rot) HIPCHK(h, hipMemcpy(ee_rot, o_rot, (size_t)B * 9 * sizeof(double), hipMemcpyDeviceToHost));
@@ -273,5 +251,16 @@ extern "C" int bmpc_fk(bmpc_handle* h, int B, const double* q, const double* dq,
     if (jac) HIPCHK(h, hipMemcpy(jac, o_jac, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
     if (dvdq) HIPCHK(h, hipMemcpy(dvdq, o_dv, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(d_q); (void)hipFree(d_dq); (void)hipFree(d_out);
+    return 0;
+}
+
+// diagnostic: per-phase cycle sums accumulated by a -DBMPC_PROFILE build (zeros otherwise)
+extern "C" int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16) {
+    if (!h || !out16) return 1;
+    std::vector<double> buf((size_t)h->nblocks_max * 16);
+    HIPCHK(h, hipMemcpy(buf.data(), h->d_prof, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) out16[i] = 0;
+    for (int b = 0; b < h->nblocks_max; b++) for (int i = 0; i < 16; i++) out16[i] += buf[(size_t)b * 16 + i];
+    HIPCHK(h, hipMemset(h->d_prof, 0, buf.size() * sizeof(double)));
     return 0;
 }

@@ -70,6 +70,7 @@ struct KernelArgs {
     int *iters, *status;
     double* ws;                         // scratch: nblocks * ws_doubles(N)
     int* counter;                       // next instance to hand out (zeroed before every launch)
+    double* prof;                       // diagnostic builds: per-block phase cycle sums (16 per block) or null
 };
 
 BMPC_HD int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32); }
@@ -81,7 +82,7 @@ struct Lds {
     LDSD *P, *W, *sp, *zeta, *znext, *yz, *g0, *g1, *gz, *lam, *pv0, *pv1, *vt0, *vt1, *rdef,
         *J, *G, *Jp, *zax, *pc, *Op, *Ov, *T1, *T2, *Hp, *Hv, *mS, *sS, *bp0, *bp1, *bpz, *bv,
         *bS0, *bS1, *bSz, *M3, *mc, *sc, *b30, *b31, *b3z, *bc0, *bc1, *bcz, *rowS, *rowA, *rowSl,
-        *rc, *Kl, *kf, *Y, *Et, *red, *dx, *dxn, *dloc, *dpt, *x1fix, *r0, *misc, *kin;
+        *rc, *Kl, *kf, *Y, *Et, *red, *dx, *dxn, *dloc, *dpt, *x1fix, *r0, *misc, *kin, *rob;
 };
 constexpr int LDS_DOUBLES =
     NX * LDP + NZ * LDW + NSP + 2 * ZPAD + ZPAD +             // P W sp zeta znext yz
@@ -90,8 +91,8 @@ constexpr int LDS_DOUBLES =
     4 * 102 + 36 + 36 + 18 + 3 + 18 + 6 + 9 +                 // Op Ov T1 T2 Hp Hv mS sS bp* bv bS*
     54 + 18 + 6 + 54 + 18 +                                   // M3 mc sc b3* bc*
     4 * NSLOT + NPOSE * 6 + NPOSE +                           // rowS rowA rowSl
-    160 + 32 + 64 +                                           // rc kf red (Kl aliases Op..T2, Y/Et alias rowA)
-    2 * NX + 16 + 24 + 24 + NX + 64 + 160;                    // dx dxn dloc dpt x1fix r0 misc kin
+    160 + 32 + BMPC_NT +                                      // rc kf red (Kl aliases Op..T2, Y/Et alias rowA)
+    2 * NX + 16 + 24 + 24 + NX + 64 + 160 + 96;               // dx dxn dloc dpt x1fix r0 misc kin rob
 
 BMPC_INL void lds_carve(LDSD* b, Lds& L) {
     auto take = [&](int n) { LDSD* r = b; b += n; return r; };
@@ -113,8 +114,8 @@ BMPC_INL void lds_carve(LDSD* b, Lds& L) {
     L.Kl = L.Op;          // gains are written after the chain phases are done with Op/Ov/T1/T2 (408 >= 288)
     L.Y = L.rowA;         // coupling scratch reuses the pose-row gradients (301 >= 246)
     L.Et = L.rowA + NZ * 3;
-    L.red = take(64); L.dx = take(NX); L.dxn = take(NX); L.dloc = take(16); L.dpt = take(24);
-    L.x1fix = take(24); L.r0 = take(NX); L.misc = take(64); L.kin = take(160);
+    L.red = take(BMPC_NT); L.dx = take(NX); L.dxn = take(NX); L.dloc = take(16); L.dpt = take(24);
+    L.x1fix = take(24); L.r0 = take(NX); L.misc = take(64); L.kin = take(160); L.rob = take(96);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -126,11 +127,11 @@ template <class PA, class PB> BMPC_INL void cross3(PA a, PB b, double* c) {
     c[1] = a[2] * b[0] - a[0] * b[2];
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
-BMPC_INL void mat3mul(const double* A, const double* B, double* C) {
+template <class PA, class PB> BMPC_INL void mat3mul(PA A, PB B, double* C) {
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
-BMPC_INL void mat3vec(const double* A, const double* v, double* r) {
+template <class PA, class PB> BMPC_INL void mat3vec(PA A, PB v, double* r) {
     for (int i = 0; i < 3; i++) r[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
 }
 
@@ -138,35 +139,40 @@ BMPC_INL void mat3vec(const double* A, const double* v, double* r) {
 BMPC_DEV double wg_sum(double v, LDSD* red, int lane) {
     BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
     double s = 0;
-    for (int i = 0; i < 64; i++) s += red[i];
+    for (int i = 0; i < BMPC_NT; i++) s += red[i];
     return s;
 }
 BMPC_DEV double wg_max(double v, LDSD* red, int lane) {
     BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
     double s = red[0];
-    for (int i = 1; i < 64; i++) s = fmax(s, red[i]);
+    for (int i = 1; i < BMPC_NT; i++) s = fmax(s, red[i]);
     return s;
 }
 BMPC_DEV double wg_min(double v, LDSD* red, int lane) {
     BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
     double s = red[0];
-    for (int i = 1; i < 64; i++) s = fmin(s, red[i]);
+    for (int i = 1; i < BMPC_NT; i++) s = fmin(s, red[i]);
     return s;
 }
 
 // sparse column structure of [As Bs] (constant part of the stage dynamics) for zeta column c:
 // returns number of (x-row, coefficient) pairs.
 struct DynC { double dt, b1, b2, b3, c1, c2, c3; };
-BMPC_INL int phi_col(int c, const DynC& d, int* idx, double* cf) {
-    if (c < Z_DQ) { idx[0] = c; cf[0] = 1.0; return 1; }
-    if (c < Z_DDQ) { idx[0] = c - 7; cf[0] = d.dt; idx[1] = c; cf[1] = 1.0; return 2; }
-    if (c < Z_PI) { idx[0] = c - 14; cf[0] = 0.5 * d.dt * d.dt; idx[1] = c - 7; cf[1] = d.dt; idx[2] = c; cf[2] = 1.0; return 3; }
-    if (c < Z_U) { idx[0] = c; cf[0] = 1.0; return 1; }
-    if (c < Z_DRS) { int j = c - Z_U; idx[0] = Z_Q + j; cf[0] = d.b3; idx[1] = Z_DQ + j; cf[1] = d.b2; idx[2] = Z_DDQ + j; cf[2] = d.b1; return 3; }
-    if (c == Z_DRS) { idx[0] = Z_RS; cf[0] = d.dt; return 1; }
-    idx[0] = Z_PS; cf[0] = d.dt; return 1;
+struct PhiCol { int i0, i1, i2; double c0, c1, c2; };   // by value: stays in registers
+BMPC_INL PhiCol phi_col(int c, const DynC& d) {
+    PhiCol r;
+    r.i0 = c; r.i1 = c; r.i2 = c; r.c0 = 1.0; r.c1 = 0.0; r.c2 = 0.0;
+    if (c < Z_DQ) {
+    } else if (c < Z_DDQ) { r.i0 = c - 7; r.c0 = d.dt; r.i1 = c; r.c1 = 1.0; }
+    else if (c < Z_PI) { r.i0 = c - 14; r.c0 = 0.5 * d.dt * d.dt; r.i1 = c - 7; r.c1 = d.dt; r.i2 = c; r.c2 = 1.0; }
+    else if (c < Z_U) {
+    } else if (c < Z_DRS) { int j = c - Z_U; r.i0 = Z_Q + j; r.c0 = d.b3; r.i1 = Z_DQ + j; r.c1 = d.b2; r.i2 = Z_DDQ + j; r.c2 = d.b1; }
+    else if (c == Z_DRS) { r.i0 = Z_RS; r.c0 = d.dt; r.i1 = Z_RS; r.i2 = Z_RS; }
+    else { r.i0 = Z_PS; r.c0 = d.dt; r.i1 = Z_PS; r.i2 = Z_PS; }
+    return r;
 }
 
+// kinematics for the stand-alone FK kernel (registers; the solver uses the LDS phases of stage_eval)
 struct Kin {
     double o[7][3], z[7][3], pee[3], Ree[9], pc[6][3];
 };
@@ -237,6 +243,7 @@ constexpr int RC_POSE = 0, RC_PROJ = 6, RC_PROJN = 9, RC_GS = 12, RC_GSN = 30, R
               RC_DPSI = 118, RC_DDPSI = 119, RC_ER2EP2 = 120, RC_DWVO = 121, RC_DER = 122 /*18*/,
               RC_GSR = 140 /*raw gs 18*/;
 // kin[] layout
+constexpr int RB_XYZ = 0, RB_ROT = 21, RB_EE = 84, RB_L4C = 87;
 constexpr int KN_O = 0 /*7x3*/, KN_PEE = 21, KN_CS = 24 /*cos7,sin7*/, KN_SUFC = 38 /*8x3*/, KN_SUFZ = 62,
               KN_PREZ = 86, KN_R1 = 110 /*3x6*/, KN_R2 = 128, KN_G12 = 146 /*12*/, KN_END = 158;
 
@@ -258,7 +265,6 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
                            const double* iw0) {
     const int N = A.o.N;
     const LDSD* sp = L.sp;
-    const RobotConst* rcn = A.rc;
     LDSD* rc = L.rc;
     LDSD* kn = L.kin;
     const bool term = (k == N - 1);
@@ -269,10 +275,12 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
     // ---- E1: kinematic chain (every lane, small live set; lane 0 publishes) ----
     {
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}, Rn[9], tmp[3];
+        const LDSD* rob = L.rob;
+#pragma unroll
         for (int i = 0; i < 7; i++) {
-            mat3vec(R, rcn->jxyz[i], tmp);
+            mat3vec(R, rob + RB_XYZ + 3 * i, tmp);
             for (int a = 0; a < 3; a++) t[a] += tmp[a];
-            mat3mul(R, rcn->jrot[i], Rn);
+            mat3mul(R, rob + RB_ROT + 9 * i, Rn);
             if (lane == 0)
                 for (int a = 0; a < 3; a++) { kn[KN_O + 3 * i + a] = t[a]; L.zax[3 * i + a] = Rn[3 * a + 2]; }
             double c = kn[KN_CS + i], s = kn[KN_CS + 7 + i];
@@ -282,11 +290,11 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
                 R[3 * a + 2] = Rn[3 * a + 2];
             }
             if (i == 3) {
-                mat3vec(R, rcn->l4c_xyz, tmp);
+                mat3vec(R, rob + RB_L4C, tmp);
                 if (lane == 0) for (int a = 0; a < 3; a++) L.pc[15 + a] = t[a] + tmp[a];
             }
         }
-        mat3vec(R, rcn->ee_xyz, tmp);
+        mat3vec(R, rob + RB_EE, tmp);
         if (lane == 0) for (int a = 0; a < 3; a++) kn[KN_PEE + a] = t[a] + tmp[a];
     }
     BMPC_SYNC();
@@ -306,7 +314,7 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
             L.pc[e] = kn[KN_O + 6 + e];     // pc[c] = o[c+2], c < 5
         }
         const int nj[6] = {2, 3, 4, 5, 6, 4};
-        for (int e = lane; e < 126; e += 64) {
+        for (int e = lane; e < 126; e += BMPC_NT) {
             int c = e / 21, a = (e % 21) / 7, i = e % 7;
             double v = 0;
             if (i < nj[c]) {
@@ -493,7 +501,7 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
     if (want_h) {
         const LDSD* wts = sp + P_W;
         double w_vp = wts[2], w_vr = wts[3];
-        for (int e = lane; e < 72; e += 64) {
+        for (int e = lane; e < 72; e += BMPC_NT) {
             if (e < 36) {
                 int i = e / 6, j = e % 6;
                 double h = 0;

@@ -3,6 +3,15 @@
 #pragma once
 #include "bmpc_device.hpp"
 
+// optional in-kernel phase timing (diagnostic builds only: -DBMPC_PROFILE; never in the product build)
+#ifdef BMPC_PROFILE
+#define BMPC_PROF_START() long long prof_t0_ = clock64()
+#define BMPC_PROF(i) do { long long t1_ = clock64(); if (lane == 0 && A.prof) A.prof[(size_t)BMPC_BLOCK() * 16 + (i)] += (double)(t1_ - prof_t0_); prof_t0_ = t1_; } while (0)
+#else
+#define BMPC_PROF_START() do {} while (0)
+#define BMPC_PROF(i) do {} while (0)
+#endif
+
 namespace bmpc {
 
 struct KktAcc {   // per-lane partial sums carried across a sweep
@@ -97,15 +106,15 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
     if (lane < NX) { L.lam[lane] = 0; L.pv0[lane] = 0; L.pv1[lane] = 0; }
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
+        BMPC_PROF_START();
         if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
-        for (int e = lane; e < NZ * LDW; e += 64) L.W[e] = (e / LDW == e % LDW) ? hreg : 0.0;
+        for (int e = lane; e < NZ * LDW; e += BMPC_NT) L.W[e] = (e / LDW == e % LDW) ? hreg : 0.0;
         if (lane < ZPAD) { L.g0[lane] = 0; L.g1[lane] = 0; L.gz[lane] = 0; }
         BMPC_SYNC();
         fsum += stage_eval(A, L, dc, k, lane, true, iw0);
+        BMPC_PROF(0);
         // ---- rows: slack/multiplier data, KKT partial sums ----
-        for (int m = 0; m < 4; m++) {
-            int s = lane + 64 * m;
-            if (s >= NSLOT) break;
+        for (int s = lane; s < NSLOT; s += BMPC_NT) {
             Row r;
             row_eval(A, L, b, k, s, r);
             double sg = 0, r0 = 0, r1 = 0, zz = 0;
@@ -127,54 +136,63 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
+        BMPC_PROF(1);
         // ---- group accumulations (one output per lane, serial over rows) ----
         {
-            const int slot_of_pr[3] = {S_EE, S_PHI - 21, S_TSET - 22};
-            for (int o = lane; o < 69; o += 64) {
+            // every output is  sum_rows  sign * scalar[row] * fa[row] * fb[row] * mask[row]  (branch-free)
+            for (int o = lane; o < 69; o += BMPC_NT) {
                 // outputs: 0..20 M6 (sym), 21..38 mS[3][6], 39..41 sS, 42..59 b{0,1,z}[6], 60..68 bS{0,1,z}[3]
-                double acc = 0;
-                int ia = 0, ib = 0, sel = 0, vecsel = 0;
-                if (o < 21) { int e = o, i = 0; while (e >= 6 - i) { e -= 6 - i; i++; } ia = i; ib = i + e; }
-                else if (o < 39) { sel = (o - 21) / 6 + 1; ia = (o - 21) % 6; }
+                int ia = 0, ib = 0, sel = 0, vecsel = 0, soff = 0;
+                bool useA = false, useB = false;
+                double sgn = 1.0;
+                if (o < 21) {
+                    int e = o, i = 0;
+                    if (e >= 6) { e -= 6; i = 1; } if (i == 1 && e >= 5) { e -= 5; i = 2; } if (i == 2 && e >= 4) { e -= 4; i = 3; }
+                    if (i == 3 && e >= 3) { e -= 3; i = 4; } if (i == 4 && e >= 2) { e -= 2; i = 5; }
+                    ia = i; ib = i + e; useA = true; useB = true;
+                } else if (o < 39) { sel = (o - 21) / 6 + 1; ia = (o - 21) % 6; useA = true; sgn = -1.0; }
                 else if (o < 42) { sel = o - 39 + 1; }
-                else if (o < 60) { vecsel = (o - 42) / 6; ia = (o - 42) % 6; }
-                else { vecsel = (o - 60) / 3; sel = (o - 60) % 3 + 1; }
+                else if (o < 60) { vecsel = (o - 42) / 6; ia = (o - 42) % 6; useA = true; soff = (vecsel + 1) * NSLOT; }
+                else { vecsel = (o - 60) / 3; sel = (o - 60) % 3 + 1; sgn = -1.0; soff = (vecsel + 1) * NSLOT; }
+                double acc = 0;
+                const double dsel = (double)sel;
+#pragma unroll 4
                 for (int pr = 0; pr < NPOSE; pr++) {
-                    double rsel = L.rowSl[pr];
-                    if (rsel < 0) continue;
-                    int s = pr + (pr < 21 ? slot_of_pr[0] : (pr == 21 ? slot_of_pr[1] : slot_of_pr[2]));
-                    if (o < 21) acc += L.rowS[s] * L.rowA[pr * 6 + ia] * L.rowA[pr * 6 + ib];
-                    else if (o < 39) { if ((int)rsel == sel) acc -= L.rowS[s] * L.rowA[pr * 6 + ia]; }
-                    else if (o < 42) { if ((int)rsel == sel) acc += L.rowS[s]; }
-                    else if (o < 60) acc += L.rowS[(vecsel == 0 ? NSLOT : vecsel == 1 ? 2 * NSLOT : 3 * NSLOT) + s] * L.rowA[pr * 6 + ia];
-                    else { if ((int)rsel == sel) acc -= L.rowS[(vecsel == 0 ? NSLOT : vecsel == 1 ? 2 * NSLOT : 3 * NSLOT) + s]; }
+                    int s = pr + (pr < 21 ? S_EE : S_PHI - 21);
+                    double v = L.rowS[soff + s];
+                    double fa = useA ? L.rowA[pr * 6 + ia] : 1.0;
+                    double fb = useB ? L.rowA[pr * 6 + ib] : 1.0;
+                    double mk = (sel == 0 || L.rowSl[pr] == dsel) ? 1.0 : 0.0;
+                    acc += v * fa * fb * mk;
                 }
+                acc *= sgn;
                 if (o < 21) { L.Hp[6 * ia + ib] += acc; if (ia != ib) L.Hp[6 * ib + ia] += acc; }
                 else if (o < 39) L.mS[(sel - 1) * 6 + ia] = acc;
                 else if (o < 42) L.sS[sel - 1] = acc;
                 else if (o < 60) { LDSD* dst = vecsel == 0 ? L.bp0 : vecsel == 1 ? L.bp1 : L.bpz; dst[ia] += acc; }
                 else { LDSD* dst = vecsel == 0 ? L.bS0 : vecsel == 1 ? L.bS1 : L.bSz; dst[sel - 1] = acc; }
             }
-            for (int o = lane; o < 132; o += 64) {
+            for (int o = lane; o < 132; o += BMPC_NT) {
                 // per point c: 0..5 M3 sym, 6..8 mc, 9 sc, 10..18 b3{0,1,z}[3], 19..21 bc{0,1,z}
                 int c = o / 22, q = o - 22 * c;
                 const LDSD* a = sp + SP_ASETJ + 45 * c;
+                int ia = 0, ib = 0, vs = 0, soff = 0;
+                bool useA = false, useB = false;
+                double sgn = 1.0;
+                if (q < 6) { int e = q, i = 0; if (e >= 3) { e -= 3; i = 1; } if (i == 1 && e >= 2) { e -= 2; i = 2; } ia = i; ib = i + e; useA = true; useB = true; }
+                else if (q < 9) { ia = q - 6; useA = true; sgn = -1.0; }
+                else if (q == 9) { }
+                else if (q < 19) { vs = (q - 10) / 3; ia = (q - 10) % 3; useA = true; soff = (vs + 1) * NSLOT; }
+                else { vs = q - 19; sgn = -1.0; soff = (vs + 1) * NSLOT; }
                 double acc = 0;
-                int ia = 0, ib = 0, vs = 0;
-                if (q < 6) { int e = q, i = 0; while (e >= 3 - i) { e -= 3 - i; i++; } ia = i; ib = i + e; }
-                else if (q < 9) ia = q - 6;
-                else if (q >= 10 && q < 19) { vs = (q - 10) / 3; ia = (q - 10) % 3; }
-                else if (q >= 19) vs = q - 19;
+#pragma unroll 5
                 for (int rr = 0; rr < 15; rr++) {
-                    int s = S_COL + 15 * c + rr;
-                    double sg = L.rowS[s];
-                    double rv = L.rowS[(vs == 0 ? NSLOT : vs == 1 ? 2 * NSLOT : 3 * NSLOT) + s];
-                    if (q < 6) acc += sg * a[rr + 15 * ia] * a[rr + 15 * ib];
-                    else if (q < 9) acc -= sg * a[rr + 15 * ia];
-                    else if (q == 9) acc += sg;
-                    else if (q < 19) acc += rv * a[rr + 15 * ia];
-                    else acc -= rv;
+                    double v = L.rowS[soff + S_COL + 15 * c + rr];
+                    double fa = useA ? a[rr + 15 * ia] : 1.0;
+                    double fb = useB ? a[rr + 15 * ib] : 1.0;
+                    acc += v * fa * fb;
                 }
+                acc *= sgn;
                 if (q < 6) { L.M3[9 * c + 3 * ia + ib] = acc; L.M3[9 * c + 3 * ib + ia] = acc; }
                 else if (q < 9) L.mc[3 * c + ia] = acc;
                 else if (q == 9) L.sc[c] = acc;
@@ -194,8 +212,9 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
+        BMPC_PROF(2);
         // ---- chain pose/velocity space through O = d(pose, v)/d(q, dq, pi) ----
-        for (int e = lane; e < 204; e += 64) {
+        for (int e = lane; e < 204; e += BMPC_NT) {
             int mat = e / 102, rr = (e % 102) / 17, cc = e % 17;
             double v = 0;
             if (mat == 0) {   // Op: rows p_pos (J lin) ; p_rot (dt/2 G_w | dt/2 J_w | I)
@@ -210,7 +229,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
-        for (int e = lane; e < 204; e += 64) {
+        for (int e = lane; e < 204; e += BMPC_NT) {
             int mat = e / 102, rr = (e % 102) / 17, cc = e % 17;
             const LDSD* H = mat ? L.Hv : L.Hp;
             const LDSD* O = mat ? L.Ov : L.Op;
@@ -222,7 +241,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         {
             auto pos17 = [](int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); };
             const int spos[3] = {Z_PS, Z_RS, Z_D + 5};
-            for (int e = lane; e < 289 + 51 + 3 + 20; e += 64) {
+            for (int e = lane; e < 289 + 51 + 3 + 20; e += BMPC_NT) {
                 if (e < 289) {
                     int i = e / 17, j = e % 17;
                     double v = 0;
@@ -251,8 +270,9 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
+        BMPC_PROF(3);
         // ---- collision points: q x q, q x d, d x d ----
-        for (int e = lane; e < 49 + 42 + 6 + 7; e += 64) {
+        for (int e = lane; e < 49 + 42 + 6 + 7; e += BMPC_NT) {
             if (e < 49) {
                 int i = e / 7, j = e % 7;
                 double v = 0;
@@ -285,6 +305,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
+        BMPC_PROF(4);
         // ---- second-order kinematic terms of the Lagrangian Hessian (hybrid mode) ----
         if (hess_mode) {
             if (lane < 27) {   // generalised forces: on p_ee (3), on v (6), on the 6 collision points (18)
@@ -299,7 +320,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
             BMPC_SYNC();
             const int njc[6] = {2, 3, 4, 5, 6, 4};
-            for (int e = lane; e < 98; e += 64) {
+            for (int e = lane; e < 98; e += BMPC_NT) {
                 const LDSD* Fp = L.misc; const LDSD* Fv = L.misc + 3; const LDSD* Fc = L.misc + 9;
                 if (e < 49) {          // q_a x q_b
                     int a = e / 7, bq = e % 7, m = a < bq ? a : bq, M = a < bq ? bq : a;
@@ -359,6 +380,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
             BMPC_SYNC();
         }
+        BMPC_PROF(5);
         // ---- direct quadratic cost terms (natural coordinates) ----
         if (lane < 20) {
             int pos; double w2; double val; double extra = 0;
@@ -370,8 +392,9 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             L.W[pos * LDW + pos] += w2; L.g0[pos] += val; L.gz[pos] += val;
         }
         BMPC_SYNC();
+        BMPC_PROF(6);
         // ---- natural -> zeta coordinates: H = T^T Hy T (column pass, then row pass + vectors) ----
-        for (int e = lane; e < NZ * 9; e += 64) {
+        for (int e = lane; e < NZ * 9; e += BMPC_NT) {
             int i = e / 9, t = e % 9;
             LDSD* row = L.W + i * LDW;
             if (t < 7) row[Z_U + t] += dc.c3 * row[Z_Q + t] + dc.c2 * row[Z_DQ + t] + dc.c1 * row[Z_DDQ + t];
@@ -379,7 +402,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             else row[Z_DPS] += 0.5 * dc.dt * row[Z_PS];
         }
         BMPC_SYNC();
-        for (int e = lane; e < NZ * 9 + 27; e += 64) {
+        for (int e = lane; e < NZ * 9 + 27; e += BMPC_NT) {
             if (e < NZ * 9) {
                 int j = e / 9, t = e % 9;
                 LDSD* W = L.W;
@@ -400,6 +423,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             L.W[pos * LDW + pos] += L.rowS[s];
             L.g0[pos] -= L.rowS[NSLOT + s]; L.g1[pos] -= L.rowS[2 * NSLOT + s]; L.gz[pos] -= L.rowS[3 * NSLOT + s];
         }
+        BMPC_PROF(7);
         // ---- coupling with stage k+1 ----
         if (!term) {
             if (lane < NZ) {
@@ -411,13 +435,10 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                     else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * L.G[7 * (3 + a) + c - Z_U] + dc.c2 * L.J[7 * (3 + a) + c - Z_U]);
                     L.Et[a * NZ + c] = v;
                 }
-                int idx[3]; double cf[3];
-                int n = phi_col(c, dc, idx, cf);
-                for (int a = 0; a < 3; a++) {
-                    double v = 0;
-                    for (int t = 0; t < n; t++) v += cf[t] * L.P[idx[t] * LDP + Z_PI + a];
-                    L.Y[c * 3 + a] = v;
-                }
+                PhiCol pc = phi_col(c, dc);
+                for (int a = 0; a < 3; a++)
+                    L.Y[c * 3 + a] = pc.c0 * L.P[pc.i0 * LDP + Z_PI + a] + pc.c1 * L.P[pc.i1 * LDP + Z_PI + a] +
+                                     pc.c2 * L.P[pc.i2 * LDP + Z_PI + a];
             }
             if (lane < NX) {
                 double r = defect_row(L, dc, lane);
@@ -429,30 +450,36 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 double v = L.pv0[lane];
                 for (int j = 0; j < NX; j++) v += L.P[lane * LDP + j] * L.rdef[j];
                 L.vt0[lane] = v;
-            } else {
+            } else if (lane < 2 * NX) {
                 L.vt1[lane - NX] = L.pv1[lane - NX];
             }
             BMPC_SYNC();
-            for (int e = lane; e < NZ * NZ; e += 64) {
-                int i = e / NZ, j = e % NZ;
-                int ii[3], jj[3]; double ci[3], cj[3];
-                int ni = phi_col(i, dc, ii, ci), nj = phi_col(j, dc, jj, cj);
-                double v = 0;
-                for (int a = 0; a < ni; a++)
-                    for (int bb = 0; bb < nj; bb++) v += ci[a] * cj[bb] * L.P[ii[a] * LDP + jj[bb]];
-                for (int a = 0; a < 3; a++) {
-                    double eai = L.Et[a * NZ + i], eaj = L.Et[a * NZ + j];
-                    v += L.Y[i * 3 + a] * eaj + eai * L.Y[j * 3 + a];
-                    if (eai != 0.0)
-                        for (int bb = 0; bb < 3; bb++) v += eai * L.P[(Z_PI + a) * LDP + Z_PI + bb] * L.Et[bb * NZ + j];
-                }
+            // W += [A B]^T P+ [A B]: structured part through the <=3-term column structure of [As Bs],
+            // dense rank-3 part through Y = [As Bs]^T P[:, pi] and E~; upper triangle, mirrored
+            for (int e = lane; e < NZ * NZ; e += BMPC_NT) {
+                int i = e / NZ, j = e - NZ * i;
+                if (j < i) continue;
+                PhiCol pi_ = phi_col(i, dc), pj = phi_col(j, dc);
+                const LDSD* P0 = L.P + pi_.i0 * LDP; const LDSD* P1 = L.P + pi_.i1 * LDP; const LDSD* P2 = L.P + pi_.i2 * LDP;
+                double v = pi_.c0 * (pj.c0 * P0[pj.i0] + pj.c1 * P0[pj.i1] + pj.c2 * P0[pj.i2]) +
+                           pi_.c1 * (pj.c0 * P1[pj.i0] + pj.c1 * P1[pj.i1] + pj.c2 * P1[pj.i2]) +
+                           pi_.c2 * (pj.c0 * P2[pj.i0] + pj.c1 * P2[pj.i1] + pj.c2 * P2[pj.i2]);
+                double ei0 = L.Et[i], ei1 = L.Et[NZ + i], ei2 = L.Et[2 * NZ + i];
+                double ej0 = L.Et[j], ej1 = L.Et[NZ + j], ej2 = L.Et[2 * NZ + j];
+                v += L.Y[i * 3] * ej0 + L.Y[i * 3 + 1] * ej1 + L.Y[i * 3 + 2] * ej2;
+                v += ei0 * L.Y[j * 3] + ei1 * L.Y[j * 3 + 1] + ei2 * L.Y[j * 3 + 2];
+                const LDSD* Pp = L.P + Z_PI * LDP + Z_PI;
+                v += ei0 * (Pp[0] * ej0 + Pp[1] * ej1 + Pp[2] * ej2) + ei1 * (Pp[LDP] * ej0 + Pp[LDP + 1] * ej1 + Pp[LDP + 2] * ej2) +
+                     ei2 * (Pp[2 * LDP] * ej0 + Pp[2 * LDP + 1] * ej1 + Pp[2 * LDP + 2] * ej2);
                 L.W[i * LDW + j] += v;
+                if (j != i) L.W[j * LDW + i] += v;
             }
             if (lane < NZ) {
-                int c = lane, idx[3]; double cf[3];
-                int n = phi_col(c, dc, idx, cf);
-                double gl = 0, a0 = 0, a1 = 0;
-                for (int t = 0; t < n; t++) { gl += cf[t] * L.lam[idx[t]]; a0 += cf[t] * L.vt0[idx[t]]; a1 += cf[t] * L.vt1[idx[t]]; }
+                int c = lane;
+                PhiCol pc = phi_col(c, dc);
+                double gl = pc.c0 * L.lam[pc.i0] + pc.c1 * L.lam[pc.i1] + pc.c2 * L.lam[pc.i2];
+                double a0 = pc.c0 * L.vt0[pc.i0] + pc.c1 * L.vt0[pc.i1] + pc.c2 * L.vt0[pc.i2];
+                double a1 = pc.c0 * L.vt1[pc.i0] + pc.c1 * L.vt1[pc.i1] + pc.c2 * L.vt1[pc.i2];
                 for (int a = 0; a < 3; a++) {
                     double ea = L.Et[a * NZ + c];
                     gl += ea * L.lam[Z_PI + a]; a0 += ea * L.vt0[Z_PI + a]; a1 += ea * L.vt1[Z_PI + a];
@@ -461,12 +488,14 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
+        BMPC_PROF(8);
         // ---- adjoint multipliers + dual residual (gz now holds the Lagrangian gradient) ----
         if (lane < NZ) {
             double gl = L.gz[lane];
             if (lane >= NX || (k == 1 && lane >= 24)) ac.dual = fmax(ac.dual, fabs(gl));
             if (lane < NX) { L.lam[lane] = gl; ac.lamsum += fabs(gl); }
         }
+        BMPC_PROF(9);
         // ---- control block factorisation, gains, Schur complement ----
         double Lc[45];
         if (!chol9(L.W, reg, Lc)) ok = false;
@@ -483,7 +512,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             }
         }
         BMPC_SYNC();
-        for (int e = lane; e < NX * NX; e += 64) {
+        for (int e = lane; e < NX * NX; e += BMPC_NT) {
             int i = e / NX, j = e % NX;
             if (j < i) continue;
             double v = L.W[i * LDW + j];
@@ -491,7 +520,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             L.P[i * LDP + j] = v;
             L.P[j * LDP + i] = v;
         }
-        {
+        if (lane < 2 * NX) {
             int i = lane & (NX - 1);
             const LDSD* g = (lane < NX) ? L.g0 : L.g1;
             const LDSD* kf = L.kf + ((lane < NX) ? 0 : 16);
@@ -501,6 +530,7 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         }
         if (lane < NZ) L.znext[lane] = L.zeta[lane];
         BMPC_SYNC();
+        BMPC_PROF(10);
     }
     // initial defect of the pinned part of x_1 (zeta_1 is still in L.zeta)
     if (lane < 24) {
@@ -570,7 +600,7 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
             ws.zsave[k * ZPAD + lane] = z;
             L.znext[lane] = (k < N - 1) ? ws.zeta[(k + 1) * ZPAD + lane] : 0.0;
         }
-        for (int e = lane; e < NU * NX; e += 64) L.Kl[e] = ws.K[(size_t)k * NU * NX + e];
+        for (int e = lane; e < NU * NX; e += BMPC_NT) L.Kl[e] = ws.K[(size_t)k * NU * NX + e];
         if (lane < 32) L.kf[lane] = ws.kf[k * 32 + lane];
         BMPC_SYNC();
         stage_eval(A, L, dc, k, lane, false, iw0);
@@ -618,9 +648,7 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
                 }
             dphi_f += s;
         }
-        for (int m = 0; m < 4; m++) {
-            int s = lane + 64 * m;
-            if (s >= NSLOT) break;
+        for (int s = lane; s < NSLOT; s += BMPC_NT) {
             Row r;
             row_eval(A, L, b, k, s, r);
             if (!r.kind) continue;
@@ -688,9 +716,7 @@ BMPC_DEV void trial_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, co
         }
         BMPC_SYNC();
         fs += stage_eval(A, L, dc, k, lane, false, iw0);
-        for (int m = 0; m < 4; m++) {
-            int s = lane + 64 * m;
-            if (s >= NSLOT) break;
+        for (int s = lane; s < NSLOT; s += BMPC_NT) {
             Row r;
             row_eval(A, L, b, k, s, r);
             if (!r.kind) continue;
@@ -724,7 +750,11 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
     ws_carve(wsbase, N, ws);
     const double* x0 = A.x0 + (size_t)b * n_w;
     const double* lbx = A.lbx + (size_t)b * n_w;
-    for (int e = lane; e < NSP; e += 64) L.sp[e] = A.p[(size_t)b * NPAR + (e < SP_ASETJ ? e : e + (P_ASETJ - SP_ASETJ))];
+    for (int e = lane; e < 90; e += BMPC_NT) {   // robot constants: jxyz[21] jrot[63] ee_xyz[3] l4c_xyz[3]
+        const double* rcp = (const double*)A.rc;
+        L.rob[e] = rcp[e < 87 ? e : e + 9];
+    }
+    for (int e = lane; e < NSP; e += BMPC_NT) L.sp[e] = A.p[(size_t)b * NPAR + (e < SP_ASETJ ? e : e + (P_ASETJ - SP_ASETJ))];
     // stage-0 pins (BoundMPC.py:551-556): lbx == ubx there
     double iw0[3];
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
@@ -774,9 +804,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
             if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
             BMPC_SYNC();
             stage_eval(A, L, dc, k, lane, false, iw0);
-            for (int m = 0; m < 4; m++) {
-                int s = lane + 64 * m;
-                if (s >= NSLOT) break;
+            for (int s = lane; s < NSLOT; s += BMPC_NT) {
                 Row r;
                 row_eval(A, L, b, k, s, r);
                 ws.t[k * NSLOT + s] = r.kind ? fmax(-r.h, 1e-2) : 1.0;
@@ -812,7 +840,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
         int tries = 0;
         StepInfo si;
         for (;;) {
-            if (ok) { forward_sweep(A, L, ws, dc, b, lane, mu, iw0, si); ok = si.ok; }
+            if (ok) { BMPC_PROF_START(); forward_sweep(A, L, ws, dc, b, lane, mu, iw0, si); ok = si.ok; BMPC_PROF(12); }
             if (ok) break;
             if (hess_mode) { hess_mode = 0; ++tries; }        // second-order terms not convex here: Gauss-Newton
             else {
@@ -832,7 +860,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
         bool armijo_case = false;
         for (int bt = 0; bt < 10; bt++) {
             double f1, th1, ls1;
-            trial_sweep(A, L, ws, dc, b, lane, alpha, iw0, f1, th1, ls1);
+            BMPC_PROF_START(); trial_sweep(A, L, ws, dc, b, lane, alpha, iw0, f1, th1, ls1); BMPC_PROF(13);
             double phi1 = f1 - mu * ls1;
             bool acc = (th1 <= theta_max);
             for (int j = 0; acc && j < nfilt; j++)
@@ -857,7 +885,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
     double* x = A.x + (size_t)b * n_w;
     double viol_l = 0;
     {
-        for (int e = lane; e < n_w; e += 64) x[e] = 0.0;
+        for (int e = lane; e < n_w; e += BMPC_NT) x[e] = 0.0;
         BMPC_SYNC();
         if (lane < 7) {
             int j = lane;
@@ -888,9 +916,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
                 x[40 * N + i] = L.yz[Z_D + i];
             }
             // constraint violation as BoundMPC.py:613-615 (g rows only, 1e-6 dead band)
-            for (int m = 0; m < 4; m++) {
-                int s = lane + 64 * m;
-                if (s >= NSLOT) break;
+            for (int s = lane; s < NSLOT; s += BMPC_NT) {
                 if (s < S_EE) continue;
                 Row r;
                 row_eval(A, L, b, k, s, r);
@@ -909,9 +935,8 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
                     g[35 * k + lane] = v;
                 }
                 double* gi = g + 35 * (N - 1) + 112 * (k - 1);
-                for (int m = 0; m < 4; m++) {
-                    int s = lane + 64 * m;
-                    if (s < S_EE || s >= S_END) continue;
+                for (int s = lane; s < S_END; s += BMPC_NT) {
+                    if (s < S_EE) continue;
                     if (s >= S_TSET && k != N - 1) continue;
                     Row r;
                     row_eval(A, L, b, k, s, r);

@@ -20,11 +20,12 @@ class BmpcOpts(ctypes.Structure):
                 ("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("device", ctypes.c_int),
                 ("hess", ctypes.c_int), ("hess_switch", ctypes.c_double), ("mu_init", ctypes.c_double),
                 ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
-                ("max_batch", ctypes.c_int), ("blocks_per_cu", ctypes.c_int)]
+                ("max_batch", ctypes.c_int), ("blocks_per_cu", ctypes.c_int), ("waves_per_instance", ctypes.c_int)]
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
-           "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_fk", "bmpc_last_kernel_ms"]
+           "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_fk", "bmpc_last_kernel_ms",
+           "bmpc_debug_phase_cycles"]
 
 _lib = None
 

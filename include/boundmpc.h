@@ -38,6 +38,7 @@ typedef struct {
     double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule */
     int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
     int blocks_per_cu;  /* resident workgroups per CU (0 = default 3) */
+    int waves_per_instance; /* 1 (one wavefront per instance, default), 2 or 4 wavefronts sharing one LDS image */
 } bmpc_opts;
 
 void bmpc_default_opts(bmpc_opts* o, int N);
@@ -79,6 +80,9 @@ int bmpc_fk(bmpc_handle* h, int B, const double* q, const double* dq, double* ee
 /* Duration (ms) of the most recent solve kernel measured with HIP events on its stream
  * (bmpc_solve: events around the launch; bmpc_solve_dev: caller must have synchronised). */
 int bmpc_last_kernel_ms(bmpc_handle* h, float* ms);
+
+/* Diagnostic builds (-DBMPC_PROFILE) only: per-phase shader-cycle sums of the last launches. */
+int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16);
 
 #ifdef __cplusplus
 }

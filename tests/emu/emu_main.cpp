@@ -19,6 +19,9 @@ static thread_local int t_lane = 0;
 typedef double LDSD;
 #define BMPC_SYNC() g_bar->arrive_and_wait()
 #define BMPC_LANE() t_lane
+#ifndef BMPC_NT
+#define BMPC_NT 64
+#endif
 #define BMPC_BLOCK() 0
 #define BMPC_NBLOCKS() 1
 #define BMPC_ATOMIC_INC(ptr) __atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED)
@@ -45,13 +48,14 @@ extern "C" int emu_solve(int N, double dt, double tol, int max_iter, int hess, d
     A.ws = ws.data();
     int counter = 0;
     A.counter = &counter;
+    A.prof = nullptr;
     Lds L;
     lds_carve(lds.data(), L);
     if (L.misc + 64 - lds.data() > LDS_DOUBLES) { fprintf(stderr, "LDS carve overflow %ld > %d\n", (long)(L.misc + 64 - lds.data()), LDS_DOUBLES); return -2; }
-    std::barrier<> bar(64);
+    std::barrier<> bar(BMPC_NT);
     g_bar = &bar;
     std::vector<std::thread> th;
-    for (int l = 0; l < 64; l++)
+    for (int l = 0; l < BMPC_NT; l++)
         th.emplace_back([&, l] { t_lane = l; solve_instance(A, L, A.ws, 0, l); });
     for (auto& t : th) t.join();
     return 0;
