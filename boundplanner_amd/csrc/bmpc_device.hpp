@@ -73,50 +73,81 @@ struct KernelArgs {
     double* prof;                       // diagnostic builds: per-block phase cycle sums (16 per block) or null
 };
 
+struct Inst {            // per-instance arguments, passed by value (registers)
+    int N, b;
+    const double *lbx, *ubx, *pg;   // this instance's rows of lbx / ubx / p
+    double* prof;                   // diagnostic builds only
+};
+
 BMPC_HD int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32); }
 
 // ------------------------------------------------------------------------------------------
 // LDS carve-up (doubles)
 // ------------------------------------------------------------------------------------------
-struct Lds {
-    LDSD *P, *W, *sp, *zeta, *znext, *yz, *g0, *g1, *gz, *lam, *pv0, *pv1, *vt0, *vt1, *rdef,
-        *J, *G, *Jp, *zax, *pc, *Op, *Ov, *T1, *T2, *Hp, *Hv, *mS, *sS, *bp0, *bp1, *bpz, *bv,
-        *bS0, *bS1, *bSz, *M3, *mc, *sc, *b30, *b31, *b3z, *bc0, *bc1, *bcz, *rowS, *rowA, *rowSl,
-        *rc, *Kl, *kf, *Y, *Et, *red, *dx, *dxn, *dloc, *dpt, *x1fix, *r0, *misc, *kin, *rob;
-};
-constexpr int LDS_DOUBLES =
-    NX * LDP + NZ * LDW + NSP + 2 * ZPAD + ZPAD +             // P W sp zeta znext yz
-    3 * ZPAD + 5 * NX + NX +                                  // g0 g1 gz | lam pv0 pv1 vt0 vt1 | rdef
-    42 + 42 + 126 + 21 + 18 +                                 // J G Jp zax pc
-    4 * 102 + 36 + 36 + 18 + 3 + 18 + 6 + 9 +                 // Op Ov T1 T2 Hp Hv mS sS bp* bv bS*
-    54 + 18 + 6 + 54 + 18 +                                   // M3 mc sc b3* bc*
-    4 * NSLOT + NPOSE * 6 + NPOSE +                           // rowS rowA rowSl
-    160 + 32 + BMPC_NT +                                      // rc kf red (Kl aliases Op..T2, Y/Et alias rowA)
-    2 * NX + 16 + 24 + 24 + NX + 64 + 160 + 96;               // dx dxn dloc dpt x1fix r0 misc kin rob
-
-BMPC_INL void lds_carve(LDSD* b, Lds& L) {
-    auto take = [&](int n) { LDSD* r = b; b += n; return r; };
-    L.P = take(NX * LDP); L.W = take(NZ * LDW); L.sp = take(NSP);
-    L.zeta = take(ZPAD); L.znext = take(ZPAD); L.yz = take(ZPAD);
-    L.g0 = take(ZPAD); L.g1 = take(ZPAD); L.gz = take(ZPAD);
-    L.lam = take(NX); L.pv0 = take(NX); L.pv1 = take(NX); L.vt0 = take(NX); L.vt1 = take(NX);
-    L.rdef = take(NX);
-    L.J = take(42); L.G = take(42); L.Jp = take(126); L.zax = take(21); L.pc = take(18);
-    L.Op = take(102); L.Ov = take(102); L.T1 = take(102); L.T2 = take(102);
-    L.Hp = take(36); L.Hv = take(36); L.mS = take(18); L.sS = take(3);
-    L.bp0 = take(6); L.bp1 = take(6); L.bpz = take(6); L.bv = take(6);
-    L.bS0 = take(3); L.bS1 = take(3); L.bSz = take(3);
-    L.M3 = take(54); L.mc = take(18); L.sc = take(6);
-    L.b30 = take(18); L.b31 = take(18); L.b3z = take(18);
-    L.bc0 = take(6); L.bc1 = take(6); L.bcz = take(6);
-    L.rowS = take(4 * NSLOT); L.rowA = take(NPOSE * 6); L.rowSl = take(NPOSE);
-    L.rc = take(160); L.kf = take(32);
-    L.Kl = L.Op;          // gains are written after the chain phases are done with Op/Ov/T1/T2 (408 >= 288)
-    L.Y = L.rowA;         // coupling scratch reuses the pose-row gradients (301 >= 246)
-    L.Et = L.rowA + NZ * 3;
-    L.red = take(BMPC_NT); L.dx = take(NX); L.dxn = take(NX); L.dloc = take(16); L.dpt = take(24);
-    L.x1fix = take(24); L.r0 = take(NX); L.misc = take(64); L.kin = take(160); L.rob = take(96);
-}
+// LDS layout: constexpr offsets (in doubles) from the workgroup's LDS base
+constexpr int O_P = 0;
+constexpr int O_W = O_P + (NX * LDP);
+constexpr int O_sp = O_W + (NZ * LDW);
+constexpr int O_zeta = O_sp + (NSP);
+constexpr int O_znext = O_zeta + (ZPAD);
+constexpr int O_yz = O_znext + (ZPAD);
+constexpr int O_g0 = O_yz + (ZPAD);
+constexpr int O_g1 = O_g0 + (ZPAD);
+constexpr int O_gz = O_g1 + (ZPAD);
+constexpr int O_lam = O_gz + (ZPAD);
+constexpr int O_pv0 = O_lam + (NX);
+constexpr int O_pv1 = O_pv0 + (NX);
+constexpr int O_vt0 = O_pv1 + (NX);
+constexpr int O_vt1 = O_vt0 + (NX);
+constexpr int O_rdef = O_vt1 + (NX);
+constexpr int O_J = O_rdef + (NX);
+constexpr int O_G = O_J + (42);
+constexpr int O_Jp = O_G + (42);
+constexpr int O_zax = O_Jp + (126);
+constexpr int O_pc = O_zax + (21);
+constexpr int O_Op = O_pc + (18);
+constexpr int O_Ov = O_Op + (102);
+constexpr int O_T1 = O_Ov + (102);
+constexpr int O_T2 = O_T1 + (102);
+constexpr int O_Hp = O_T2 + (102);
+constexpr int O_Hv = O_Hp + (36);
+constexpr int O_mS = O_Hv + (36);
+constexpr int O_sS = O_mS + (18);
+constexpr int O_bp0 = O_sS + (3);
+constexpr int O_bp1 = O_bp0 + (6);
+constexpr int O_bpz = O_bp1 + (6);
+constexpr int O_bv = O_bpz + (6);
+constexpr int O_bS0 = O_bv + (6);
+constexpr int O_bS1 = O_bS0 + (3);
+constexpr int O_bSz = O_bS1 + (3);
+constexpr int O_M3 = O_bSz + (3);
+constexpr int O_mc = O_M3 + (54);
+constexpr int O_sc = O_mc + (18);
+constexpr int O_b30 = O_sc + (6);
+constexpr int O_b31 = O_b30 + (18);
+constexpr int O_b3z = O_b31 + (18);
+constexpr int O_bc0 = O_b3z + (18);
+constexpr int O_bc1 = O_bc0 + (6);
+constexpr int O_bcz = O_bc1 + (6);
+constexpr int O_rowS = O_bcz + (6);
+constexpr int O_rowA = O_rowS + (4 * NSLOT);
+constexpr int O_rowSl = O_rowA + (NPOSE * 6);
+constexpr int O_rc = O_rowSl + (NPOSE);
+constexpr int O_kf = O_rc + (160);
+constexpr int O_red = O_kf + (32);
+constexpr int O_dx = O_red + (BMPC_NT);
+constexpr int O_dxn = O_dx + (NX);
+constexpr int O_dloc = O_dxn + (NX);
+constexpr int O_dpt = O_dloc + (16);
+constexpr int O_x1fix = O_dpt + (24);
+constexpr int O_r0 = O_x1fix + (24);
+constexpr int O_misc = O_r0 + (NX);
+constexpr int O_kin = O_misc + (64);
+constexpr int O_rob = O_kin + (160);
+constexpr int LDS_DOUBLES = O_rob + (96);
+constexpr int O_Kl = O_Op;
+constexpr int O_Y = O_rowA;
+constexpr int O_Et = O_rowA + NZ * 3;
 
 // ------------------------------------------------------------------------------------------
 // small helpers
@@ -159,7 +190,7 @@ BMPC_DEV double wg_min(double v, LDSD* red, int lane) {
 // returns number of (x-row, coefficient) pairs.
 struct DynC { double dt, b1, b2, b3, c1, c2, c3; };
 struct PhiCol { int i0, i1, i2; double c0, c1, c2; };   // by value: stays in registers
-BMPC_INL PhiCol phi_col(int c, const DynC& d) {
+BMPC_INL PhiCol phi_col(int c, const DynC d) {
     PhiCol r;
     r.i0 = c; r.i1 = c; r.i2 = c; r.c0 = 1.0; r.c1 = 0.0; r.c2 = 0.0;
     if (c < Z_DQ) {
@@ -247,7 +278,7 @@ constexpr int RB_XYZ = 0, RB_ROT = 21, RB_EE = 84, RB_L4C = 87;
 constexpr int KN_O = 0 /*7x3*/, KN_PEE = 21, KN_CS = 24 /*cos7,sin7*/, KN_SUFC = 38 /*8x3*/, KN_SUFZ = 62,
               KN_PREZ = 86, KN_R1 = 110 /*3x6*/, KN_R2 = 128, KN_G12 = 146 /*12*/, KN_END = 158;
 
-BMPC_INL double nat_from_zeta(const LDSD* z, int i, const DynC& d) {
+BMPC_INL double nat_from_zeta(const LDSD* z, int i, const DynC d) {
     if (i < Z_DQ) return z[i] + d.c3 * z[Z_U + i];
     if (i < Z_DDQ) return z[i] + d.c2 * z[Z_U + i - 7];
     if (i < Z_PI) return z[i] + d.c1 * z[Z_U + i - 14];
@@ -261,28 +292,28 @@ BMPC_INL double nat_from_zeta(const LDSD* z, int i, const DynC& d) {
 // Returns the stage cost value (same on every lane).  Publishes to LDS: yz, kinematics (J, G, Jp,
 // zax, pc), the row context rc[], the output-space cost gradient kin[KN_G12..] and, when want_h,
 // the Gauss-Newton/convex cost Hessian blocks Hp/Hv plus the initial group gradients bp0/bpz/bp1/bv.
-BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, int k, int lane, bool want_h,
+BMPC_NOINL double stage_eval(const Inst I, LDSD* lds, const DynC dc, int k, int lane, bool want_h,
                            const double* iw0) {
-    const int N = A.o.N;
-    const LDSD* sp = L.sp;
-    LDSD* rc = L.rc;
-    LDSD* kn = L.kin;
+    const int N = I.N;
+    const LDSD* sp = (lds + O_sp);
+    LDSD* rc = (lds + O_rc);
+    LDSD* kn = (lds + O_kin);
     const bool term = (k == N - 1);
     // ---- E0: natural variables, sin/cos ----
-    if (lane < NZ) L.yz[lane] = nat_from_zeta(L.zeta, lane, dc);
-    if (lane < 7) { double q = nat_from_zeta(L.zeta, lane, dc); kn[KN_CS + lane] = cos(q); kn[KN_CS + 7 + lane] = sin(q); }
+    if (lane < NZ) (lds + O_yz)[lane] = nat_from_zeta((lds + O_zeta), lane, dc);
+    if (lane < 7) { double q = nat_from_zeta((lds + O_zeta), lane, dc); kn[KN_CS + lane] = cos(q); kn[KN_CS + 7 + lane] = sin(q); }
     BMPC_SYNC();
     // ---- E1: kinematic chain (every lane, small live set; lane 0 publishes) ----
     {
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}, Rn[9], tmp[3];
-        const LDSD* rob = L.rob;
+        const LDSD* rob = (lds + O_rob);
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             mat3vec(R, rob + RB_XYZ + 3 * i, tmp);
             for (int a = 0; a < 3; a++) t[a] += tmp[a];
             mat3mul(R, rob + RB_ROT + 9 * i, Rn);
             if (lane == 0)
-                for (int a = 0; a < 3; a++) { kn[KN_O + 3 * i + a] = t[a]; L.zax[3 * i + a] = Rn[3 * a + 2]; }
+                for (int a = 0; a < 3; a++) { kn[KN_O + 3 * i + a] = t[a]; (lds + O_zax)[3 * i + a] = Rn[3 * a + 2]; }
             double c = kn[KN_CS + i], s = kn[KN_CS + 7 + i];
             for (int a = 0; a < 3; a++) {
                 R[3 * a] = Rn[3 * a] * c + Rn[3 * a + 1] * s;
@@ -291,7 +322,7 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
             }
             if (i == 3) {
                 mat3vec(R, rob + RB_L4C, tmp);
-                if (lane == 0) for (int a = 0; a < 3; a++) L.pc[15 + a] = t[a] + tmp[a];
+                if (lane == 0) for (int a = 0; a < 3; a++) (lds + O_pc)[15 + a] = t[a] + tmp[a];
             }
         }
         mat3vec(R, rob + RB_EE, tmp);
@@ -306,12 +337,12 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
             if (a < 3) {
                 int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
                 double r1 = kn[KN_PEE + a1] - kn[KN_O + 3 * i + a1], r2 = kn[KN_PEE + a2] - kn[KN_O + 3 * i + a2];
-                v = L.zax[3 * i + a1] * r2 - L.zax[3 * i + a2] * r1;
-            } else v = L.zax[3 * i + a - 3];
-            L.J[lane] = v;
+                v = (lds + O_zax)[3 * i + a1] * r2 - (lds + O_zax)[3 * i + a2] * r1;
+            } else v = (lds + O_zax)[3 * i + a - 3];
+            (lds + O_J)[lane] = v;
         } else if (lane < 57) {
             int e = lane - 42;
-            L.pc[e] = kn[KN_O + 6 + e];     // pc[c] = o[c+2], c < 5
+            (lds + O_pc)[e] = kn[KN_O + 6 + e];     // pc[c] = o[c+2], c < 5
         }
         const int nj[6] = {2, 3, 4, 5, 6, 4};
         for (int e = lane; e < 126; e += BMPC_NT) {
@@ -319,29 +350,29 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
             double v = 0;
             if (i < nj[c]) {
                 int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
-                double p1 = (c < 5) ? kn[KN_O + 3 * (c + 2) + a1] : L.pc[15 + a1];
-                double p2 = (c < 5) ? kn[KN_O + 3 * (c + 2) + a2] : L.pc[15 + a2];
+                double p1 = (c < 5) ? kn[KN_O + 3 * (c + 2) + a1] : (lds + O_pc)[15 + a1];
+                double p2 = (c < 5) ? kn[KN_O + 3 * (c + 2) + a2] : (lds + O_pc)[15 + a2];
                 double r1 = p1 - kn[KN_O + 3 * i + a1], r2 = p2 - kn[KN_O + 3 * i + a2];
-                v = L.zax[3 * i + a1] * r2 - L.zax[3 * i + a2] * r1;
+                v = (lds + O_zax)[3 * i + a1] * r2 - (lds + O_zax)[3 * i + a2] * r1;
             }
-            L.Jp[e] = v;
+            (lds + O_Jp)[e] = v;
         }
     }
     BMPC_SYNC();
     // ---- E3: v = J dq, prefix/suffix sums for G ----
     if (lane < 6) {
         double s = 0;
-        for (int j = 0; j < 7; j++) s += L.J[7 * lane + j] * L.yz[Z_DQ + j];
+        for (int j = 0; j < 7; j++) s += (lds + O_J)[7 * lane + j] * (lds + O_yz)[Z_DQ + j];
         rc[RC_V + lane] = s;
     } else if (lane < 9) {
         int a = lane - 6;
         double sc = 0, sz = 0, pz = 0;
         kn[KN_SUFC + 21 + a] = 0; kn[KN_SUFZ + 21 + a] = 0; kn[KN_PREZ + a] = 0;
         for (int j = 6; j >= 0; j--) {
-            sc += L.J[7 * a + j] * L.yz[Z_DQ + j]; sz += L.zax[3 * j + a] * L.yz[Z_DQ + j];
+            sc += (lds + O_J)[7 * a + j] * (lds + O_yz)[Z_DQ + j]; sz += (lds + O_zax)[3 * j + a] * (lds + O_yz)[Z_DQ + j];
             kn[KN_SUFC + 3 * j + a] = sc; kn[KN_SUFZ + 3 * j + a] = sz;
         }
-        for (int j = 0; j < 7; j++) { pz += L.zax[3 * j + a] * L.yz[Z_DQ + j]; kn[KN_PREZ + 3 * (j + 1) + a] = pz; }
+        for (int j = 0; j < 7; j++) { pz += (lds + O_zax)[3 * j + a] * (lds + O_yz)[Z_DQ + j]; kn[KN_PREZ + 3 * (j + 1) + a] = pz; }
     }
     BMPC_SYNC();
     // ---- E4: G = d(J dq)/dq, pose ----
@@ -351,16 +382,16 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
         if (a < 3) {
             int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
             // (z_i x sufc_i)[a] + (prez_i x c_i)[a]
-            v = L.zax[3 * i + a1] * kn[KN_SUFC + 3 * i + a2] - L.zax[3 * i + a2] * kn[KN_SUFC + 3 * i + a1];
-            v += kn[KN_PREZ + 3 * i + a1] * L.J[7 * a2 + i] - kn[KN_PREZ + 3 * i + a2] * L.J[7 * a1 + i];
+            v = (lds + O_zax)[3 * i + a1] * kn[KN_SUFC + 3 * i + a2] - (lds + O_zax)[3 * i + a2] * kn[KN_SUFC + 3 * i + a1];
+            v += kn[KN_PREZ + 3 * i + a1] * (lds + O_J)[7 * a2 + i] - kn[KN_PREZ + 3 * i + a2] * (lds + O_J)[7 * a1 + i];
         } else {
             int b = a - 3, a1 = (b + 1) % 3, a2 = (b + 2) % 3;
-            v = L.zax[3 * i + a1] * kn[KN_SUFZ + 3 * (i + 1) + a2] - L.zax[3 * i + a2] * kn[KN_SUFZ + 3 * (i + 1) + a1];
+            v = (lds + O_zax)[3 * i + a1] * kn[KN_SUFZ + 3 * (i + 1) + a2] - (lds + O_zax)[3 * i + a2] * kn[KN_SUFZ + 3 * (i + 1) + a1];
         }
-        L.G[lane] = v;
+        (lds + O_G)[lane] = v;
     } else if (lane < 48) {
         int a = lane - 42;
-        double v = (a < 3) ? kn[KN_PEE + a] : L.yz[Z_PI + a - 3] + 0.5 * dc.dt * rc[RC_V + a];
+        double v = (a < 3) ? kn[KN_PEE + a] : (lds + O_yz)[Z_PI + a - 3] + 0.5 * dc.dt * rc[RC_V + a];
         rc[RC_POSE + a] = v;
         if (a >= 3) rc[RC_PROT + a - 3] = v;
     }
@@ -419,15 +450,15 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
         fv += wts[0] * ep2 + wts[1] / 50.0 * (dot3(eo1, eo1) + dot3(eo2, eo2));
         if (term)
             for (int a = 0; a < 6; a++) fv += 100.0 * vv[a] * vv[a];
-        for (int j = 2; j <= 4; j++) fv += wts[6] * L.yz[Z_DQ + j] * L.yz[Z_DQ + j];
-        for (int j = 0; j < 7; j++) fv += wts[7] * L.yz[Z_U + j] * L.yz[Z_U + j];
-        fv += wts[9] * L.yz[Z_RS] * L.yz[Z_RS] + wts[10] * L.yz[Z_DRS] * L.yz[Z_DRS] +
-              wts[9] * L.yz[Z_PS] * L.yz[Z_PS] + wts[10] * L.yz[Z_DPS] * L.yz[Z_DPS];
+        for (int j = 2; j <= 4; j++) fv += wts[6] * (lds + O_yz)[Z_DQ + j] * (lds + O_yz)[Z_DQ + j];
+        for (int j = 0; j < 7; j++) fv += wts[7] * (lds + O_yz)[Z_U + j] * (lds + O_yz)[Z_U + j];
+        fv += wts[9] * (lds + O_yz)[Z_RS] * (lds + O_yz)[Z_RS] + wts[10] * (lds + O_yz)[Z_DRS] * (lds + O_yz)[Z_DRS] +
+              wts[9] * (lds + O_yz)[Z_PS] * (lds + O_yz)[Z_PS] + wts[10] * (lds + O_yz)[Z_DPS] * (lds + O_yz)[Z_DPS];
         if (term)
             for (int i = 0; i < 6; i++) {
-                double sl = sp[P_SLACKS0 + i] + L.yz[Z_D + i];
+                double sl = sp[P_SLACKS0 + i] + (lds + O_yz)[Z_D + i];
                 if (i != 4) fv += wts[8] * sl * sl;
-                fv += wts[10] * L.yz[Z_D + i] * L.yz[Z_D + i];
+                fv += wts[10] * (lds + O_yz)[Z_D + i] * (lds + O_yz)[Z_D + i];
             }
         if (lane == 0) {
             double bp1[3], bp2[3];
@@ -442,7 +473,7 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
             }
             rc[RC_PHI] = phi; rc[RC_PHIEND] = sp[P_PHISW + n];
             rc[RC_TZ] = dot3(bp1, ep); rc[RC_TZ + 1] = dot3(bp2, ep);
-            for (int i = 0; i < 6; i++) { rc[RC_SL + i] = sp[P_SLACKS0 + i] + L.yz[Z_D + i]; rc[RC_VO + i] = vo[i]; }
+            for (int i = 0; i < 6; i++) { rc[RC_SL + i] = sp[P_SLACKS0 + i] + (lds + O_yz)[Z_D + i]; rc[RC_VO + i] = vo[i]; }
             rc[RC_FVAL] = fv; rc[RC_SEG] = (double)s; rc[RC_SEG + 1] = (double)n;
             rc[RC_SIG] = sig; rc[RC_DSIG] = dsig; rc[RC_DPHI] = dphi;
             rc[RC_DPSI] = -wts[4] * dphid / rt; rc[RC_DDPSI] = wts[4] * 0.01 / (rt * rt * rt);
@@ -515,7 +546,7 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
                     for (int a = 0; a < 3; a++) dd += rc[RC_DEP + 3 * a + i] * rc[RC_DEP + 3 * a + j];
                     h += 2 * wts[0] * dd + rc[RC_DDPSI] * rc[RC_DPP + i] * rc[RC_DPP + j];
                 }
-                L.Hp[e] = h;
+                (lds + O_Hp)[e] = h;
             } else {
                 int i = (e - 36) / 6, j = (e - 36) % 6;
                 double dWd = 0;
@@ -525,10 +556,10 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
                 double h = (i == j ? wi : 0.0) - wi * TABP(P_DPREF, s, i) * dj - di * wj * TABP(P_DPREF, s, j) + di * dj * dWd;
                 h = 2 * h + 2 * wts[5] * di * dj;
                 if (term && i == j) h += 200.0;
-                L.Hv[e - 36] = h;
+                (lds + O_Hv)[e - 36] = h;
             }
         }
-        if (lane < 6) { double g = kn[KN_G12 + lane]; L.bp0[lane] = g; L.bpz[lane] = g; L.bp1[lane] = 0; L.bv[lane] = kn[KN_G12 + 6 + lane]; }
+        if (lane < 6) { double g = kn[KN_G12 + lane]; (lds + O_bp0)[lane] = g; (lds + O_bpz)[lane] = g; (lds + O_bp1)[lane] = 0; (lds + O_bv)[lane] = kn[KN_G12 + 6 + lane]; }
     }
     BMPC_SYNC();
     return fv;
@@ -539,40 +570,39 @@ BMPC_DEV double stage_eval(const KernelArgs& A, const Lds& L, const DynC& dc, in
 // (a6 + slack selector 0 none / 1 ps / 2 rs / 3 d5, coefficient -1), 4 point row (point c, a3, -d_c)
 struct Row { int kind, pos, sel; double coef, h, a[6]; };
 
-BMPC_DEV void row_eval(const KernelArgs& A, const Lds& L, int b, int k, int s, Row& r) {
-    const int N = A.o.N;
-    const LDSD* sp = L.sp;
-    const double* pg = A.p + (size_t)b * NPAR;   // EE sets live in global memory
-    const LDSD* rc = L.rc;
+BMPC_NOINL void row_eval(const Inst I, LDSD* lds, int k, int s, Row& r) {
+    const int N = I.N;
+    const LDSD* sp = (lds + O_sp);
+    const double* pg = I.pg;   // EE sets live in global memory
+    const LDSD* rc = (lds + O_rc);
     r.kind = 0; r.pos = 0; r.sel = 0; r.coef = 0; r.h = 0;
     for (int c = 0; c < 6; c++) r.a[c] = 0;
-    size_t xb = (size_t)b * (44 * N + 6);
     if (s < S_NONNEG) {                       // box bounds on q,dq,ddq,u (BoundMPC.py:171-186,544-589)
         int j = s >> 1, blk = j / 7, jj = j - 7 * blk;
         int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + jj;
-        size_t wi = xb + (size_t)blk * 7 * N + (size_t)jj * N + k;
+        size_t wi = (size_t)blk * 7 * N + (size_t)jj * N + k;
         if ((s & 1) == 0) {
-            double ub = A.ubx[wi];
-            if (ub < BIGB) { r.kind = 1; r.pos = pos; r.coef = 1.0; r.h = L.yz[pos] - ub; }
+            double ub = I.ubx[wi];
+            if (ub < BIGB) { r.kind = 1; r.pos = pos; r.coef = 1.0; r.h = (lds + O_yz)[pos] - ub; }
         } else {
-            double lb = A.lbx[wi];
-            if (lb > -BIGB) { r.kind = 1; r.pos = pos; r.coef = -1.0; r.h = lb - L.yz[pos]; }
+            double lb = I.lbx[wi];
+            if (lb > -BIGB) { r.kind = 1; r.pos = pos; r.coef = -1.0; r.h = lb - (lds + O_yz)[pos]; }
         }
     } else if (s < S_RS1) {                   // rs, drs, ps, dps >= 0 (Q6)
         int m = s - S_NONNEG;
         int pos = (m == 0 ? Z_RS : m == 1 ? Z_DRS : m == 2 ? Z_PS : Z_DPS);
-        r.kind = 1; r.pos = pos; r.coef = -1.0; r.h = -L.yz[pos];
+        r.kind = 1; r.pos = pos; r.coef = -1.0; r.h = -(lds + O_yz)[pos];
     } else if (s < S_D1) {                    // stage-0 slacks: rs~_1, ps~_1 >= 0
-        if (k == 1) { int pos = (s == S_RS1) ? Z_RS : Z_PS; r.kind = 2; r.pos = pos; r.coef = -1.0; r.h = -L.zeta[pos]; }
+        if (k == 1) { int pos = (s == S_RS1) ? Z_RS : Z_PS; r.kind = 2; r.pos = pos; r.coef = -1.0; r.h = -(lds + O_zeta)[pos]; }
     } else if (s < S_EE) {                    // dslacks >= 0
-        if (k == 1) { int pos = Z_D + (s - S_D1); r.kind = 1; r.pos = pos; r.coef = -1.0; r.h = -L.yz[pos]; }
+        if (k == 1) { int pos = Z_D + (s - S_D1); r.kind = 1; r.pos = pos; r.coef = -1.0; r.h = -(lds + O_yz)[pos]; }
     } else if (s < S_ROTU) {                  // EE in current set (ocp :304)
         int rr = s - S_EE, sg = (int)rc[RC_SEG];
         const double* a = pg + P_ASET + 45 * sg;
         double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = pg[P_BSET + rr * 4 + sg];
         if (!(a0 == 0 && a1 == 0 && a2 == 0 && bb > 0)) {
             r.kind = 3; r.sel = 1; r.a[0] = a0; r.a[1] = a1; r.a[2] = a2;
-            r.h = a0 * rc[RC_POSE] + a1 * rc[RC_POSE + 1] + a2 * rc[RC_POSE + 2] - bb - L.yz[Z_PS];
+            r.h = a0 * rc[RC_POSE] + a1 * rc[RC_POSE + 1] + a2 * rc[RC_POSE + 2] - bb - (lds + O_yz)[Z_PS];
         }
     } else if (s < S_COL) {                   // orientation bounds (ocp :308-321)
         int m = s - S_ROTU;
@@ -581,14 +611,14 @@ BMPC_DEV void row_eval(const KernelArgs& A, const Lds& L, int b, int k, int s, R
         r.kind = 3; r.sel = 2;
         double sgn = lower ? -1.0 : 1.0;
         for (int c = 0; c < 6; c++) r.a[c] = sgn * rc[RC_GS + 6 * m + c];
-        r.h = lower ? -(rc[RC_PROJ + m] - rc[RC_LB + m] + L.yz[Z_RS]) : (rc[RC_PROJ + m] - rc[RC_UB + m] - L.yz[Z_RS]);
+        r.h = lower ? -(rc[RC_PROJ + m] - rc[RC_LB + m] + (lds + O_yz)[Z_RS]) : (rc[RC_PROJ + m] - rc[RC_UB + m] - (lds + O_yz)[Z_RS]);
     } else if (s < S_PHI) {                   // collision points (ocp :323-330)
         int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c;
         const LDSD* a = sp + SP_ASETJ + 45 * c;
         double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = sp[SP_BSETJ + rr * 6 + c];
         if (!(a0 == 0 && a1 == 0 && a2 == 0 && bb + sp[P_SLACKS0 + c] > 0)) {
             r.kind = 4; r.pos = c; r.a[0] = a0; r.a[1] = a1; r.a[2] = a2;
-            r.h = a0 * L.pc[3 * c] + a1 * L.pc[3 * c + 1] + a2 * L.pc[3 * c + 2] - bb - rc[RC_SL + c];
+            r.h = a0 * (lds + O_pc)[3 * c] + a1 * (lds + O_pc)[3 * c + 1] + a2 * (lds + O_pc)[3 * c + 2] - bb - rc[RC_SL + c];
         }
     } else if (s == S_PHI) {                  // phi cap (ocp :332)
         r.kind = 3; r.sel = 0;

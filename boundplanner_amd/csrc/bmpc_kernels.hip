@@ -16,19 +16,18 @@ using namespace bmpc;
 
 __global__ __launch_bounds__(BMPC_NT) void BMPC_CAT(bmpc_solve_kernel_nt, BMPC_NT)(KernelArgs A) {
     __shared__ double lds[LDS_DOUBLES];
-    Lds L;
-    lds_carve((LDSD*)lds, L);
+    LDSD* ldsb = (LDSD*)lds;
     const int lane = BMPC_LANE();
     double* wsb = A.ws + (size_t)BMPC_BLOCK() * ws_doubles(A.o.N);
     // one wavefront per instance; resident workgroups pull the next instance from a device-scope
     // counter (iteration counts vary 7..100, so a static deal leaves most CUs idle at the tail)
     for (;;) {
-        if (lane == 0) L.misc[63] = (double)BMPC_ATOMIC_INC(A.counter);
+        if (lane == 0) (ldsb + O_misc)[63] = (double)BMPC_ATOMIC_INC(A.counter);
         BMPC_SYNC();
-        int b = (int)L.misc[63];
+        int b = (int)(ldsb + O_misc)[63];
         BMPC_SYNC();
         if (b >= A.B) break;
-        solve_instance(A, L, wsb, b, lane);
+        solve_instance(A, ldsb, wsb, b, lane);
     }
 }
 

@@ -15,3 +15,4 @@
 // doubles that live in LDS: address-space-qualified so that every access is a ds_* instruction
 // (generic pointers to __shared__ memory compile to flat_* loads through the vector-memory path)
 typedef __attribute__((address_space(3))) double LDSD;
+#define BMPC_NOINL __device__ __attribute__((noinline))

@@ -6,7 +6,7 @@
 // optional in-kernel phase timing (diagnostic builds only: -DBMPC_PROFILE; never in the product build)
 #ifdef BMPC_PROFILE
 #define BMPC_PROF_START() long long prof_t0_ = clock64()
-#define BMPC_PROF(i) do { long long t1_ = clock64(); if (lane == 0 && A.prof) A.prof[(size_t)BMPC_BLOCK() * 16 + (i)] += (double)(t1_ - prof_t0_); prof_t0_ = t1_; } while (0)
+#define BMPC_PROF(i) do { long long t1_ = clock64(); if (lane == 0 && I.prof) I.prof[(size_t)BMPC_BLOCK() * 16 + (i)] += (double)(t1_ - prof_t0_); prof_t0_ = t1_; } while (0)
 #else
 #define BMPC_PROF_START() do {} while (0)
 #define BMPC_PROF(i) do {} while (0)
@@ -35,18 +35,18 @@ BMPC_INL void ws_carve(double* b, int N, WsPtr& w) {
 
 BMPC_INL double sp_b(const double* sp, int off, int row, int stride, int col) { return sp[off + row * stride + col]; }
 
-// dynamics defect of stage k (needs zeta_k in L.zeta, zeta_{k+1} in L.znext, v in rc)
-BMPC_INL double defect_row(const Lds& L, const DynC& d, int i) {
-    const LDSD* z = L.zeta;
+// dynamics defect of stage k (needs zeta_k in (lds + O_zeta), zeta_{k+1} in (lds + O_znext), v in rc)
+BMPC_INL double defect_row(LDSD* lds, const DynC d, int i) {
+    const LDSD* z = (lds + O_zeta);
     double v;
     if (i < Z_DQ) v = z[i] + d.dt * z[i + 7] + 0.5 * d.dt * d.dt * z[i + 14] + d.b3 * z[Z_U + i];
     else if (i < Z_DDQ) v = z[i] + d.dt * z[i + 7] + d.b2 * z[Z_U + i - 7];
     else if (i < Z_PI) v = z[i] + d.b1 * z[Z_U + i - 14];
-    else if (i < Z_RS) v = z[i] + d.dt * L.rc[RC_V + 3 + (i - Z_PI)];
+    else if (i < Z_RS) v = z[i] + d.dt * (lds + O_rc)[RC_V + 3 + (i - Z_PI)];
     else if (i == Z_RS) v = z[i] + d.dt * z[Z_DRS];
     else if (i == Z_PS) v = z[i] + d.dt * z[Z_DPS];
     else v = z[i];
-    return v - L.znext[i];
+    return v - (lds + O_znext)[i];
 }
 
 // 9x9 Cholesky in registers (every lane redundantly); returns false when not positive definite
@@ -93,30 +93,30 @@ BMPC_INL void chol9_solve(const double* Lc, double* b) {
 // Backward sweep: evaluation + KKT error + adjoint multipliers + Riccati factorisation with
 // two right-hand sides (g = g0 + mu g1).  Returns false if a control block is not PD.
 // ------------------------------------------------------------------------------------------
-BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
+BMPC_NOINL bool backward_sweep(const Inst I, LDSD* lds, const WsPtr ws, const DynC dc, int lane,
                              double ad_pend, const double* iw0, double reg, double hreg, int hess_mode, Kkt& kk) {
-    const int N = A.o.N;
-    const LDSD* sp = L.sp;
+    const int N = I.N;
+    const LDSD* sp = (lds + O_sp);
     const LDSD* wts = sp + P_W;
     KktAcc ac;
     ac.cmax = 0; ac.csum = 0; ac.cmin = 1e300; ac.zsum = 0; ac.prim = 0; ac.theta = 0; ac.logs = 0;
     ac.lamsum = 0; ac.dual = 0; ac.nrows = 0;
     double fsum = 0;
     bool ok = true;
-    if (lane < NX) { L.lam[lane] = 0; L.pv0[lane] = 0; L.pv1[lane] = 0; }
+    if (lane < NX) { (lds + O_lam)[lane] = 0; (lds + O_pv0)[lane] = 0; (lds + O_pv1)[lane] = 0; }
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
         BMPC_PROF_START();
-        if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
-        for (int e = lane; e < NZ * LDW; e += BMPC_NT) L.W[e] = (e / LDW == e % LDW) ? hreg : 0.0;
-        if (lane < ZPAD) { L.g0[lane] = 0; L.g1[lane] = 0; L.gz[lane] = 0; }
+        if (lane < NZ) (lds + O_zeta)[lane] = ws.zeta[k * ZPAD + lane];
+        for (int e = lane; e < NZ * LDW; e += BMPC_NT) (lds + O_W)[e] = (e / LDW == e % LDW) ? hreg : 0.0;
+        if (lane < ZPAD) { (lds + O_g0)[lane] = 0; (lds + O_g1)[lane] = 0; (lds + O_gz)[lane] = 0; }
         BMPC_SYNC();
-        fsum += stage_eval(A, L, dc, k, lane, true, iw0);
+        fsum += stage_eval(I, lds, dc, k, lane, true, iw0);
         BMPC_PROF(0);
         // ---- rows: slack/multiplier data, KKT partial sums ----
         for (int s = lane; s < NSLOT; s += BMPC_NT) {
             Row r;
-            row_eval(A, L, b, k, s, r);
+            row_eval(I, lds, k, s, r);
             double sg = 0, r0 = 0, r1 = 0, zz = 0;
             if (r.kind) {
                 double t = ws.t[k * NSLOT + s];
@@ -128,11 +128,11 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 ac.prim = fmax(ac.prim, fabs(r.h + t)); ac.theta += fabs(r.h + t); ac.logs += log(t);
                 ac.nrows++;
             }
-            L.rowS[s] = sg; L.rowS[NSLOT + s] = r0; L.rowS[2 * NSLOT + s] = r1; L.rowS[3 * NSLOT + s] = zz;
+            (lds + O_rowS)[s] = sg; (lds + O_rowS)[NSLOT + s] = r0; (lds + O_rowS)[2 * NSLOT + s] = r1; (lds + O_rowS)[3 * NSLOT + s] = zz;
             int pr = pose_row_index(s);
             if (pr >= 0) {
-                for (int c = 0; c < 6; c++) L.rowA[pr * 6 + c] = r.a[c];
-                L.rowSl[pr] = (r.kind == 3) ? (double)r.sel : -1.0;
+                for (int c = 0; c < 6; c++) (lds + O_rowA)[pr * 6 + c] = r.a[c];
+                (lds + O_rowSl)[pr] = (r.kind == 3) ? (double)r.sel : -1.0;
             }
         }
         BMPC_SYNC();
@@ -159,18 +159,18 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
 #pragma unroll 4
                 for (int pr = 0; pr < NPOSE; pr++) {
                     int s = pr + (pr < 21 ? S_EE : S_PHI - 21);
-                    double v = L.rowS[soff + s];
-                    double fa = useA ? L.rowA[pr * 6 + ia] : 1.0;
-                    double fb = useB ? L.rowA[pr * 6 + ib] : 1.0;
-                    double mk = (sel == 0 || L.rowSl[pr] == dsel) ? 1.0 : 0.0;
+                    double v = (lds + O_rowS)[soff + s];
+                    double fa = useA ? (lds + O_rowA)[pr * 6 + ia] : 1.0;
+                    double fb = useB ? (lds + O_rowA)[pr * 6 + ib] : 1.0;
+                    double mk = (sel == 0 || (lds + O_rowSl)[pr] == dsel) ? 1.0 : 0.0;
                     acc += v * fa * fb * mk;
                 }
                 acc *= sgn;
-                if (o < 21) { L.Hp[6 * ia + ib] += acc; if (ia != ib) L.Hp[6 * ib + ia] += acc; }
-                else if (o < 39) L.mS[(sel - 1) * 6 + ia] = acc;
-                else if (o < 42) L.sS[sel - 1] = acc;
-                else if (o < 60) { LDSD* dst = vecsel == 0 ? L.bp0 : vecsel == 1 ? L.bp1 : L.bpz; dst[ia] += acc; }
-                else { LDSD* dst = vecsel == 0 ? L.bS0 : vecsel == 1 ? L.bS1 : L.bSz; dst[sel - 1] = acc; }
+                if (o < 21) { (lds + O_Hp)[6 * ia + ib] += acc; if (ia != ib) (lds + O_Hp)[6 * ib + ia] += acc; }
+                else if (o < 39) (lds + O_mS)[(sel - 1) * 6 + ia] = acc;
+                else if (o < 42) (lds + O_sS)[sel - 1] = acc;
+                else if (o < 60) { LDSD* dst = vecsel == 0 ? (lds + O_bp0) : vecsel == 1 ? (lds + O_bp1) : (lds + O_bpz); dst[ia] += acc; }
+                else { LDSD* dst = vecsel == 0 ? (lds + O_bS0) : vecsel == 1 ? (lds + O_bS1) : (lds + O_bSz); dst[sel - 1] = acc; }
             }
             for (int o = lane; o < 132; o += BMPC_NT) {
                 // per point c: 0..5 M3 sym, 6..8 mc, 9 sc, 10..18 b3{0,1,z}[3], 19..21 bc{0,1,z}
@@ -187,17 +187,17 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 double acc = 0;
 #pragma unroll 5
                 for (int rr = 0; rr < 15; rr++) {
-                    double v = L.rowS[soff + S_COL + 15 * c + rr];
+                    double v = (lds + O_rowS)[soff + S_COL + 15 * c + rr];
                     double fa = useA ? a[rr + 15 * ia] : 1.0;
                     double fb = useB ? a[rr + 15 * ib] : 1.0;
                     acc += v * fa * fb;
                 }
                 acc *= sgn;
-                if (q < 6) { L.M3[9 * c + 3 * ia + ib] = acc; L.M3[9 * c + 3 * ib + ia] = acc; }
-                else if (q < 9) L.mc[3 * c + ia] = acc;
-                else if (q == 9) L.sc[c] = acc;
-                else if (q < 19) { LDSD* dst = vs == 0 ? L.b30 : vs == 1 ? L.b31 : L.b3z; dst[3 * c + ia] = acc; }
-                else { LDSD* dst = vs == 0 ? L.bc0 : vs == 1 ? L.bc1 : L.bcz; dst[c] = acc; }
+                if (q < 6) { (lds + O_M3)[9 * c + 3 * ia + ib] = acc; (lds + O_M3)[9 * c + 3 * ib + ia] = acc; }
+                else if (q < 9) (lds + O_mc)[3 * c + ia] = acc;
+                else if (q == 9) (lds + O_sc)[c] = acc;
+                else if (q < 19) { LDSD* dst = vs == 0 ? (lds + O_b30) : vs == 1 ? (lds + O_b31) : (lds + O_b3z); dst[3 * c + ia] = acc; }
+                else { LDSD* dst = vs == 0 ? (lds + O_bc0) : vs == 1 ? (lds + O_bc1) : (lds + O_bcz); dst[c] = acc; }
             }
             // natural-diagonal rows straight into W / g
             if (lane < 38) {
@@ -206,9 +206,9 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 else if (lane < 32) { s0 = S_NONNEG + lane - 28; s1 = -1; int m = lane - 28; pos = (m == 0 ? Z_RS : m == 1 ? Z_DRS : m == 2 ? Z_PS : Z_DPS); }
                 else { s0 = S_D1 + lane - 32; s1 = -1; pos = Z_D + lane - 32; }
                 double c0 = (lane < 28) ? 1.0 : -1.0;   // upper rows +1, all others -1
-                double h = L.rowS[s0], a0 = c0 * L.rowS[NSLOT + s0], a1 = c0 * L.rowS[2 * NSLOT + s0], az = c0 * L.rowS[3 * NSLOT + s0];
-                if (s1 >= 0) { h += L.rowS[s1]; a0 -= L.rowS[NSLOT + s1]; a1 -= L.rowS[2 * NSLOT + s1]; az -= L.rowS[3 * NSLOT + s1]; }
-                L.W[pos * LDW + pos] += h; L.g0[pos] += a0; L.g1[pos] += a1; L.gz[pos] += az;
+                double h = (lds + O_rowS)[s0], a0 = c0 * (lds + O_rowS)[NSLOT + s0], a1 = c0 * (lds + O_rowS)[2 * NSLOT + s0], az = c0 * (lds + O_rowS)[3 * NSLOT + s0];
+                if (s1 >= 0) { h += (lds + O_rowS)[s1]; a0 -= (lds + O_rowS)[NSLOT + s1]; a1 -= (lds + O_rowS)[2 * NSLOT + s1]; az -= (lds + O_rowS)[3 * NSLOT + s1]; }
+                (lds + O_W)[pos * LDW + pos] += h; (lds + O_g0)[pos] += a0; (lds + O_g1)[pos] += a1; (lds + O_gz)[pos] += az;
             }
         }
         BMPC_SYNC();
@@ -218,24 +218,24 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             int mat = e / 102, rr = (e % 102) / 17, cc = e % 17;
             double v = 0;
             if (mat == 0) {   // Op: rows p_pos (J lin) ; p_rot (dt/2 G_w | dt/2 J_w | I)
-                if (rr < 3) v = (cc < 7) ? L.J[7 * rr + cc] : 0.0;
-                else if (cc < 7) v = 0.5 * dc.dt * L.G[7 * rr + cc];
-                else if (cc < 14) v = 0.5 * dc.dt * L.J[7 * rr + cc - 7];
+                if (rr < 3) v = (cc < 7) ? (lds + O_J)[7 * rr + cc] : 0.0;
+                else if (cc < 7) v = 0.5 * dc.dt * (lds + O_G)[7 * rr + cc];
+                else if (cc < 14) v = 0.5 * dc.dt * (lds + O_J)[7 * rr + cc - 7];
                 else v = (cc - 14 == rr - 3) ? 1.0 : 0.0;
-                L.Op[e] = v;
+                (lds + O_Op)[e] = v;
             } else {          // Ov: [G | J | 0]
-                v = (cc < 7) ? L.G[7 * rr + cc] : (cc < 14 ? L.J[7 * rr + cc - 7] : 0.0);
-                L.Ov[e - 102] = v;
+                v = (cc < 7) ? (lds + O_G)[7 * rr + cc] : (cc < 14 ? (lds + O_J)[7 * rr + cc - 7] : 0.0);
+                (lds + O_Ov)[e - 102] = v;
             }
         }
         BMPC_SYNC();
         for (int e = lane; e < 204; e += BMPC_NT) {
             int mat = e / 102, rr = (e % 102) / 17, cc = e % 17;
-            const LDSD* H = mat ? L.Hv : L.Hp;
-            const LDSD* O = mat ? L.Ov : L.Op;
+            const LDSD* H = mat ? (lds + O_Hv) : (lds + O_Hp);
+            const LDSD* O = mat ? (lds + O_Ov) : (lds + O_Op);
             double v = 0;
             for (int a = 0; a < 6; a++) v += H[6 * rr + a] * O[17 * a + cc];
-            (mat ? L.T2 : L.T1)[17 * rr + cc] = v;
+            (mat ? (lds + O_T2) : (lds + O_T1))[17 * rr + cc] = v;
         }
         BMPC_SYNC();
         {
@@ -245,27 +245,27 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 if (e < 289) {
                     int i = e / 17, j = e % 17;
                     double v = 0;
-                    for (int a = 0; a < 6; a++) v += L.Op[17 * a + i] * L.T1[17 * a + j] + L.Ov[17 * a + i] * L.T2[17 * a + j];
-                    L.W[pos17(i) * LDW + pos17(j)] += v;
+                    for (int a = 0; a < 6; a++) v += (lds + O_Op)[17 * a + i] * (lds + O_T1)[17 * a + j] + (lds + O_Ov)[17 * a + i] * (lds + O_T2)[17 * a + j];
+                    (lds + O_W)[pos17(i) * LDW + pos17(j)] += v;
                 } else if (e < 340) {
                     int i = (e - 289) / 3, sl = (e - 289) % 3;
                     double v = 0;
-                    for (int a = 0; a < 6; a++) v += L.Op[17 * a + i] * L.mS[6 * sl + a];
-                    L.W[pos17(i) * LDW + spos[sl]] += v;
-                    L.W[spos[sl] * LDW + pos17(i)] += v;
+                    for (int a = 0; a < 6; a++) v += (lds + O_Op)[17 * a + i] * (lds + O_mS)[6 * sl + a];
+                    (lds + O_W)[pos17(i) * LDW + spos[sl]] += v;
+                    (lds + O_W)[spos[sl] * LDW + pos17(i)] += v;
                 } else if (e < 343) {
                     int sl = e - 340;
-                    L.W[spos[sl] * LDW + spos[sl]] += L.sS[sl];
-                    L.g0[spos[sl]] += L.bS0[sl]; L.g1[spos[sl]] += L.bS1[sl]; L.gz[spos[sl]] += L.bSz[sl];
+                    (lds + O_W)[spos[sl] * LDW + spos[sl]] += (lds + O_sS)[sl];
+                    (lds + O_g0)[spos[sl]] += (lds + O_bS0)[sl]; (lds + O_g1)[spos[sl]] += (lds + O_bS1)[sl]; (lds + O_gz)[spos[sl]] += (lds + O_bSz)[sl];
                 } else if (e < 360) {
                     int i = e - 343;
                     double v0 = 0, v1 = 0, vz = 0;
                     for (int a = 0; a < 6; a++) {
-                        v0 += L.Op[17 * a + i] * L.bp0[a] + L.Ov[17 * a + i] * L.bv[a];
-                        v1 += L.Op[17 * a + i] * L.bp1[a];
-                        vz += L.Op[17 * a + i] * L.bpz[a] + L.Ov[17 * a + i] * L.bv[a];
+                        v0 += (lds + O_Op)[17 * a + i] * (lds + O_bp0)[a] + (lds + O_Ov)[17 * a + i] * (lds + O_bv)[a];
+                        v1 += (lds + O_Op)[17 * a + i] * (lds + O_bp1)[a];
+                        vz += (lds + O_Op)[17 * a + i] * (lds + O_bpz)[a] + (lds + O_Ov)[17 * a + i] * (lds + O_bv)[a];
                     }
-                    L.g0[pos17(i)] += v0; L.g1[pos17(i)] += v1; L.gz[pos17(i)] += vz;
+                    (lds + O_g0)[pos17(i)] += v0; (lds + O_g1)[pos17(i)] += v1; (lds + O_gz)[pos17(i)] += vz;
                 }
             }
         }
@@ -279,29 +279,29 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 for (int c = 0; c < 6; c++)
                     for (int a = 0; a < 3; a++) {
                         double t = 0;
-                        for (int bb = 0; bb < 3; bb++) t += L.M3[9 * c + 3 * a + bb] * L.Jp[21 * c + 7 * bb + j];
-                        v += L.Jp[21 * c + 7 * a + i] * t;
+                        for (int bb = 0; bb < 3; bb++) t += (lds + O_M3)[9 * c + 3 * a + bb] * (lds + O_Jp)[21 * c + 7 * bb + j];
+                        v += (lds + O_Jp)[21 * c + 7 * a + i] * t;
                     }
-                L.W[(Z_Q + i) * LDW + Z_Q + j] += v;
+                (lds + O_W)[(Z_Q + i) * LDW + Z_Q + j] += v;
             } else if (e < 91) {
                 int i = (e - 49) / 6, c = (e - 49) % 6;
                 double v = 0;
-                for (int a = 0; a < 3; a++) v += L.Jp[21 * c + 7 * a + i] * L.mc[3 * c + a];
-                L.W[(Z_Q + i) * LDW + Z_D + c] += v;
-                L.W[(Z_D + c) * LDW + Z_Q + i] += v;
+                for (int a = 0; a < 3; a++) v += (lds + O_Jp)[21 * c + 7 * a + i] * (lds + O_mc)[3 * c + a];
+                (lds + O_W)[(Z_Q + i) * LDW + Z_D + c] += v;
+                (lds + O_W)[(Z_D + c) * LDW + Z_Q + i] += v;
             } else if (e < 97) {
                 int c = e - 91;
-                L.W[(Z_D + c) * LDW + Z_D + c] += L.sc[c];
-                L.g0[Z_D + c] += L.bc0[c]; L.g1[Z_D + c] += L.bc1[c]; L.gz[Z_D + c] += L.bcz[c];
+                (lds + O_W)[(Z_D + c) * LDW + Z_D + c] += (lds + O_sc)[c];
+                (lds + O_g0)[Z_D + c] += (lds + O_bc0)[c]; (lds + O_g1)[Z_D + c] += (lds + O_bc1)[c]; (lds + O_gz)[Z_D + c] += (lds + O_bcz)[c];
             } else {
                 int i = e - 97;
                 double v0 = 0, v1 = 0, vz = 0;
                 for (int c = 0; c < 6; c++)
                     for (int a = 0; a < 3; a++) {
-                        double jp = L.Jp[21 * c + 7 * a + i];
-                        v0 += jp * L.b30[3 * c + a]; v1 += jp * L.b31[3 * c + a]; vz += jp * L.b3z[3 * c + a];
+                        double jp = (lds + O_Jp)[21 * c + 7 * a + i];
+                        v0 += jp * (lds + O_b30)[3 * c + a]; v1 += jp * (lds + O_b31)[3 * c + a]; vz += jp * (lds + O_b3z)[3 * c + a];
                     }
-                L.g0[Z_Q + i] += v0; L.g1[Z_Q + i] += v1; L.gz[Z_Q + i] += vz;
+                (lds + O_g0)[Z_Q + i] += v0; (lds + O_g1)[Z_Q + i] += v1; (lds + O_gz)[Z_Q + i] += vz;
             }
         }
         BMPC_SYNC();
@@ -310,50 +310,50 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         if (hess_mode) {
             if (lane < 27) {   // generalised forces: on p_ee (3), on v (6), on the 6 collision points (18)
                 double v;
-                if (lane < 3) v = L.bpz[lane];
+                if (lane < 3) v = (lds + O_bpz)[lane];
                 else if (lane < 9) {
                     int a = lane - 3;
-                    v = L.bv[a];
-                    if (a >= 3) { v += 0.5 * dc.dt * L.bpz[a]; if (!term) v += dc.dt * L.lam[Z_PI + a - 3]; }
-                } else v = L.b3z[lane - 9];
-                L.misc[lane] = v;
+                    v = (lds + O_bv)[a];
+                    if (a >= 3) { v += 0.5 * dc.dt * (lds + O_bpz)[a]; if (!term) v += dc.dt * (lds + O_lam)[Z_PI + a - 3]; }
+                } else v = (lds + O_b3z)[lane - 9];
+                (lds + O_misc)[lane] = v;
             }
             BMPC_SYNC();
             const int njc[6] = {2, 3, 4, 5, 6, 4};
             for (int e = lane; e < 98; e += BMPC_NT) {
-                const LDSD* Fp = L.misc; const LDSD* Fv = L.misc + 3; const LDSD* Fc = L.misc + 9;
+                const LDSD* Fp = (lds + O_misc); const LDSD* Fv = (lds + O_misc) + 3; const LDSD* Fc = (lds + O_misc) + 9;
                 if (e < 49) {          // q_a x q_b
                     int a = e / 7, bq = e % 7, m = a < bq ? a : bq, M = a < bq ? bq : a;
-                    double zm[3] = {L.zax[3 * m], L.zax[3 * m + 1], L.zax[3 * m + 2]};
-                    double cM[3] = {L.J[M], L.J[7 + M], L.J[14 + M]}, zc[3];
+                    double zm[3] = {(lds + O_zax)[3 * m], (lds + O_zax)[3 * m + 1], (lds + O_zax)[3 * m + 2]};
+                    double cM[3] = {(lds + O_J)[M], (lds + O_J)[7 + M], (lds + O_J)[14 + M]}, zc[3];
                     cross3(zm, cM, zc);
                     double acc = dot3(Fp, zc);
                     for (int c = 0; c < 6; c++)
                         if (M < njc[c]) {
-                            double cc[3] = {L.Jp[21 * c + M], L.Jp[21 * c + 7 + M], L.Jp[21 * c + 14 + M]};
+                            double cc[3] = {(lds + O_Jp)[21 * c + M], (lds + O_Jp)[21 * c + 7 + M], (lds + O_Jp)[21 * c + 14 + M]};
                             cross3(zm, cc, zc);
                             acc += dot3(Fc + 3 * c, zc);
                         }
                     // q-q block of the v = J(q) dq curvature (third-order kinematics times dq)
                     for (int j = 0; j < 7; j++) {
-                        double dqj = L.yz[Z_DQ + j];
+                        double dqj = (lds + O_yz)[Z_DQ + j];
                         if (dqj == 0.0) continue;
                         int m1 = a < j ? a : j, M1 = a < j ? j : a;
-                        double z1[3] = {L.zax[3 * m1], L.zax[3 * m1 + 1], L.zax[3 * m1 + 2]};
-                        double c1[3] = {L.J[M1], L.J[7 + M1], L.J[14 + M1]};
+                        double z1[3] = {(lds + O_zax)[3 * m1], (lds + O_zax)[3 * m1 + 1], (lds + O_zax)[3 * m1 + 2]};
+                        double c1[3] = {(lds + O_J)[M1], (lds + O_J)[7 + M1], (lds + O_J)[14 + M1]};
                         double t1[3] = {0, 0, 0}, t2[3], dzm[3], dcM[3];
-                        if (bq < m1) { double zb[3] = {L.zax[3 * bq], L.zax[3 * bq + 1], L.zax[3 * bq + 2]}; cross3(zb, z1, dzm); cross3(dzm, c1, t1); }
+                        if (bq < m1) { double zb[3] = {(lds + O_zax)[3 * bq], (lds + O_zax)[3 * bq + 1], (lds + O_zax)[3 * bq + 2]}; cross3(zb, z1, dzm); cross3(dzm, c1, t1); }
                         int m2 = bq < M1 ? bq : M1, M2 = bq < M1 ? M1 : bq;
-                        double z2[3] = {L.zax[3 * m2], L.zax[3 * m2 + 1], L.zax[3 * m2 + 2]};
-                        double c2[3] = {L.J[M2], L.J[7 + M2], L.J[14 + M2]};
+                        double z2[3] = {(lds + O_zax)[3 * m2], (lds + O_zax)[3 * m2 + 1], (lds + O_zax)[3 * m2 + 2]};
+                        double c2[3] = {(lds + O_J)[M2], (lds + O_J)[7 + M2], (lds + O_J)[14 + M2]};
                         cross3(z2, c2, dcM);
                         cross3(z1, dcM, t2);
                         double lin = Fv[0] * (t1[0] + t2[0]) + Fv[1] * (t1[1] + t2[1]) + Fv[2] * (t1[2] + t2[2]);
                         double ang = 0;
                         if (a < j) {
-                            double za[3] = {L.zax[3 * a], L.zax[3 * a + 1], L.zax[3 * a + 2]};
-                            double zj[3] = {L.zax[3 * j], L.zax[3 * j + 1], L.zax[3 * j + 2]};
-                            double zb[3] = {L.zax[3 * bq], L.zax[3 * bq + 1], L.zax[3 * bq + 2]};
+                            double za[3] = {(lds + O_zax)[3 * a], (lds + O_zax)[3 * a + 1], (lds + O_zax)[3 * a + 2]};
+                            double zj[3] = {(lds + O_zax)[3 * j], (lds + O_zax)[3 * j + 1], (lds + O_zax)[3 * j + 2]};
+                            double zb[3] = {(lds + O_zax)[3 * bq], (lds + O_zax)[3 * bq + 1], (lds + O_zax)[3 * bq + 2]};
                             double u1[3] = {0, 0, 0}, u2[3] = {0, 0, 0}, tmp[3];
                             if (bq < a) { cross3(zb, za, tmp); cross3(tmp, zj, u1); }
                             if (bq < j) { cross3(zb, zj, tmp); cross3(za, tmp, u2); }
@@ -361,21 +361,21 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                         }
                         acc += dqj * (lin + ang);
                     }
-                    L.W[(Z_Q + a) * LDW + Z_Q + bq] += acc;
+                    (lds + O_W)[(Z_Q + a) * LDW + Z_Q + bq] += acc;
                 } else {               // q_i x dq_j  (d2 v / dq_i d dq_j = dJ[:, j]/dq_i)
                     int i = (e - 49) / 7, j = (e - 49) % 7, m = i < j ? i : j, M = i < j ? j : i;
-                    double zm[3] = {L.zax[3 * m], L.zax[3 * m + 1], L.zax[3 * m + 2]};
-                    double cM[3] = {L.J[M], L.J[7 + M], L.J[14 + M]}, zc[3];
+                    double zm[3] = {(lds + O_zax)[3 * m], (lds + O_zax)[3 * m + 1], (lds + O_zax)[3 * m + 2]};
+                    double cM[3] = {(lds + O_J)[M], (lds + O_J)[7 + M], (lds + O_J)[14 + M]}, zc[3];
                     cross3(zm, cM, zc);
                     double acc = dot3(Fv, zc);
                     if (i < j) {
-                        double zi[3] = {L.zax[3 * i], L.zax[3 * i + 1], L.zax[3 * i + 2]};
-                        double zj[3] = {L.zax[3 * j], L.zax[3 * j + 1], L.zax[3 * j + 2]}, zz[3];
+                        double zi[3] = {(lds + O_zax)[3 * i], (lds + O_zax)[3 * i + 1], (lds + O_zax)[3 * i + 2]};
+                        double zj[3] = {(lds + O_zax)[3 * j], (lds + O_zax)[3 * j + 1], (lds + O_zax)[3 * j + 2]}, zz[3];
                         cross3(zi, zj, zz);
                         acc += dot3(Fv + 3, zz);
                     }
-                    L.W[(Z_Q + i) * LDW + Z_DQ + j] += acc;
-                    L.W[(Z_DQ + j) * LDW + Z_Q + i] += acc;
+                    (lds + O_W)[(Z_Q + i) * LDW + Z_DQ + j] += acc;
+                    (lds + O_W)[(Z_DQ + j) * LDW + Z_Q + i] += acc;
                 }
             }
             BMPC_SYNC();
@@ -388,15 +388,15 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
             else if (lane < 10) { pos = Z_U + lane - 3; w2 = 2 * wts[7]; }
             else if (lane < 14) { int m = lane - 10; pos = (m == 0 ? Z_RS : m == 1 ? Z_DRS : m == 2 ? Z_PS : Z_DPS); w2 = 2 * ((m & 1) ? wts[10] : wts[9]); }
             else { int i = lane - 14; pos = Z_D + i; w2 = term ? (2 * wts[10] + (i != 4 ? 2 * wts[8] : 0.0)) : 0.0; extra = (term && i != 4) ? 2 * wts[8] * sp[P_SLACKS0 + i] : 0.0; }
-            val = w2 * L.yz[pos] + extra;
-            L.W[pos * LDW + pos] += w2; L.g0[pos] += val; L.gz[pos] += val;
+            val = w2 * (lds + O_yz)[pos] + extra;
+            (lds + O_W)[pos * LDW + pos] += w2; (lds + O_g0)[pos] += val; (lds + O_gz)[pos] += val;
         }
         BMPC_SYNC();
         BMPC_PROF(6);
         // ---- natural -> zeta coordinates: H = T^T Hy T (column pass, then row pass + vectors) ----
         for (int e = lane; e < NZ * 9; e += BMPC_NT) {
             int i = e / 9, t = e % 9;
-            LDSD* row = L.W + i * LDW;
+            LDSD* row = (lds + O_W) + i * LDW;
             if (t < 7) row[Z_U + t] += dc.c3 * row[Z_Q + t] + dc.c2 * row[Z_DQ + t] + dc.c1 * row[Z_DDQ + t];
             else if (t == 7) row[Z_DRS] += 0.5 * dc.dt * row[Z_RS];
             else row[Z_DPS] += 0.5 * dc.dt * row[Z_PS];
@@ -405,13 +405,13 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         for (int e = lane; e < NZ * 9 + 27; e += BMPC_NT) {
             if (e < NZ * 9) {
                 int j = e / 9, t = e % 9;
-                LDSD* W = L.W;
+                LDSD* W = (lds + O_W);
                 if (t < 7) W[(Z_U + t) * LDW + j] += dc.c3 * W[(Z_Q + t) * LDW + j] + dc.c2 * W[(Z_DQ + t) * LDW + j] + dc.c1 * W[(Z_DDQ + t) * LDW + j];
                 else if (t == 7) W[Z_DRS * LDW + j] += 0.5 * dc.dt * W[Z_RS * LDW + j];
                 else W[Z_DPS * LDW + j] += 0.5 * dc.dt * W[Z_PS * LDW + j];
             } else {
                 int vsel = (e - NZ * 9) / 9, t = (e - NZ * 9) % 9;
-                LDSD* g = vsel == 0 ? L.g0 : vsel == 1 ? L.g1 : L.gz;
+                LDSD* g = vsel == 0 ? (lds + O_g0) : vsel == 1 ? (lds + O_g1) : (lds + O_gz);
                 if (t < 7) g[Z_U + t] += dc.c3 * g[Z_Q + t] + dc.c2 * g[Z_DQ + t] + dc.c1 * g[Z_DDQ + t];
                 else if (t == 7) g[Z_DRS] += 0.5 * dc.dt * g[Z_RS];
                 else g[Z_DPS] += 0.5 * dc.dt * g[Z_PS];
@@ -420,8 +420,8 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
         BMPC_SYNC();
         if (k == 1 && lane < 2) {   // zeta-diagonal rows rs~_1, ps~_1 >= 0
             int s = S_RS1 + lane, pos = lane ? Z_PS : Z_RS;
-            L.W[pos * LDW + pos] += L.rowS[s];
-            L.g0[pos] -= L.rowS[NSLOT + s]; L.g1[pos] -= L.rowS[2 * NSLOT + s]; L.gz[pos] -= L.rowS[3 * NSLOT + s];
+            (lds + O_W)[pos * LDW + pos] += (lds + O_rowS)[s];
+            (lds + O_g0)[pos] -= (lds + O_rowS)[NSLOT + s]; (lds + O_g1)[pos] -= (lds + O_rowS)[2 * NSLOT + s]; (lds + O_gz)[pos] -= (lds + O_rowS)[3 * NSLOT + s];
         }
         BMPC_PROF(7);
         // ---- coupling with stage k+1 ----
@@ -430,28 +430,28 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 int c = lane;
                 for (int a = 0; a < 3; a++) {
                     double v = 0;
-                    if (c < Z_DQ) v = dc.dt * L.G[7 * (3 + a) + c];
-                    else if (c < Z_DDQ) v = dc.dt * L.J[7 * (3 + a) + c - 7];
-                    else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * L.G[7 * (3 + a) + c - Z_U] + dc.c2 * L.J[7 * (3 + a) + c - Z_U]);
-                    L.Et[a * NZ + c] = v;
+                    if (c < Z_DQ) v = dc.dt * (lds + O_G)[7 * (3 + a) + c];
+                    else if (c < Z_DDQ) v = dc.dt * (lds + O_J)[7 * (3 + a) + c - 7];
+                    else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * (lds + O_G)[7 * (3 + a) + c - Z_U] + dc.c2 * (lds + O_J)[7 * (3 + a) + c - Z_U]);
+                    (lds + O_Et)[a * NZ + c] = v;
                 }
                 PhiCol pc = phi_col(c, dc);
                 for (int a = 0; a < 3; a++)
-                    L.Y[c * 3 + a] = pc.c0 * L.P[pc.i0 * LDP + Z_PI + a] + pc.c1 * L.P[pc.i1 * LDP + Z_PI + a] +
-                                     pc.c2 * L.P[pc.i2 * LDP + Z_PI + a];
+                    (lds + O_Y)[c * 3 + a] = pc.c0 * (lds + O_P)[pc.i0 * LDP + Z_PI + a] + pc.c1 * (lds + O_P)[pc.i1 * LDP + Z_PI + a] +
+                                     pc.c2 * (lds + O_P)[pc.i2 * LDP + Z_PI + a];
             }
             if (lane < NX) {
-                double r = defect_row(L, dc, lane);
-                L.rdef[lane] = r;
+                double r = defect_row(lds, dc, lane);
+                (lds + O_rdef)[lane] = r;
                 ac.prim = fmax(ac.prim, fabs(r)); ac.theta += fabs(r);
             }
             BMPC_SYNC();
             if (lane < NX) {
-                double v = L.pv0[lane];
-                for (int j = 0; j < NX; j++) v += L.P[lane * LDP + j] * L.rdef[j];
-                L.vt0[lane] = v;
+                double v = (lds + O_pv0)[lane];
+                for (int j = 0; j < NX; j++) v += (lds + O_P)[lane * LDP + j] * (lds + O_rdef)[j];
+                (lds + O_vt0)[lane] = v;
             } else if (lane < 2 * NX) {
-                L.vt1[lane - NX] = L.pv1[lane - NX];
+                (lds + O_vt1)[lane - NX] = (lds + O_pv1)[lane - NX];
             }
             BMPC_SYNC();
             // W += [A B]^T P+ [A B]: structured part through the <=3-term column structure of [As Bs],
@@ -460,88 +460,88 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
                 int i = e / NZ, j = e - NZ * i;
                 if (j < i) continue;
                 PhiCol pi_ = phi_col(i, dc), pj = phi_col(j, dc);
-                const LDSD* P0 = L.P + pi_.i0 * LDP; const LDSD* P1 = L.P + pi_.i1 * LDP; const LDSD* P2 = L.P + pi_.i2 * LDP;
+                const LDSD* P0 = (lds + O_P) + pi_.i0 * LDP; const LDSD* P1 = (lds + O_P) + pi_.i1 * LDP; const LDSD* P2 = (lds + O_P) + pi_.i2 * LDP;
                 double v = pi_.c0 * (pj.c0 * P0[pj.i0] + pj.c1 * P0[pj.i1] + pj.c2 * P0[pj.i2]) +
                            pi_.c1 * (pj.c0 * P1[pj.i0] + pj.c1 * P1[pj.i1] + pj.c2 * P1[pj.i2]) +
                            pi_.c2 * (pj.c0 * P2[pj.i0] + pj.c1 * P2[pj.i1] + pj.c2 * P2[pj.i2]);
-                double ei0 = L.Et[i], ei1 = L.Et[NZ + i], ei2 = L.Et[2 * NZ + i];
-                double ej0 = L.Et[j], ej1 = L.Et[NZ + j], ej2 = L.Et[2 * NZ + j];
-                v += L.Y[i * 3] * ej0 + L.Y[i * 3 + 1] * ej1 + L.Y[i * 3 + 2] * ej2;
-                v += ei0 * L.Y[j * 3] + ei1 * L.Y[j * 3 + 1] + ei2 * L.Y[j * 3 + 2];
-                const LDSD* Pp = L.P + Z_PI * LDP + Z_PI;
+                double ei0 = (lds + O_Et)[i], ei1 = (lds + O_Et)[NZ + i], ei2 = (lds + O_Et)[2 * NZ + i];
+                double ej0 = (lds + O_Et)[j], ej1 = (lds + O_Et)[NZ + j], ej2 = (lds + O_Et)[2 * NZ + j];
+                v += (lds + O_Y)[i * 3] * ej0 + (lds + O_Y)[i * 3 + 1] * ej1 + (lds + O_Y)[i * 3 + 2] * ej2;
+                v += ei0 * (lds + O_Y)[j * 3] + ei1 * (lds + O_Y)[j * 3 + 1] + ei2 * (lds + O_Y)[j * 3 + 2];
+                const LDSD* Pp = (lds + O_P) + Z_PI * LDP + Z_PI;
                 v += ei0 * (Pp[0] * ej0 + Pp[1] * ej1 + Pp[2] * ej2) + ei1 * (Pp[LDP] * ej0 + Pp[LDP + 1] * ej1 + Pp[LDP + 2] * ej2) +
                      ei2 * (Pp[2 * LDP] * ej0 + Pp[2 * LDP + 1] * ej1 + Pp[2 * LDP + 2] * ej2);
-                L.W[i * LDW + j] += v;
-                if (j != i) L.W[j * LDW + i] += v;
+                (lds + O_W)[i * LDW + j] += v;
+                if (j != i) (lds + O_W)[j * LDW + i] += v;
             }
             if (lane < NZ) {
                 int c = lane;
                 PhiCol pc = phi_col(c, dc);
-                double gl = pc.c0 * L.lam[pc.i0] + pc.c1 * L.lam[pc.i1] + pc.c2 * L.lam[pc.i2];
-                double a0 = pc.c0 * L.vt0[pc.i0] + pc.c1 * L.vt0[pc.i1] + pc.c2 * L.vt0[pc.i2];
-                double a1 = pc.c0 * L.vt1[pc.i0] + pc.c1 * L.vt1[pc.i1] + pc.c2 * L.vt1[pc.i2];
+                double gl = pc.c0 * (lds + O_lam)[pc.i0] + pc.c1 * (lds + O_lam)[pc.i1] + pc.c2 * (lds + O_lam)[pc.i2];
+                double a0 = pc.c0 * (lds + O_vt0)[pc.i0] + pc.c1 * (lds + O_vt0)[pc.i1] + pc.c2 * (lds + O_vt0)[pc.i2];
+                double a1 = pc.c0 * (lds + O_vt1)[pc.i0] + pc.c1 * (lds + O_vt1)[pc.i1] + pc.c2 * (lds + O_vt1)[pc.i2];
                 for (int a = 0; a < 3; a++) {
-                    double ea = L.Et[a * NZ + c];
-                    gl += ea * L.lam[Z_PI + a]; a0 += ea * L.vt0[Z_PI + a]; a1 += ea * L.vt1[Z_PI + a];
+                    double ea = (lds + O_Et)[a * NZ + c];
+                    gl += ea * (lds + O_lam)[Z_PI + a]; a0 += ea * (lds + O_vt0)[Z_PI + a]; a1 += ea * (lds + O_vt1)[Z_PI + a];
                 }
-                L.gz[c] += gl; L.g0[c] += a0; L.g1[c] += a1;
+                (lds + O_gz)[c] += gl; (lds + O_g0)[c] += a0; (lds + O_g1)[c] += a1;
             }
         }
         BMPC_SYNC();
         BMPC_PROF(8);
         // ---- adjoint multipliers + dual residual (gz now holds the Lagrangian gradient) ----
         if (lane < NZ) {
-            double gl = L.gz[lane];
+            double gl = (lds + O_gz)[lane];
             if (lane >= NX || (k == 1 && lane >= 24)) ac.dual = fmax(ac.dual, fabs(gl));
-            if (lane < NX) { L.lam[lane] = gl; ac.lamsum += fabs(gl); }
+            if (lane < NX) { (lds + O_lam)[lane] = gl; ac.lamsum += fabs(gl); }
         }
         BMPC_PROF(9);
         // ---- control block factorisation, gains, Schur complement ----
         double Lc[45];
-        if (!chol9(L.W, reg, Lc)) ok = false;
+        if (!chol9((lds + O_W), reg, Lc)) ok = false;
         if (lane < NX + 2) {
             double rhs[NU];
 #pragma unroll
             for (int l = 0; l < NU; l++)
-                rhs[l] = (lane < NX) ? L.W[(NX + l) * LDW + lane] : (lane == NX ? L.g0[NX + l] : L.g1[NX + l]);
+                rhs[l] = (lane < NX) ? (lds + O_W)[(NX + l) * LDW + lane] : (lane == NX ? (lds + O_g0)[NX + l] : (lds + O_g1)[NX + l]);
             chol9_solve(Lc, rhs);
 #pragma unroll
             for (int l = 0; l < NU; l++) {
-                if (lane < NX) { L.Kl[l * NX + lane] = -rhs[l]; ws.K[(size_t)k * NU * NX + l * NX + lane] = -rhs[l]; }
-                else { L.kf[(lane - NX) * 16 + l] = -rhs[l]; ws.kf[k * 32 + (lane - NX) * 16 + l] = -rhs[l]; }
+                if (lane < NX) { (lds + O_Kl)[l * NX + lane] = -rhs[l]; ws.K[(size_t)k * NU * NX + l * NX + lane] = -rhs[l]; }
+                else { (lds + O_kf)[(lane - NX) * 16 + l] = -rhs[l]; ws.kf[k * 32 + (lane - NX) * 16 + l] = -rhs[l]; }
             }
         }
         BMPC_SYNC();
         for (int e = lane; e < NX * NX; e += BMPC_NT) {
             int i = e / NX, j = e % NX;
             if (j < i) continue;
-            double v = L.W[i * LDW + j];
-            for (int l = 0; l < NU; l++) v += L.W[(NX + l) * LDW + i] * L.Kl[l * NX + j];
-            L.P[i * LDP + j] = v;
-            L.P[j * LDP + i] = v;
+            double v = (lds + O_W)[i * LDW + j];
+            for (int l = 0; l < NU; l++) v += (lds + O_W)[(NX + l) * LDW + i] * (lds + O_Kl)[l * NX + j];
+            (lds + O_P)[i * LDP + j] = v;
+            (lds + O_P)[j * LDP + i] = v;
         }
         if (lane < 2 * NX) {
             int i = lane & (NX - 1);
-            const LDSD* g = (lane < NX) ? L.g0 : L.g1;
-            const LDSD* kf = L.kf + ((lane < NX) ? 0 : 16);
+            const LDSD* g = (lane < NX) ? (lds + O_g0) : (lds + O_g1);
+            const LDSD* kf = (lds + O_kf) + ((lane < NX) ? 0 : 16);
             double v = g[i];
-            for (int l = 0; l < NU; l++) v += L.W[(NX + l) * LDW + i] * kf[l];
-            ((lane < NX) ? L.pv0 : L.pv1)[i] = v;
+            for (int l = 0; l < NU; l++) v += (lds + O_W)[(NX + l) * LDW + i] * kf[l];
+            ((lane < NX) ? (lds + O_pv0) : (lds + O_pv1))[i] = v;
         }
-        if (lane < NZ) L.znext[lane] = L.zeta[lane];
+        if (lane < NZ) (lds + O_znext)[lane] = (lds + O_zeta)[lane];
         BMPC_SYNC();
         BMPC_PROF(10);
     }
-    // initial defect of the pinned part of x_1 (zeta_1 is still in L.zeta)
+    // initial defect of the pinned part of x_1 (zeta_1 is still in (lds + O_zeta))
     if (lane < 24) {
-        double r = L.x1fix[lane] - L.zeta[lane];
-        L.r0[lane] = r;
+        double r = (lds + O_x1fix)[lane] - (lds + O_zeta)[lane];
+        (lds + O_r0)[lane] = r;
         ac.prim = fmax(ac.prim, fabs(r)); ac.theta += fabs(r);
     }
-    double cmax = wg_max(ac.cmax, L.red, lane), csum = wg_sum(ac.csum, L.red, lane), cmin = wg_min(ac.cmin, L.red, lane);
-    double zsum = wg_sum(ac.zsum, L.red, lane), prim = wg_max(ac.prim, L.red, lane), theta = wg_sum(ac.theta, L.red, lane);
-    double logs = wg_sum(ac.logs, L.red, lane), lamsum = wg_sum(ac.lamsum, L.red, lane), dual = wg_max(ac.dual, L.red, lane);
-    int nrows = (int)(wg_sum((double)ac.nrows, L.red, lane) + 0.5);
+    double cmax = wg_max(ac.cmax, (lds + O_red), lane), csum = wg_sum(ac.csum, (lds + O_red), lane), cmin = wg_min(ac.cmin, (lds + O_red), lane);
+    double zsum = wg_sum(ac.zsum, (lds + O_red), lane), prim = wg_max(ac.prim, (lds + O_red), lane), theta = wg_sum(ac.theta, (lds + O_red), lane);
+    double logs = wg_sum(ac.logs, (lds + O_red), lane), lamsum = wg_sum(ac.lamsum, (lds + O_red), lane), dual = wg_max(ac.dual, (lds + O_red), lane);
+    int nrows = (int)(wg_sum((double)ac.nrows, (lds + O_red), lane) + 0.5);
     int neq = NX * (N - 2) + 24;
     kk.sd = fmax(100.0, (lamsum + zsum) / (double)(neq + nrows)) / 100.0;
     kk.sc = fmax(100.0, zsum / (double)nrows) / 100.0;
@@ -556,10 +556,10 @@ BMPC_DEV bool backward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws,
 // ------------------------------------------------------------------------------------------
 struct StepInfo { double ap, ad, dphi_f, dphi_bar; bool ok; };
 
-BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
+BMPC_NOINL void forward_sweep(const Inst I, LDSD* lds, const WsPtr ws, const DynC dc, int lane,
                             double mu, const double* iw0, StepInfo& si) {
-    const int N = A.o.N;
-    const LDSD* sp = L.sp;
+    const int N = I.N;
+    const LDSD* sp = (lds + O_sp);
     const LDSD* wts = sp + P_W;
     double tau = fmax(0.99, 1.0 - mu);
     double ap_l = 1.0, ad_l = 1.0, dbar_l = 0.0, dphi_f = 0.0;
@@ -568,19 +568,19 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
     {
         double Pf[36], rhs[8];
         for (int i = 0; i < 8; i++) {
-            double s = L.pv0[24 + i] + mu * L.pv1[24 + i];
-            for (int j = 0; j < 24; j++) s += L.P[(24 + i) * LDP + j] * L.r0[j];
+            double s = (lds + O_pv0)[24 + i] + mu * (lds + O_pv1)[24 + i];
+            for (int j = 0; j < 24; j++) s += (lds + O_P)[(24 + i) * LDP + j] * (lds + O_r0)[j];
             rhs[i] = -s;
         }
 #define PF(i, j) Pf[(i) * ((i) + 1) / 2 + (j)]
         for (int j = 0; j < 8; j++) {
-            double d = L.P[(24 + j) * LDP + 24 + j];
+            double d = (lds + O_P)[(24 + j) * LDP + 24 + j];
             for (int l = 0; l < j; l++) d -= PF(j, l) * PF(j, l);
             if (!(d > 0)) { si.ok = false; d = 1.0; }
             d = sqrt(d);
             PF(j, j) = d;
             for (int i = j + 1; i < 8; i++) {
-                double s = L.P[(24 + i) * LDP + 24 + j];
+                double s = (lds + O_P)[(24 + i) * LDP + 24 + j];
                 for (int l = 0; l < j; l++) s -= PF(i, l) * PF(j, l);
                 PF(i, j) = s / d;
             }
@@ -589,81 +589,81 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
         for (int i = 7; i >= 0; i--) { double s = rhs[i]; for (int l = i + 1; l < 8; l++) s -= PF(l, i) * rhs[l]; rhs[i] = s / PF(i, i); }
 #undef PF
         BMPC_SYNC();
-        if (lane < 24) L.dx[lane] = L.r0[lane];
-        if (lane == 0) for (int i = 0; i < 8; i++) L.dx[24 + i] = rhs[i];
+        if (lane < 24) (lds + O_dx)[lane] = (lds + O_r0)[lane];
+        if (lane == 0) for (int i = 0; i < 8; i++) (lds + O_dx)[24 + i] = rhs[i];
         BMPC_SYNC();
     }
     for (int k = 1; k < N; k++) {
         if (lane < NZ) {
             double z = ws.zeta[k * ZPAD + lane];
-            L.zeta[lane] = z;
+            (lds + O_zeta)[lane] = z;
             ws.zsave[k * ZPAD + lane] = z;
-            L.znext[lane] = (k < N - 1) ? ws.zeta[(k + 1) * ZPAD + lane] : 0.0;
+            (lds + O_znext)[lane] = (k < N - 1) ? ws.zeta[(k + 1) * ZPAD + lane] : 0.0;
         }
-        for (int e = lane; e < NU * NX; e += BMPC_NT) L.Kl[e] = ws.K[(size_t)k * NU * NX + e];
-        if (lane < 32) L.kf[lane] = ws.kf[k * 32 + lane];
+        for (int e = lane; e < NU * NX; e += BMPC_NT) (lds + O_Kl)[e] = ws.K[(size_t)k * NU * NX + e];
+        if (lane < 32) (lds + O_kf)[lane] = ws.kf[k * 32 + lane];
         BMPC_SYNC();
-        stage_eval(A, L, dc, k, lane, false, iw0);
+        stage_eval(I, lds, dc, k, lane, false, iw0);
         // g0 := dzeta, g1 := dy (natural)
-        if (lane < NX) L.g0[lane] = L.dx[lane];
+        if (lane < NX) (lds + O_g0)[lane] = (lds + O_dx)[lane];
         else if (lane < NZ) {
             int l = lane - NX;
-            double s = L.kf[l] + mu * L.kf[16 + l];
-            for (int j = 0; j < NX; j++) s += L.Kl[l * NX + j] * L.dx[j];
-            L.g0[lane] = s;
+            double s = (lds + O_kf)[l] + mu * (lds + O_kf)[16 + l];
+            for (int j = 0; j < NX; j++) s += (lds + O_Kl)[l * NX + j] * (lds + O_dx)[j];
+            (lds + O_g0)[lane] = s;
         }
         BMPC_SYNC();
-        if (lane < NZ) { ws.dz[k * ZPAD + lane] = L.g0[lane]; L.g1[lane] = nat_from_zeta(L.g0, lane, dc); }
+        if (lane < NZ) { ws.dz[k * ZPAD + lane] = (lds + O_g0)[lane]; (lds + O_g1)[lane] = nat_from_zeta((lds + O_g0), lane, dc); }
         BMPC_SYNC();
         if (lane < 24) {
             double s = 0;
-            if (lane < 3) { for (int j = 0; j < 7; j++) s += L.J[7 * lane + j] * L.g1[Z_Q + j]; L.dloc[lane] = s; }
+            if (lane < 3) { for (int j = 0; j < 7; j++) s += (lds + O_J)[7 * lane + j] * (lds + O_g1)[Z_Q + j]; (lds + O_dloc)[lane] = s; }
             else if (lane < 6) {
-                for (int j = 0; j < 7; j++) s += L.G[7 * lane + j] * L.g1[Z_Q + j] + L.J[7 * lane + j] * L.g1[Z_DQ + j];
-                L.dloc[lane] = L.g1[Z_PI + lane - 3] + 0.5 * dc.dt * s;
+                for (int j = 0; j < 7; j++) s += (lds + O_G)[7 * lane + j] * (lds + O_g1)[Z_Q + j] + (lds + O_J)[7 * lane + j] * (lds + O_g1)[Z_DQ + j];
+                (lds + O_dloc)[lane] = (lds + O_g1)[Z_PI + lane - 3] + 0.5 * dc.dt * s;
             } else {
                 int c = (lane - 6) / 3, a = (lane - 6) % 3;
-                for (int j = 0; j < 7; j++) s += L.Jp[21 * c + 7 * a + j] * L.g1[Z_Q + j];
-                L.dpt[lane - 6] = s;
+                for (int j = 0; j < 7; j++) s += (lds + O_Jp)[21 * c + 7 * a + j] * (lds + O_g1)[Z_Q + j];
+                (lds + O_dpt)[lane - 6] = s;
             }
         }
         BMPC_SYNC();
         // directional derivative of f (every lane, registers)
         {
             double s = 0;
-            for (int a = 0; a < 6; a++) s += L.kin[KN_G12 + a] * L.dloc[a];
+            for (int a = 0; a < 6; a++) s += (lds + O_kin)[KN_G12 + a] * (lds + O_dloc)[a];
             for (int a = 0; a < 6; a++) {
                 double dv = 0;
-                for (int j = 0; j < 7; j++) dv += L.G[7 * a + j] * L.g1[Z_Q + j] + L.J[7 * a + j] * L.g1[Z_DQ + j];
-                s += L.kin[KN_G12 + 6 + a] * dv;
+                for (int j = 0; j < 7; j++) dv += (lds + O_G)[7 * a + j] * (lds + O_g1)[Z_Q + j] + (lds + O_J)[7 * a + j] * (lds + O_g1)[Z_DQ + j];
+                s += (lds + O_kin)[KN_G12 + 6 + a] * dv;
             }
-            for (int j = 2; j <= 4; j++) s += 2 * wts[6] * L.yz[Z_DQ + j] * L.g1[Z_DQ + j];
-            for (int j = 0; j < 7; j++) s += 2 * wts[7] * L.yz[Z_U + j] * L.g1[Z_U + j];
-            s += 2 * wts[9] * L.yz[Z_RS] * L.g1[Z_RS] + 2 * wts[10] * L.yz[Z_DRS] * L.g1[Z_DRS] +
-                 2 * wts[9] * L.yz[Z_PS] * L.g1[Z_PS] + 2 * wts[10] * L.yz[Z_DPS] * L.g1[Z_DPS];
+            for (int j = 2; j <= 4; j++) s += 2 * wts[6] * (lds + O_yz)[Z_DQ + j] * (lds + O_g1)[Z_DQ + j];
+            for (int j = 0; j < 7; j++) s += 2 * wts[7] * (lds + O_yz)[Z_U + j] * (lds + O_g1)[Z_U + j];
+            s += 2 * wts[9] * (lds + O_yz)[Z_RS] * (lds + O_g1)[Z_RS] + 2 * wts[10] * (lds + O_yz)[Z_DRS] * (lds + O_g1)[Z_DRS] +
+                 2 * wts[9] * (lds + O_yz)[Z_PS] * (lds + O_g1)[Z_PS] + 2 * wts[10] * (lds + O_yz)[Z_DPS] * (lds + O_g1)[Z_DPS];
             if (k == N - 1)
                 for (int i = 0; i < 6; i++) {
-                    double gg = 2 * wts[10] * L.yz[Z_D + i] + (i != 4 ? 2 * wts[8] * (sp[P_SLACKS0 + i] + L.yz[Z_D + i]) : 0.0);
-                    s += gg * L.g1[Z_D + i];
+                    double gg = 2 * wts[10] * (lds + O_yz)[Z_D + i] + (i != 4 ? 2 * wts[8] * (sp[P_SLACKS0 + i] + (lds + O_yz)[Z_D + i]) : 0.0);
+                    s += gg * (lds + O_g1)[Z_D + i];
                 }
             dphi_f += s;
         }
         for (int s = lane; s < NSLOT; s += BMPC_NT) {
             Row r;
-            row_eval(A, L, b, k, s, r);
+            row_eval(I, lds, k, s, r);
             if (!r.kind) continue;
             double adot;
-            if (r.kind == 1) adot = r.coef * L.g1[r.pos];
-            else if (r.kind == 2) adot = r.coef * L.g0[r.pos];
+            if (r.kind == 1) adot = r.coef * (lds + O_g1)[r.pos];
+            else if (r.kind == 2) adot = r.coef * (lds + O_g0)[r.pos];
             else if (r.kind == 3) {
                 adot = 0;
-                for (int c = 0; c < 6; c++) adot += r.a[c] * L.dloc[c];
-                if (r.sel == 1) adot -= L.g1[Z_PS];
-                else if (r.sel == 2) adot -= L.g1[Z_RS];
-                else if (r.sel == 3) adot -= L.g1[Z_D + 5];
+                for (int c = 0; c < 6; c++) adot += r.a[c] * (lds + O_dloc)[c];
+                if (r.sel == 1) adot -= (lds + O_g1)[Z_PS];
+                else if (r.sel == 2) adot -= (lds + O_g1)[Z_RS];
+                else if (r.sel == 3) adot -= (lds + O_g1)[Z_D + 5];
             } else {
                 int c = r.pos;
-                adot = r.a[0] * L.dpt[3 * c] + r.a[1] * L.dpt[3 * c + 1] + r.a[2] * L.dpt[3 * c + 2] - L.g1[Z_D + c];
+                adot = r.a[0] * (lds + O_dpt)[3 * c] + r.a[1] * (lds + O_dpt)[3 * c + 1] + r.a[2] * (lds + O_dpt)[3 * c + 2] - (lds + O_g1)[Z_D + c];
             }
             double t = ws.t[k * NSLOT + s], z = ws.z[k * NSLOT + s];
             double dti = -(r.h + t) - adot;
@@ -676,7 +676,7 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
         // next dx = A dx + B dw + defect
         if (k < N - 1) {
             if (lane < NX) {
-                const LDSD* d = L.g0;
+                const LDSD* d = (lds + O_g0);
                 int i = lane;
                 double v;
                 if (i < Z_DQ) v = d[i] + dc.dt * d[i + 7] + 0.5 * dc.dt * dc.dt * d[i + 14] + dc.b3 * d[Z_U + i];
@@ -686,61 +686,66 @@ BMPC_DEV void forward_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, 
                     int a = i - Z_PI;
                     v = d[i];
                     for (int j = 0; j < 7; j++)
-                        v += dc.dt * (L.G[7 * (3 + a) + j] * L.g1[Z_Q + j] + L.J[7 * (3 + a) + j] * L.g1[Z_DQ + j]);
+                        v += dc.dt * ((lds + O_G)[7 * (3 + a) + j] * (lds + O_g1)[Z_Q + j] + (lds + O_J)[7 * (3 + a) + j] * (lds + O_g1)[Z_DQ + j]);
                 } else if (i == Z_RS) v = d[i] + dc.dt * d[Z_DRS];
                 else if (i == Z_PS) v = d[i] + dc.dt * d[Z_DPS];
                 else v = d[i];
-                L.dxn[i] = v + defect_row(L, dc, i);
+                (lds + O_dxn)[i] = v + defect_row(lds, dc, i);
             }
             BMPC_SYNC();
-            if (lane < NX) L.dx[lane] = L.dxn[lane];
+            if (lane < NX) (lds + O_dx)[lane] = (lds + O_dxn)[lane];
         }
         BMPC_SYNC();
     }
-    si.ap = fmin(1.0, wg_min(ap_l, L.red, lane));
-    si.ad = fmin(1.0, wg_min(ad_l, L.red, lane));
-    si.dphi_bar = wg_sum(dbar_l, L.red, lane);
+    si.ap = fmin(1.0, wg_min(ap_l, (lds + O_red), lane));
+    si.ad = fmin(1.0, wg_min(ad_l, (lds + O_red), lane));
+    si.dphi_bar = wg_sum(dbar_l, (lds + O_red), lane);
     si.dphi_f = dphi_f;
 }
 
 // trial point zeta = zsave + alpha dz, t = tsave + alpha dt: barrier objective pieces
-BMPC_DEV void trial_sweep(const KernelArgs& A, const Lds& L, const WsPtr& ws, const DynC& dc, int b, int lane,
+BMPC_NOINL void trial_sweep(const Inst I, LDSD* lds, const WsPtr ws, const DynC dc, int lane,
                           double alpha, const double* iw0, double& f1, double& th1, double& ls1) {
-    const int N = A.o.N;
+    const int N = I.N;
     double th_l = 0, ls_l = 0, fs = 0;
     for (int k = N - 1; k >= 1; k--) {
         if (lane < NZ) {
             double z = ws.zsave[k * ZPAD + lane] + alpha * ws.dz[k * ZPAD + lane];
-            L.zeta[lane] = z;
+            (lds + O_zeta)[lane] = z;
             ws.zeta[k * ZPAD + lane] = z;
         }
         BMPC_SYNC();
-        fs += stage_eval(A, L, dc, k, lane, false, iw0);
+        fs += stage_eval(I, lds, dc, k, lane, false, iw0);
         for (int s = lane; s < NSLOT; s += BMPC_NT) {
             Row r;
-            row_eval(A, L, b, k, s, r);
+            row_eval(I, lds, k, s, r);
             if (!r.kind) continue;
             double t = ws.tsave[k * NSLOT + s] + alpha * ws.dt[k * NSLOT + s];
             ws.t[k * NSLOT + s] = t;
             th_l += fabs(r.h + t);
             ls_l += log(t);
         }
-        if (k < N - 1 && lane < NX) th_l += fabs(defect_row(L, dc, lane));
+        if (k < N - 1 && lane < NX) th_l += fabs(defect_row(lds, dc, lane));
         BMPC_SYNC();
-        if (lane < NZ) L.znext[lane] = L.zeta[lane];
+        if (lane < NZ) (lds + O_znext)[lane] = (lds + O_zeta)[lane];
         BMPC_SYNC();
     }
-    if (lane < 24) th_l += fabs(L.x1fix[lane] - L.zeta[lane]);
-    th1 = wg_sum(th_l, L.red, lane);
-    ls1 = wg_sum(ls_l, L.red, lane);
+    if (lane < 24) th_l += fabs((lds + O_x1fix)[lane] - (lds + O_zeta)[lane]);
+    th1 = wg_sum(th_l, (lds + O_red), lane);
+    ls1 = wg_sum(ls_l, (lds + O_red), lane);
     f1 = fs;
 }
 
 // ------------------------------------------------------------------------------------------
 // One instance
 // ------------------------------------------------------------------------------------------
-BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, int b, int lane) {
+BMPC_DEV void solve_instance(const KernelArgs& A, LDSD* lds, double* wsbase, int b, int lane) {
     const SolverOpts& o = A.o;
+    Inst I;
+    I.N = A.o.N; I.b = b;
+    I.lbx = A.lbx + (size_t)b * (44 * A.o.N + 6); I.ubx = A.ubx + (size_t)b * (44 * A.o.N + 6);
+    I.pg = A.p + (size_t)b * NPAR;
+    I.prof = A.prof;
     const int N = o.N, n_w = 44 * N + 6;
     const double dt = o.dt;
     DynC dc;
@@ -752,21 +757,21 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
     const double* lbx = A.lbx + (size_t)b * n_w;
     for (int e = lane; e < 90; e += BMPC_NT) {   // robot constants: jxyz[21] jrot[63] ee_xyz[3] l4c_xyz[3]
         const double* rcp = (const double*)A.rc;
-        L.rob[e] = rcp[e < 87 ? e : e + 9];
+        (lds + O_rob)[e] = rcp[e < 87 ? e : e + 9];
     }
-    for (int e = lane; e < NSP; e += BMPC_NT) L.sp[e] = A.p[(size_t)b * NPAR + (e < SP_ASETJ ? e : e + (P_ASETJ - SP_ASETJ))];
+    for (int e = lane; e < NSP; e += BMPC_NT) (lds + O_sp)[e] = A.p[(size_t)b * NPAR + (e < SP_ASETJ ? e : e + (P_ASETJ - SP_ASETJ))];
     // stage-0 pins (BoundMPC.py:551-556): lbx == ubx there
     double iw0[3];
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     if (lane < 7) {
         int j = lane;
         double q0 = lbx[j * N], dq0 = lbx[7 * N + j * N], ddq0 = lbx[14 * N + j * N], u0 = lbx[21 * N + j * N];
-        L.x1fix[Z_Q + j] = q0 + dt * dq0 + dt * dt / 2 * ddq0 + dt * dt * dt / 8 * u0;
-        L.x1fix[Z_DQ + j] = dq0 + dt * ddq0 + dt * dt / 3 * u0;
-        L.x1fix[Z_DDQ + j] = ddq0 + dt / 2 * u0;
+        (lds + O_x1fix)[Z_Q + j] = q0 + dt * dq0 + dt * dt / 2 * ddq0 + dt * dt * dt / 8 * u0;
+        (lds + O_x1fix)[Z_DQ + j] = dq0 + dt * ddq0 + dt * dt / 3 * u0;
+        (lds + O_x1fix)[Z_DDQ + j] = ddq0 + dt / 2 * u0;
     } else if (lane < 10) {
         int c = lane - 7;
-        L.x1fix[Z_PI + c] = lbx[28 * N + (3 + c) * N] + dt / 2 * lbx[34 * N + (3 + c) * N];
+        (lds + O_x1fix)[Z_PI + c] = lbx[28 * N + (3 + c) * N] + dt / 2 * lbx[34 * N + (3 + c) * N];
     }
     BMPC_SYNC();
     // ---- initial iterate from x0 (natural -> zeta); pi_k = p_rot_k - dt/2 w(q_k, dq_k) ----
@@ -774,26 +779,26 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
         if (lane < 7) {
             int j = lane;
             double uu = x0[21 * N + j * N + k];
-            L.zeta[Z_Q + j] = x0[j * N + k] - dc.c3 * uu;
-            L.zeta[Z_DQ + j] = x0[7 * N + j * N + k] - dc.c2 * uu;
-            L.zeta[Z_DDQ + j] = x0[14 * N + j * N + k] - dc.c1 * uu;
-            L.zeta[Z_U + j] = uu;
+            (lds + O_zeta)[Z_Q + j] = x0[j * N + k] - dc.c3 * uu;
+            (lds + O_zeta)[Z_DQ + j] = x0[7 * N + j * N + k] - dc.c2 * uu;
+            (lds + O_zeta)[Z_DDQ + j] = x0[14 * N + j * N + k] - dc.c1 * uu;
+            (lds + O_zeta)[Z_U + j] = uu;
         } else if (lane < 10) {
             int c = lane - 7;
-            L.zeta[Z_PI + c] = x0[28 * N + (3 + c) * N + k];      // p_rot for now
+            (lds + O_zeta)[Z_PI + c] = x0[28 * N + (3 + c) * N + k];      // p_rot for now
         } else if (lane == 10) {
             double rs = x0[40 * N + 6 + k], drs = x0[41 * N + 6 + k], ps = x0[42 * N + 6 + k], dps = x0[43 * N + 6 + k];
-            L.zeta[Z_RS] = rs - dt / 2 * drs; L.zeta[Z_PS] = ps - dt / 2 * dps;
-            L.zeta[Z_DRS] = drs; L.zeta[Z_DPS] = dps;
+            (lds + O_zeta)[Z_RS] = rs - dt / 2 * drs; (lds + O_zeta)[Z_PS] = ps - dt / 2 * dps;
+            (lds + O_zeta)[Z_DRS] = drs; (lds + O_zeta)[Z_DPS] = dps;
         } else if (lane < 17) {
             int i = lane - 11;
-            L.zeta[Z_D + i] = x0[40 * N + i];
+            (lds + O_zeta)[Z_D + i] = x0[40 * N + i];
         }
         BMPC_SYNC();
-        stage_eval(A, L, dc, k, lane, false, iw0);
+        stage_eval(I, lds, dc, k, lane, false, iw0);
         if (lane < NZ) {
-            double z = L.zeta[lane];
-            if (lane >= Z_PI && lane < Z_RS) z -= dt / 2 * L.rc[RC_V + 3 + lane - Z_PI];
+            double z = (lds + O_zeta)[lane];
+            if (lane >= Z_PI && lane < Z_RS) z -= dt / 2 * (lds + O_rc)[RC_V + 3 + lane - Z_PI];
             ws.zeta[k * ZPAD + lane] = z;
         }
         BMPC_SYNC();
@@ -801,12 +806,12 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
     // ---- row slacks / multipliers: t = max(-h, 1e-2), z = 1 ----
     {
             for (int k = N - 1; k >= 1; k--) {
-            if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
+            if (lane < NZ) (lds + O_zeta)[lane] = ws.zeta[k * ZPAD + lane];
             BMPC_SYNC();
-            stage_eval(A, L, dc, k, lane, false, iw0);
+            stage_eval(I, lds, dc, k, lane, false, iw0);
             for (int s = lane; s < NSLOT; s += BMPC_NT) {
                 Row r;
-                row_eval(A, L, b, k, s, r);
+                row_eval(I, lds, k, s, r);
                 ws.t[k * NSLOT + s] = r.kind ? fmax(-r.h, 1e-2) : 1.0;
                 ws.z[k * NSLOT + s] = r.kind ? 1.0 : 0.0;
                 ws.dzr[k * NSLOT + s] = 0.0;
@@ -824,7 +829,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
     double err_prev = 1e300;
     for (it = 0;; it++) {
         int hess_mode = (o.hess == 2 && err_prev < o.hess_switch) ? 1 : 0;
-        bool ok = backward_sweep(A, L, ws, dc, b, lane, ad_pend, iw0, reg, hreg, hess_mode, kk);
+        bool ok = backward_sweep(I, lds, ws, dc, lane, ad_pend, iw0, reg, hreg, hess_mode, kk);
         ad_pend = 0.0;
         if (kk.err <= o.tol && kk.dual <= 1.0 && kk.prim <= 1e-4 && kk.compl_ <= 1e-4) { st = 0; break; }
         if (it >= o.max_iter) { st = 1; break; }
@@ -840,14 +845,14 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
         int tries = 0;
         StepInfo si;
         for (;;) {
-            if (ok) { BMPC_PROF_START(); forward_sweep(A, L, ws, dc, b, lane, mu, iw0, si); ok = si.ok; BMPC_PROF(12); }
+            if (ok) { BMPC_PROF_START(); forward_sweep(I, lds, ws, dc, lane, mu, iw0, si); ok = si.ok; BMPC_PROF(12); }
             if (ok) break;
             if (hess_mode) { hess_mode = 0; ++tries; }        // second-order terms not convex here: Gauss-Newton
             else {
                 hreg = (hreg == 0.0) ? 1e-4 : hreg * 8;       // inertia correction (IPOPT delta_w)
                 if (++tries > 12) { st = 3; break; }
             }
-            ok = backward_sweep(A, L, ws, dc, b, lane, 0.0, iw0, reg, hreg, hess_mode, kk);
+            ok = backward_sweep(I, lds, ws, dc, lane, 0.0, iw0, reg, hreg, hess_mode, kk);
         }
         if (st == 3) break;
         if (tries == 0) hreg = (hreg < 1e-8) ? 0.0 : hreg / 3;
@@ -860,7 +865,7 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
         bool armijo_case = false;
         for (int bt = 0; bt < 10; bt++) {
             double f1, th1, ls1;
-            BMPC_PROF_START(); trial_sweep(A, L, ws, dc, b, lane, alpha, iw0, f1, th1, ls1); BMPC_PROF(13);
+            BMPC_PROF_START(); trial_sweep(I, lds, ws, dc, lane, alpha, iw0, f1, th1, ls1); BMPC_PROF(13);
             double phi1 = f1 - mu * ls1;
             bool acc = (th1 <= theta_max);
             for (int j = 0; acc && j < nfilt; j++)
@@ -896,42 +901,42 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
             x[34 * N + c * N] = lbx[34 * N + c * N];
         }
             for (int k = N - 1; k >= 1; k--) {
-            if (lane < NZ) L.zeta[lane] = ws.zeta[k * ZPAD + lane];
+            if (lane < NZ) (lds + O_zeta)[lane] = ws.zeta[k * ZPAD + lane];
             BMPC_SYNC();
-            stage_eval(A, L, dc, k, lane, false, iw0);
+            stage_eval(I, lds, dc, k, lane, false, iw0);
             if (lane < 28) {
                 int blk = lane / 7, j = lane - 7 * blk;
                 int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + j;
-                x[blk * 7 * N + j * N + k] = L.yz[pos];
+                x[blk * 7 * N + j * N + k] = (lds + O_yz)[pos];
             } else if (lane < 34) {
                 int c = lane - 28;
-                x[28 * N + c * N + k] = L.rc[RC_POSE + c];
-                x[34 * N + c * N + k] = L.rc[RC_V + c];
+                x[28 * N + c * N + k] = (lds + O_rc)[RC_POSE + c];
+                x[34 * N + c * N + k] = (lds + O_rc)[RC_V + c];
             } else if (lane == 34) {
-                x[40 * N + 6 + k] = L.yz[Z_RS]; x[41 * N + 6 + k] = L.yz[Z_DRS];
-                x[42 * N + 6 + k] = L.yz[Z_PS]; x[43 * N + 6 + k] = L.yz[Z_DPS];
-                if (k == 1) { x[40 * N + 6] = L.zeta[Z_RS]; x[42 * N + 6] = L.zeta[Z_PS]; }
+                x[40 * N + 6 + k] = (lds + O_yz)[Z_RS]; x[41 * N + 6 + k] = (lds + O_yz)[Z_DRS];
+                x[42 * N + 6 + k] = (lds + O_yz)[Z_PS]; x[43 * N + 6 + k] = (lds + O_yz)[Z_DPS];
+                if (k == 1) { x[40 * N + 6] = (lds + O_zeta)[Z_RS]; x[42 * N + 6] = (lds + O_zeta)[Z_PS]; }
             } else if (lane < 41 && k == N - 1) {
                 int i = lane - 35;
-                x[40 * N + i] = L.yz[Z_D + i];
+                x[40 * N + i] = (lds + O_yz)[Z_D + i];
             }
             // constraint violation as BoundMPC.py:613-615 (g rows only, 1e-6 dead band)
             for (int s = lane; s < NSLOT; s += BMPC_NT) {
                 if (s < S_EE) continue;
                 Row r;
-                row_eval(A, L, b, k, s, r);
+                row_eval(I, lds, k, s, r);
                 if (r.kind && r.h > 1e-6) viol_l += r.h;
             }
-            if (k < N - 1 && lane < NX) { double r = fabs(defect_row(L, dc, lane)); if (r > 1e-6 && lane < Z_D) viol_l += r; }
+            if (k < N - 1 && lane < NX) { double r = fabs(defect_row(lds, dc, lane)); if (r > 1e-6 && lane < Z_D) viol_l += r; }
             if (A.g) {
                 // constraint vector in the reference order (casadi_ocp_formulation.py:144-164, 304-380)
                 double* g = A.g + (size_t)b * (147 * (N - 1) + 21);
                 if (k < N - 1 && lane < 35) {
                     double v = 0.0;
-                    if (lane < 21) v = defect_row(L, dc, lane);
-                    else if (lane >= 24 && lane < 27) v = defect_row(L, dc, Z_PI + lane - 24);
-                    else if (lane == 33) v = defect_row(L, dc, Z_RS);
-                    else if (lane == 34) v = defect_row(L, dc, Z_PS);
+                    if (lane < 21) v = defect_row(lds, dc, lane);
+                    else if (lane >= 24 && lane < 27) v = defect_row(lds, dc, Z_PI + lane - 24);
+                    else if (lane == 33) v = defect_row(lds, dc, Z_RS);
+                    else if (lane == 34) v = defect_row(lds, dc, Z_PS);
                     g[35 * k + lane] = v;
                 }
                 double* gi = g + 35 * (N - 1) + 112 * (k - 1);
@@ -939,30 +944,30 @@ BMPC_DEV void solve_instance(const KernelArgs& A, const Lds& L, double* wsbase, 
                     if (s < S_EE) continue;
                     if (s >= S_TSET && k != N - 1) continue;
                     Row r;
-                    row_eval(A, L, b, k, s, r);
+                    row_eval(I, lds, k, s, r);
                     double v;
                     bool lower = (s >= S_ROTL && s < S_COL) || (s >= S_TROTL);
                     if (r.kind) v = lower ? -r.h : r.h;
-                    else if (s < S_ROTU) v = -sp_b(A.p + (size_t)b * NPAR, P_BSET, s - S_EE, 4, (int)L.rc[RC_SEG]) - L.yz[Z_PS];
-                    else if (s < S_PHI) { int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c; v = -L.sp[SP_BSETJ + rr * 6 + c] - L.rc[RC_SL + c]; }
-                    else v = -sp_b(A.p + (size_t)b * NPAR, P_BSET, s - S_TSET, 4, (int)L.rc[RC_SEG + 1]) - L.rc[RC_SL + 5];
+                    else if (s < S_ROTU) v = -sp_b(A.p + (size_t)b * NPAR, P_BSET, s - S_EE, 4, (int)(lds + O_rc)[RC_SEG]) - (lds + O_yz)[Z_PS];
+                    else if (s < S_PHI) { int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c; v = -(lds + O_sp)[SP_BSETJ + rr * 6 + c] - (lds + O_rc)[RC_SL + c]; }
+                    else v = -sp_b(A.p + (size_t)b * NPAR, P_BSET, s - S_TSET, 4, (int)(lds + O_rc)[RC_SEG + 1]) - (lds + O_rc)[RC_SL + 5];
                     gi[s - S_EE] = v;
                 }
             }
             BMPC_SYNC();
-            if (lane < NZ) L.znext[lane] = L.zeta[lane];
+            if (lane < NZ) (lds + O_znext)[lane] = (lds + O_zeta)[lane];
             BMPC_SYNC();
         }
-        if (lane < 24) { double r = fabs(L.x1fix[lane] - L.zeta[lane]); if (r > 1e-6) viol_l += r; }
+        if (lane < 24) { double r = fabs((lds + O_x1fix)[lane] - (lds + O_zeta)[lane]); if (r > 1e-6) viol_l += r; }
         if (A.g && lane < 35) {
             double* g = A.g + (size_t)b * (147 * (N - 1) + 21);
             double v = 0.0;
-            if (lane < 21) v = L.x1fix[lane] - L.zeta[lane];
-            else if (lane >= 24 && lane < 27) v = L.x1fix[Z_PI + lane - 24] - L.zeta[Z_PI + lane - 24];
+            if (lane < 21) v = (lds + O_x1fix)[lane] - (lds + O_zeta)[lane];
+            else if (lane >= 24 && lane < 27) v = (lds + O_x1fix)[Z_PI + lane - 24] - (lds + O_zeta)[Z_PI + lane - 24];
             g[lane] = v;
         }
     }
-    double viol = wg_sum(viol_l, L.red, lane);
+    double viol = wg_sum(viol_l, (lds + O_red), lane);
     if (lane == 0) {
         A.f[b] = kk.f;
         A.iters[b] = it;

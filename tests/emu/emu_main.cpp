@@ -16,6 +16,7 @@ static thread_local int t_lane = 0;
 #define BMPC_DEV
 #define BMPC_INL inline
 #define BMPC_HD inline
+#define BMPC_NOINL
 typedef double LDSD;
 #define BMPC_SYNC() g_bar->arrive_and_wait()
 #define BMPC_LANE() t_lane
@@ -49,14 +50,11 @@ extern "C" int emu_solve(int N, double dt, double tol, int max_iter, int hess, d
     int counter = 0;
     A.counter = &counter;
     A.prof = nullptr;
-    Lds L;
-    lds_carve(lds.data(), L);
-    if (L.misc + 64 - lds.data() > LDS_DOUBLES) { fprintf(stderr, "LDS carve overflow %ld > %d\n", (long)(L.misc + 64 - lds.data()), LDS_DOUBLES); return -2; }
     std::barrier<> bar(BMPC_NT);
     g_bar = &bar;
     std::vector<std::thread> th;
     for (int l = 0; l < BMPC_NT; l++)
-        th.emplace_back([&, l] { t_lane = l; solve_instance(A, L, A.ws, 0, l); });
+        th.emplace_back([&, l] { t_lane = l; solve_instance(A, lds.data(), A.ws, 0, l); });
     for (auto& t : th) t.join();
     return 0;
 }
