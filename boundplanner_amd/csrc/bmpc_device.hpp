@@ -79,7 +79,8 @@ struct Inst {            // per-instance arguments, passed by value (registers)
     double* prof;                   // diagnostic builds only
 };
 
-BMPC_HD int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32); }
+constexpr int WS_EVAL = 624;   // >= EVAL_DOUBLES, per-stage cache of the evaluation block
+BMPC_HD int ws_doubles(int N) { return N * (3 * ZPAD + 5 * NSLOT + NU * NX + 32 + WS_EVAL); }
 
 // ------------------------------------------------------------------------------------------
 // LDS carve-up (doubles)
@@ -90,8 +91,17 @@ constexpr int O_W = O_P + (NX * LDP);
 constexpr int O_sp = O_W + (NZ * LDW);
 constexpr int O_zeta = O_sp + (NSP);
 constexpr int O_znext = O_zeta + (ZPAD);
+// ---- evaluation block (contiguous: cached per stage in the scratch slab, see EVAL_DOUBLES) ----
 constexpr int O_yz = O_znext + (ZPAD);
-constexpr int O_g0 = O_yz + (ZPAD);
+constexpr int O_J = O_yz + (ZPAD);
+constexpr int O_G = O_J + (42);
+constexpr int O_Jp = O_G + (42);
+constexpr int O_zax = O_Jp + (126);
+constexpr int O_pc = O_zax + (21);
+constexpr int O_rc = O_pc + (18);
+constexpr int O_kin = O_rc + (160);
+constexpr int EVAL_DOUBLES = ZPAD + 42 + 42 + 126 + 21 + 18 + 160 + 160;
+constexpr int O_g0 = O_kin + (160);
 constexpr int O_g1 = O_g0 + (ZPAD);
 constexpr int O_gz = O_g1 + (ZPAD);
 constexpr int O_lam = O_gz + (ZPAD);
@@ -100,12 +110,7 @@ constexpr int O_pv1 = O_pv0 + (NX);
 constexpr int O_vt0 = O_pv1 + (NX);
 constexpr int O_vt1 = O_vt0 + (NX);
 constexpr int O_rdef = O_vt1 + (NX);
-constexpr int O_J = O_rdef + (NX);
-constexpr int O_G = O_J + (42);
-constexpr int O_Jp = O_G + (42);
-constexpr int O_zax = O_Jp + (126);
-constexpr int O_pc = O_zax + (21);
-constexpr int O_Op = O_pc + (18);
+constexpr int O_Op = O_rdef + (NX);
 constexpr int O_Ov = O_Op + (102);
 constexpr int O_T1 = O_Ov + (102);
 constexpr int O_T2 = O_T1 + (102);
@@ -132,8 +137,7 @@ constexpr int O_bcz = O_bc1 + (6);
 constexpr int O_rowS = O_bcz + (6);
 constexpr int O_rowA = O_rowS + (4 * NSLOT);
 constexpr int O_rowSl = O_rowA + (NPOSE * 6);
-constexpr int O_rc = O_rowSl + (NPOSE);
-constexpr int O_kf = O_rc + (160);
+constexpr int O_kf = O_rowSl + (NPOSE);
 constexpr int O_red = O_kf + (32);
 constexpr int O_dx = O_red + (BMPC_NT);
 constexpr int O_dxn = O_dx + (NX);
@@ -142,8 +146,7 @@ constexpr int O_dpt = O_dloc + (16);
 constexpr int O_x1fix = O_dpt + (24);
 constexpr int O_r0 = O_x1fix + (24);
 constexpr int O_misc = O_r0 + (NX);
-constexpr int O_kin = O_misc + (64);
-constexpr int O_rob = O_kin + (160);
+constexpr int O_rob = O_misc + (64);
 constexpr int LDS_DOUBLES = O_rob + (96);
 constexpr int O_Kl = O_Op;
 constexpr int O_Y = O_rowA;
@@ -292,13 +295,17 @@ BMPC_INL double nat_from_zeta(const LDSD* z, int i, const DynC d) {
 // Returns the stage cost value (same on every lane).  Publishes to LDS: yz, kinematics (J, G, Jp,
 // zax, pc), the row context rc[], the output-space cost gradient kin[KN_G12..] and, when want_h,
 // the Gauss-Newton/convex cost Hessian blocks Hp/Hv plus the initial group gradients bp0/bpz/bp1/bv.
-BMPC_NOINL double stage_eval(const Inst I, LDSD* lds, const DynC dc, int k, int lane, bool want_h,
+BMPC_NOINL double stage_eval(const Inst I, LDSD* lds, const DynC dc, int k, int lane, int mode,
                            const double* iw0) {
+    // mode 1: evaluate the point (everything but the Hessian blocks); mode 2: Hessian blocks only, the
+    // evaluation block [O_yz, O_yz + EVAL_DOUBLES) having been loaded from the cache; mode 3: both
+    const bool want_h = (mode & 2) != 0;
     const int N = I.N;
     const LDSD* sp = (lds + O_sp);
     LDSD* rc = (lds + O_rc);
     LDSD* kn = (lds + O_kin);
     const bool term = (k == N - 1);
+    if (mode & 1) {
     // ---- E0: natural variables, sin/cos ----
     if (lane < NZ) (lds + O_yz)[lane] = nat_from_zeta((lds + O_zeta), lane, dc);
     if (lane < 7) { double q = nat_from_zeta((lds + O_zeta), lane, dc); kn[KN_CS + lane] = cos(q); kn[KN_CS + 7 + lane] = sin(q); }
@@ -396,13 +403,15 @@ BMPC_NOINL double stage_eval(const Inst I, LDSD* lds, const DynC dc, int k, int 
         if (a >= 3) rc[RC_PROT + a - 3] = v;
     }
     BMPC_SYNC();
+    }
     // ---- E5: reference / error scalars (bound_mpc_functions.py:85-390), every lane ----
     int s = 0;
     if ((double)k > sp[P_SPLIT + 1]) s = 1;
     if ((double)k > sp[P_SPLIT + 2]) s = 2;
     const int n = (sp[P_SPLIT + 1] == (double)N) ? 1 : ((sp[P_SPLIT + 2] == (double)N) ? 2 : 3);
-    double fv;
-    {
+    double fv = 0.0;
+    if (!(mode & 1)) fv = rc[RC_FVAL];
+    if (mode & 1) {
         const bool iw_param = ((double)k <= sp[P_SPLIT + 1]);
         double dpp[3], dpr[3], d[3], tmp[3], delta[3], er[3], ep[3], jrdpr[3], vv[6];
         for (int a = 0; a < 3; a++) { dpp[a] = TABP(P_DPREF, s, a); dpr[a] = TABP(P_DPREF, s, 3 + a); d[a] = rc[RC_POSE + a] - TABP(P_PREF, s, a); }

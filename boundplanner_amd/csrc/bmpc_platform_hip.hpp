@@ -15,4 +15,8 @@
 // doubles that live in LDS: address-space-qualified so that every access is a ds_* instruction
 // (generic pointers to __shared__ memory compile to flat_* loads through the vector-memory path)
 typedef __attribute__((address_space(3))) double LDSD;
+#ifdef BMPC_NO_NOINLINE
+#define BMPC_NOINL __device__
+#else
 #define BMPC_NOINL __device__ __attribute__((noinline))
+#endif
