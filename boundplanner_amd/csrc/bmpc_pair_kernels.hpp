@@ -1,0 +1,942 @@
+// bmpc_pair_kernels.hpp -- the thread-per-(instance, stage) kernels of the pipeline:
+//   k_init   initial iterate from x0 (BoundMPC.py:412-416 warm/cold start vector), row slacks
+//   k_eval   accept the trial point, evaluate it, assemble the stage record for the Riccati sweep
+//   k_step   row steps of the Newton direction, fraction-to-boundary partials, merit derivative
+//   k_trial  line-search trial point: barrier objective pieces
+//   k_out    solution in the reference layout (casadi_ocp_formulation.py:89-101), g, violation
+// Bodies are plain functions of (args, wave, lane, lds) so that tests/emu can run them on the host.
+#pragma once
+#include "bmpc_pipeline.hpp"
+
+namespace bmpc {
+
+BMPC_INL constexpr int sym7(int i, int j) { return i <= j ? (i * 7 - i * (i - 1) / 2 + (j - i)) : (j * 7 - j * (j - 1) / 2 + (i - j)); }
+BMPC_INL constexpr int sym3(int i, int j) { return i <= j ? (i * 3 - i * (i - 1) / 2 + (j - i)) : (j * 3 - j * (j - 1) / 2 + (i - j)); }
+
+// everything the pair kernels need about one stage point
+struct StagePoint {
+    double zeta[NZ], y[NZ];
+    KinT K;
+    double Jl[3][7];
+    SegCtx C;
+};
+
+BMPC_INL void load_zeta(const double* arr, size_t NP, size_t pi, double* z) {
+    BMPC_UNROLL
+    for (int i = 0; i < NZ; i++) z[i] = arr[(size_t)i * NP + pi];
+}
+
+// kinematics + context at zeta (values only; Jacobian G computed by the caller when needed)
+BMPC_INL void stage_point(const PipeArgs& A, const double* pg, const double* iw0, int k, const DynC dc, StagePoint& S) {
+    nat_all(S.zeta, dc, S.y);
+    kin_chain(A.rc, S.y + Z_Q, S.K);
+    kin_jlin(S.K, S.Jl);
+    kin_vel(S.K, S.Jl, S.y + Z_DQ, S.C.v);
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) { S.C.pose[a] = S.K.pee[a]; S.C.pose[3 + a] = S.y[Z_PI + a] + 0.5 * dc.dt * S.C.v[3 + a]; }
+    seg_ctx_eval(pg, A.N, k, S.y, iw0, S.C);
+}
+
+// dynamics defect of stage k given zeta_{k+1}[0..31]
+BMPC_INL void defect_all(const double* z, const double* zn, const double* vang, const DynC d, double* r) {
+    BMPC_UNROLL
+    for (int i = 0; i < 7; i++) {
+        r[Z_Q + i] = z[Z_Q + i] + d.dt * z[Z_DQ + i] + 0.5 * d.dt * d.dt * z[Z_DDQ + i] + d.b3 * z[Z_U + i] - zn[Z_Q + i];
+        r[Z_DQ + i] = z[Z_DQ + i] + d.dt * z[Z_DDQ + i] + d.b2 * z[Z_U + i] - zn[Z_DQ + i];
+        r[Z_DDQ + i] = z[Z_DDQ + i] + d.b1 * z[Z_U + i] - zn[Z_DDQ + i];
+    }
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) r[Z_PI + a] = z[Z_PI + a] + d.dt * vang[a] - zn[Z_PI + a];
+    r[Z_RS] = z[Z_RS] + d.dt * z[Z_DRS] - zn[Z_RS];
+    r[Z_PS] = z[Z_PS] + d.dt * z[Z_DPS] - zn[Z_PS];
+    BMPC_UNROLL
+    for (int i = 0; i < 6; i++) r[Z_D + i] = z[Z_D + i] - zn[Z_D + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_init
+// ------------------------------------------------------------------------------------------
+struct InitVisitor {
+    const PipeArgs* A; size_t pi; bool valid;
+    BMPC_INL void set(int s, double h) {
+        if (!valid) return;
+        size_t o = (size_t)s * A->NP + pi;
+        A->t_t[o] = fmax(-h, 1e-2); A->z[o] = 1.0; A->dzr[o] = 0.0;
+    }
+    BMPC_INL void skip(int s) {
+        if (!valid) return;
+        size_t o = (size_t)s * A->NP + pi;
+        A->t_t[o] = 1.0; A->z[o] = 0.0; A->dzr[o] = 0.0;
+    }
+    BMPC_INL void diag(int s, int, double, double h) { set(s, h); }
+    BMPC_INL void zdiag(int s, int, double, double h) { set(s, h); }
+    BMPC_INL void pose(int s, const double*, int, double h) { set(s, h); }
+    template <int C> BMPC_INL void point_begin() {}
+    template <int C> BMPC_INL void point(int s, const double*, double h) { set(s, h); }
+    template <int C> BMPC_INL void point_end() {}
+};
+
+BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane) {
+    const int count = A.B, N = A.N;
+    if (wave * (64 / (N - 1)) >= count) return;
+    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    const int k = m.k, n_w = 44 * N + 6;
+    const DynC dc = make_dync(A.o.dt);
+    const double* x0 = A.x0 + (size_t)m.b * n_w;
+    const double* lbx = A.lbx + (size_t)m.b * n_w;
+    const double* ubx = A.ubx + (size_t)m.b * n_w;
+    const double* pg = A.p + (size_t)m.b * NPAR;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    StagePoint S;
+    BMPC_UNROLL
+    for (int j = 0; j < 7; j++) {
+        double uu = x0[21 * N + j * N + k];
+        S.zeta[Z_Q + j] = x0[j * N + k] - dc.c3 * uu;
+        S.zeta[Z_DQ + j] = x0[7 * N + j * N + k] - dc.c2 * uu;
+        S.zeta[Z_DDQ + j] = x0[14 * N + j * N + k] - dc.c1 * uu;
+        S.zeta[Z_U + j] = uu;
+    }
+    double prot[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) { prot[c] = x0[28 * N + (3 + c) * N + k]; S.zeta[Z_PI + c] = prot[c]; }
+    {
+        double rs = x0[40 * N + 6 + k], drs = x0[41 * N + 6 + k], ps = x0[42 * N + 6 + k], dps = x0[43 * N + 6 + k];
+        S.zeta[Z_RS] = rs - dc.dt / 2 * drs; S.zeta[Z_PS] = ps - dc.dt / 2 * dps;
+        S.zeta[Z_DRS] = drs; S.zeta[Z_DPS] = dps;
+    }
+    BMPC_UNROLL
+    for (int i = 0; i < 6; i++) S.zeta[Z_D + i] = x0[40 * N + i];
+    // pi_k = p_rot_k - dt/2 w(q_k, dq_k)
+    nat_all(S.zeta, dc, S.y);
+    kin_chain(A.rc, S.y + Z_Q, S.K);
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) {
+        double w = 0;
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) w += S.K.zx[j][a] * S.y[Z_DQ + j];
+        S.zeta[Z_PI + a] = prot[a] - dc.dt / 2 * w;
+    }
+    stage_point(A, pg, iw0, k, dc, S);
+    if (m.valid)
+        BMPC_UNROLL
+        for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
+    InitVisitor v{&A, m.pi, m.valid};
+    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, v);
+    if (m.valid)
+        for (int s = S_END; s < NSLOT; s++) v.skip(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_eval
+// ------------------------------------------------------------------------------------------
+struct RowAcc {   // row data access (accepting the trial values) + KKT partial sums
+    const PipeArgs* A; size_t pi; bool valid; double ad;
+    double cmax, csum, cmin, zsum, prim, theta, logs, nrows;
+    BMPC_INL void init(const PipeArgs* A_, size_t pi_, bool valid_, double ad_) {
+        A = A_; pi = pi_; valid = valid_; ad = ad_;
+        cmax = 0; csum = 0; cmin = 1e300; zsum = 0; prim = 0; theta = 0; logs = 0; nrows = 0;
+    }
+    BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
+        size_t o = (size_t)s * A->NP + pi;
+        double t = A->t_t[o];
+        zz = A->z[o];
+        if (ad != 0.0) zz += ad * A->dzr[o];
+        if (valid) { A->t[o] = t; A->z[o] = zz; }
+        sg = zz / t; r0 = sg * (h + t); r1 = 1.0 / t;
+        double c = t * zz;
+        cmax = fmax(cmax, c); csum += c; cmin = fmin(cmin, c); zsum += zz;
+        prim = fmax(prim, fabs(h + t)); theta += fabs(h + t); logs += log(t);
+        nrows += 1.0;
+    }
+};
+
+struct PointAsm {
+    RowAcc* R; const KinT* K; Emitter* E;
+    double M3[6], mc[3], sc, b30[3], b31[3], b3z[3], bc0, bc1, bcz;
+    double Hqq[28], gq0[7], gq1[7], gqz[7], dD[6], gD0[6], gD1[6], gDz[6], cd5[7], Fc[6][3];
+    BMPC_INL void init() {
+        BMPC_UNROLL
+        for (int i = 0; i < 28; i++) Hqq[i] = 0;
+        BMPC_UNROLL
+        for (int i = 0; i < 7; i++) { gq0[i] = 0; gq1[i] = 0; gqz[i] = 0; }
+    }
+    BMPC_INL void skip(int) {}
+    template <int C> BMPC_INL void point_begin() {
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) M3[i] = 0;
+        BMPC_UNROLL
+        for (int i = 0; i < 3; i++) { mc[i] = 0; b30[i] = 0; b31[i] = 0; b3z[i] = 0; }
+        sc = 0; bc0 = 0; bc1 = 0; bcz = 0;
+    }
+    template <int C> BMPC_INL void point(int s, const double* a, double h) {
+        double sg, r0, r1, zz;
+        R->row(s, h, sg, r0, r1, zz);
+        BMPC_UNROLL
+        for (int i = 0; i < 3; i++) {
+            BMPC_UNROLL
+            for (int j = i; j < 3; j++) M3[sym3(i, j)] += sg * a[i] * a[j];
+            mc[i] -= sg * a[i]; b30[i] += r0 * a[i]; b31[i] += r1 * a[i]; b3z[i] += zz * a[i];
+        }
+        sc += sg; bc0 -= r0; bc1 -= r1; bcz -= zz;
+    }
+    template <int C> BMPC_INL void point_end() {
+        constexpr int nj = PointNJ<C>::value;
+        const double* pc = kin_point<C>(*K);
+        double Jp[nj][3], T[nj][3];
+        BMPC_UNROLL
+        for (int i = 0; i < nj; i++) {
+            double r[3] = {pc[0] - K->o[i][0], pc[1] - K->o[i][1], pc[2] - K->o[i][2]};
+            cross3r(K->zx[i], r, Jp[i]);
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) T[i][a] = M3[sym3(a, 0)] * Jp[i][0] + M3[sym3(a, 1)] * Jp[i][1] + M3[sym3(a, 2)] * Jp[i][2];
+        }
+        BMPC_UNROLL
+        for (int i = 0; i < nj; i++) {
+            BMPC_UNROLL
+            for (int j = i; j < nj; j++) Hqq[sym7(i, j)] += Jp[i][0] * T[j][0] + Jp[i][1] * T[j][1] + Jp[i][2] * T[j][2];
+            gq0[i] += Jp[i][0] * b30[0] + Jp[i][1] * b30[1] + Jp[i][2] * b30[2];
+            gq1[i] += Jp[i][0] * b31[0] + Jp[i][1] * b31[1] + Jp[i][2] * b31[2];
+            gqz[i] += Jp[i][0] * b3z[0] + Jp[i][1] * b3z[1] + Jp[i][2] * b3z[2];
+        }
+        BMPC_UNROLL
+        for (int i = 0; i < 7; i++) {
+            double v = (i < nj) ? (Jp[i < nj ? i : 0][0] * mc[0] + Jp[i < nj ? i : 0][1] * mc[1] + Jp[i < nj ? i : 0][2] * mc[2]) : 0.0;
+            if (C < 5) E->put(v); else cd5[i] = v;
+        }
+        dD[C] = sc; gD0[C] = bc0; gD1[C] = bc1; gDz[C] = bcz;
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) Fc[C][a] = b3z[a];
+    }
+};
+
+struct PoseAsm {
+    RowAcc* R;
+    double M6[21], mS[3][6], sS[3], bp0[6], bp1[6], bpz[6], bS0[3], bS1[3], bSz[3];
+    BMPC_INL void init(const double* Hp, const double* g12) {
+        BMPC_UNROLL
+        for (int i = 0; i < 21; i++) M6[i] = Hp[i];
+        BMPC_UNROLL
+        for (int s = 0; s < 3; s++) {
+            sS[s] = 0; bS0[s] = 0; bS1[s] = 0; bSz[s] = 0;
+            BMPC_UNROLL
+            for (int i = 0; i < 6; i++) mS[s][i] = 0;
+        }
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) { bp0[i] = g12[i]; bpz[i] = g12[i]; bp1[i] = 0; }
+    }
+    // NA = number of leading nonzero coefficients (3 for position-only rows)
+    template <int NA, int SEL> BMPC_INL void add(int s, const double* a, double h) {
+        double sg, r0, r1, zz;
+        R->row(s, h, sg, r0, r1, zz);
+        BMPC_UNROLL
+        for (int i = 0; i < NA; i++) {
+            BMPC_UNROLL
+            for (int j = i; j < NA; j++) M6[sym6(i, j)] += sg * a[i] * a[j];
+            bp0[i] += r0 * a[i]; bp1[i] += r1 * a[i]; bpz[i] += zz * a[i];
+            if (SEL > 0) mS[SEL > 0 ? SEL - 1 : 0][i] -= sg * a[i];
+        }
+        if (SEL > 0) { sS[SEL - 1] += sg; bS0[SEL - 1] -= r0; bS1[SEL - 1] -= r1; bSz[SEL - 1] -= zz; }
+    }
+};
+
+// pose rows of one stage in slot order, for any visitor exposing add<NA, SEL>(s, a, h)
+template <class V>
+BMPC_INL void walk_pose_rows(const double* pg, int N, int k, const double* y, const SegCtx& C, V& v) {
+    const bool term = (k == N - 1);
+    {
+        const double* a = pg + P_ASET + 45 * C.s;
+        BMPC_UNROLL
+        for (int rr = 0; rr < 15; rr++) {
+            double a3[3] = {a[rr], a[rr + 15], a[rr + 30]};
+            double bb = pg[P_BSET + rr * 4 + C.s];
+            if (!(a3[0] == 0 && a3[1] == 0 && a3[2] == 0 && bb > 0))
+                v.template add<3, 1>(S_EE + rr, a3, a3[0] * C.pose[0] + a3[1] * C.pose[1] + a3[2] * C.pose[2] - bb - y[Z_PS]);
+        }
+    }
+    BMPC_UNROLL
+    for (int m = 0; m < 3; m++) {
+        double al[6];
+        BMPC_UNROLL
+        for (int c = 0; c < 6; c++) al[c] = -C.gs[m][c];
+        v.template add<6, 2>(S_ROTU + m, C.gs[m], C.proj[m] - C.ub[m] - y[Z_RS]);
+        v.template add<6, 2>(S_ROTL + m, al, -(C.proj[m] - C.lb[m] + y[Z_RS]));
+    }
+    v.template add<3, 0>(S_PHI, C.dpp, C.phi - (C.phiend + 0.005));
+    if (term) {
+        const double* a = pg + P_ASET + 45 * C.n;
+        BMPC_UNROLL
+        for (int rr = 0; rr < 15; rr++) {
+            double an[3] = {a[rr], a[rr + 15], a[rr + 30]};
+            double bn = pg[P_BSET + rr * 4 + C.n];
+            if (!(an[0] == 0 && an[1] == 0 && an[2] == 0 && bn + pg[P_SLACKS0 + 5] > 0)) {
+                double a1 = dot3(an, C.bp1), a2 = dot3(an, C.bp2);
+                double bnew = bn - dot3(an, C.pend);
+                double a3[3];
+                BMPC_UNROLL
+                for (int c = 0; c < 3; c++) {
+                    double tt = 0;
+                    BMPC_UNROLL
+                    for (int a_ = 0; a_ < 3; a_++) tt += (a1 * C.bp1[a_] + a2 * C.bp2[a_]) * C.Dep[a_][c];
+                    a3[c] = tt;
+                }
+                v.template add<3, 3>(S_TSET + rr, a3, a1 * C.tz[0] + a2 * C.tz[1] - bnew - C.sl[5]);
+            }
+        }
+        BMPC_UNROLL
+        for (int m = 0; m < 3; m++) {
+            double al[6];
+            BMPC_UNROLL
+            for (int c = 0; c < 6; c++) al[c] = -C.gsn[m][c];
+            v.template add<6, 3>(S_TROTU + m, C.gsn[m], C.projn[m] - C.ubn[m] - C.sl[5]);
+            v.template add<6, 3>(S_TROTL + m, al, -(C.projn[m] - C.lbn[m] + C.sl[5]));
+        }
+    }
+}
+
+// natural-diagonal rows of DG position I (dg_pos order); calls v.diag(s, coef, h) per active row
+template <int I, class V>
+BMPC_INL void walk_diag_pos(const double* lbx, const double* ubx, int N, int k, const double* y, V& v) {
+    if constexpr (I < 28) {
+        constexpr int blk = I / 7, jj = I % 7;
+        constexpr int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + jj;
+        size_t wi = (size_t)blk * 7 * N + (size_t)jj * N + k;
+        double ub = ubx[wi], lb = lbx[wi];
+        if (ub < BIGB) v.diag(2 * I, 1.0, y[pos] - ub);
+        if (lb > -BIGB) v.diag(2 * I + 1, -1.0, lb - y[pos]);
+    } else if constexpr (I < 32) {
+        constexpr int pos = (I == 28 ? Z_RS : I == 29 ? Z_DRS : I == 30 ? Z_PS : Z_DPS);
+        constexpr int m = (I == 28 ? 0 : I == 29 ? 1 : I == 30 ? 2 : 3);
+        v.diag(S_NONNEG + m, -1.0, -y[pos]);
+    } else if constexpr (I < 38) {
+        if (k == 1) v.diag(S_D1 + (I - 32), -1.0, -y[Z_D + I - 32]);
+    }
+}
+
+struct DiagAsm {
+    RowAcc* R;
+    double D, g0, g1, gz;
+    BMPC_INL void begin() { D = 0; g0 = 0; g1 = 0; gz = 0; }
+    BMPC_INL void diag(int s, double coef, double h) {
+        double sg, r0, r1, zz;
+        R->row(s, h, sg, r0, r1, zz);
+        D += sg; g0 += coef * r0; g1 += coef * r1; gz += coef * zz;
+    }
+};
+
+// column j of Op = d(pose)/d(q, dq, pi) and Ov = d(v)/d(q, dq, pi)
+template <int J>
+BMPC_INL void chain_cols(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, double* cO, double* cV) {
+    if constexpr (J < 7) {
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) { cO[a] = Jl[a][J]; cO[3 + a] = hdt * G[3 + a][J]; cV[a] = G[a][J]; cV[3 + a] = G[3 + a][J]; }
+    } else if constexpr (J < 14) {
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) { cO[a] = 0; cO[3 + a] = hdt * K.zx[J - 7][a]; cV[a] = Jl[a][J - 7]; cV[3 + a] = K.zx[J - 7][a]; }
+    } else {
+        BMPC_UNROLL
+        for (int a = 0; a < 6; a++) { cO[a] = (a == 3 + (J - 14)) ? 1.0 : 0.0; cV[a] = 0; }
+    }
+}
+
+struct ChainOut { double g17[3][17]; };
+
+template <int J, int I>
+BMPC_INL void chain_rows(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* t1,
+                         const double* t2, const double* Hqq, Emitter& E) {
+    if constexpr (I <= J) {
+        double cO[6], cV[6];
+        chain_cols<I>(K, Jl, G, hdt, cO, cV);
+        double s = 0;
+        BMPC_UNROLL
+        for (int a = 0; a < 6; a++) s += cO[a] * t1[a] + cV[a] * t2[a];
+        if constexpr (J < 7) s += Hqq[sym7(I, J)];
+        E.put(s);
+        chain_rows<J, I + 1>(K, Jl, G, hdt, t1, t2, Hqq, E);
+    }
+}
+template <int J>
+BMPC_INL void chain_column(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* M6,
+                           const double* Hv, const double* Hqq, Emitter& E) {
+    double cO[6], cV[6], t1[6], t2[6];
+    chain_cols<J>(K, Jl, G, hdt, cO, cV);
+    BMPC_UNROLL
+    for (int a = 0; a < 6; a++) {
+        double s1 = 0, s2 = 0;
+        BMPC_UNROLL
+        for (int b = 0; b < 6; b++) { s1 += M6[sym6(a, b)] * cO[b]; s2 += Hv[sym6(a, b)] * cV[b]; }
+        t1[a] = s1; t2[a] = s2;
+    }
+    chain_rows<J, 0>(K, Jl, G, hdt, t1, t2, Hqq, E);
+}
+template <int J>
+BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* M6,
+                        const double* Hv, const double* Hqq, Emitter& E) {
+    if constexpr (J < 17) {
+        chain_column<J>(K, Jl, G, hdt, M6, Hv, Hqq, E);
+        chain_all<J + 1>(K, Jl, G, hdt, M6, Hv, Hqq, E);
+    }
+}
+// C3 and the chained gradients
+template <int I>
+BMPC_INL void chain_vecs(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const PoseAsm& P,
+                         const double* bv, const double* cd5, double c3[3][17], double g17[3][17]) {
+    if constexpr (I < 17) {
+        double cO[6], cV[6];
+        chain_cols<I>(K, Jl, G, hdt, cO, cV);
+        BMPC_UNROLL
+        for (int sl = 0; sl < 3; sl++) {
+            double s = 0;
+            BMPC_UNROLL
+            for (int a = 0; a < 6; a++) s += cO[a] * P.mS[sl][a];
+            if (sl == 2 && I < 7) s += cd5[I < 7 ? I : 0];
+            c3[sl][I] = s;
+        }
+        double v0 = 0, v1 = 0, vz = 0;
+        BMPC_UNROLL
+        for (int a = 0; a < 6; a++) {
+            v0 += cO[a] * P.bp0[a] + cV[a] * bv[a];
+            v1 += cO[a] * P.bp1[a];
+            vz += cO[a] * P.bpz[a] + cV[a] * bv[a];
+        }
+        g17[0][I] = v0; g17[1][I] = v1; g17[2][I] = vz;
+        chain_vecs<I + 1>(K, Jl, G, hdt, P, bv, cd5, c3, g17);
+    }
+}
+
+// second-order kinematic terms of the Lagrangian Hessian for generalised forces Fp (on p_ee),
+// Fv (on v; WITHOUT the multiplier of the pi dynamics, which k_ric adds), Fc (on the 6 points)
+BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double* dq, const double* Fp, const double* Fv,
+                             const double Fc[6][3], Emitter& E) {
+    const int njc[6] = {2, 3, 4, 5, 6, 4};
+    BMPC_UNROLL
+    for (int a = 0; a < 7; a++)
+        BMPC_UNROLL
+        for (int bq = 0; bq < 7; bq++) {
+            const int m = a < bq ? a : bq, M = a < bq ? bq : a;
+            double cM[3] = {Jl[0][M], Jl[1][M], Jl[2][M]}, zc[3];
+            cross3r(K.zx[m], cM, zc);
+            double acc = dot3(Fp, zc);
+            BMPC_UNROLL
+            for (int c = 0; c < 6; c++)
+                if (M < njc[c]) {
+                    const double* pc = (c < 5) ? K.o[c + 2] : K.pl4;
+                    double r[3] = {pc[0] - K.o[M][0], pc[1] - K.o[M][1], pc[2] - K.o[M][2]}, cc[3];
+                    cross3r(K.zx[M], r, cc);
+                    cross3r(K.zx[m], cc, zc);
+                    acc += dot3(Fc[c], zc);
+                }
+            BMPC_UNROLL
+            for (int j = 0; j < 7; j++) {
+                const int m1 = a < j ? a : j, M1 = a < j ? j : a;
+                double c1[3] = {Jl[0][M1], Jl[1][M1], Jl[2][M1]};
+                double t1[3] = {0, 0, 0}, t2[3], dzm[3], dcM[3];
+                if (bq < m1) { cross3r(K.zx[bq], K.zx[m1], dzm); cross3r(dzm, c1, t1); }
+                const int m2 = bq < M1 ? bq : M1, M2 = bq < M1 ? M1 : bq;
+                double c2[3] = {Jl[0][M2], Jl[1][M2], Jl[2][M2]};
+                cross3r(K.zx[m2], c2, dcM);
+                cross3r(K.zx[m1], dcM, t2);
+                double lin = Fv[0] * (t1[0] + t2[0]) + Fv[1] * (t1[1] + t2[1]) + Fv[2] * (t1[2] + t2[2]);
+                double ang = 0;
+                if (a < j) {
+                    double u1[3] = {0, 0, 0}, u2[3] = {0, 0, 0}, tmp[3];
+                    if (bq < a) { cross3r(K.zx[bq], K.zx[a], tmp); cross3r(tmp, K.zx[j], u1); }
+                    if (bq < j) { cross3r(K.zx[bq], K.zx[j], tmp); cross3r(K.zx[a], tmp, u2); }
+                    ang = Fv[3] * (u1[0] + u2[0]) + Fv[4] * (u1[1] + u2[1]) + Fv[5] * (u1[2] + u2[2]);
+                }
+                acc += dq[j] * (lin + ang);
+            }
+            E.put(acc);
+        }
+    BMPC_UNROLL
+    for (int i = 0; i < 7; i++)
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) {
+            const int m = i < j ? i : j, M = i < j ? j : i;
+            double cM[3] = {Jl[0][M], Jl[1][M], Jl[2][M]}, zc[3];
+            cross3r(K.zx[m], cM, zc);
+            double acc = dot3(Fv, zc);
+            if (i < j) { double zz[3]; cross3r(K.zx[i], K.zx[j], zz); acc += dot3(Fv + 3, zz); }
+            E.put(acc);
+        }
+}
+
+// DG entries: position I of the dg order
+template <int I>
+BMPC_INL void dg_emit_all(const PipeArgs& A, const double* pg, const double* lbx, const double* ubx, int k, bool term,
+                          const double* y, RowAcc& R, const PointAsm& PA, const PoseAsm& PO, const double g17[3][17],
+                          Emitter& E) {
+    if constexpr (I < 41) {
+        const double* wts = pg + P_W;
+        DiagAsm dgv;
+        dgv.R = &R;
+        dgv.begin();
+        walk_diag_pos<I>(lbx, ubx, A.N, k, y, dgv);
+        double D = dgv.D, g0 = dgv.g0, g1 = dgv.g1, gz = dgv.gz;
+        // chained parts
+        if constexpr (I < 7) { g0 += g17[0][I] + PA.gq0[I]; g1 += g17[1][I] + PA.gq1[I]; gz += g17[2][I] + PA.gqz[I]; }
+        else if constexpr (I < 14) { g0 += g17[0][I]; g1 += g17[1][I]; gz += g17[2][I]; }
+        else if constexpr (I >= 38) { g0 += g17[0][14 + I - 38]; g1 += g17[1][14 + I - 38]; gz += g17[2][14 + I - 38]; }
+        // slack columns of the pose rows (ps, rs, d5) and of the point rows (d_c)
+        if constexpr (I == 30) { D += PO.sS[0]; g0 += PO.bS0[0]; g1 += PO.bS1[0]; gz += PO.bSz[0]; }
+        if constexpr (I == 28) { D += PO.sS[1]; g0 += PO.bS0[1]; g1 += PO.bS1[1]; gz += PO.bSz[1]; }
+        if constexpr (I >= 32 && I < 38) {
+            constexpr int c = I - 32;
+            D += PA.dD[c]; g0 += PA.gD0[c]; g1 += PA.gD1[c]; gz += PA.gDz[c];
+            if constexpr (c == 5) { D += PO.sS[2]; g0 += PO.bS0[2]; g1 += PO.bS1[2]; gz += PO.bSz[2]; }
+        }
+        // direct quadratic cost terms (natural coordinates)
+        {
+            double w2 = 0, extra = 0;
+            bool has = false;
+            if constexpr (I >= 7 + 2 && I <= 7 + 4) { w2 = 2 * wts[6]; has = true; }
+            else if constexpr (I >= 21 && I < 28) { w2 = 2 * wts[7]; has = true; }
+            else if constexpr (I == 28 || I == 30) { w2 = 2 * wts[9]; has = true; }
+            else if constexpr (I == 29 || I == 31) { w2 = 2 * wts[10]; has = true; }
+            else if constexpr (I >= 32 && I < 38) {
+                constexpr int i = I - 32;
+                w2 = term ? (2 * wts[10] + (i != 4 ? 2 * wts[8] : 0.0)) : 0.0;
+                extra = (term && i != 4) ? 2 * wts[8] * pg[P_SLACKS0 + i] : 0.0;
+                has = true;
+            }
+            if (has) {
+                double val = w2 * y[dg_pos_c(I)] + extra;
+                D += w2; g0 += val; gz += val;
+            }
+        }
+        E.put(D); E.put(g0); E.put(g1); E.put(gz);
+        dg_emit_all<I + 1>(A, pg, lbx, ubx, k, term, y, R, PA, PO, g17, E);
+    }
+}
+
+// lds: EM_DOUBLES doubles per wave
+BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
+    const int count = A.L.cnt[0], N = A.N;
+    if (wave * (64 / (N - 1)) >= count) return;
+    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    const int k = m.k, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
+    const DynC dc = make_dync(A.o.dt);
+    const double* lbx = A.lbx + (size_t)m.b * n_w;
+    const double* ubx = A.ubx + (size_t)m.b * n_w;
+    const double* pg = A.p + (size_t)m.b * NPAR;
+    const double ad = A.st[m.b].ad;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    Emitter E;
+    E.init(lds, A.hrec, lane, m.pi, m.valid);
+    BMPC_SYNC();
+    StagePoint S;
+    load_zeta(A.zeta_t, A.NP, m.pi, S.zeta);
+    if (m.valid)
+        BMPC_UNROLL
+        for (int i = 0; i < NZ; i++) A.zeta[(size_t)i * A.NP + m.pi] = S.zeta[i];
+    stage_point(A, pg, iw0, k, dc, S);
+    double G[6][7];
+    kin_G(S.K, S.Jl, S.y + Z_DQ, G);
+    double g12[12], Hp[21], Hv[21];
+    cost_grad12(pg, S.C, term, g12);
+    cost_hess(pg, S.C, term, Hp, Hv);
+    RowAcc R;
+    R.init(&A, m.pi, m.valid, ad);
+    // ---- collision points -> q x q block, q x d columns ----
+    PointAsm PA;
+    PA.R = &R; PA.K = &S.K; PA.E = &E;
+    PA.init();
+    walk_points<PointAsm, 0>(pg, S.K, S.C, PA);
+    // ---- pose rows -> chained (q, dq, pi) block ----
+    PoseAsm PO;
+    PO.R = &R;
+    PO.init(Hp, g12);
+    walk_pose_rows(pg, N, k, S.y, S.C, PO);
+    const double hdt = 0.5 * dc.dt;
+    chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA.Hqq, E);
+    double c3[3][17], g17[3][17];
+    chain_vecs<0>(S.K, S.Jl, G, hdt, PO, g12 + 6, PA.cd5, c3, g17);
+    BMPC_UNROLL
+    for (int sl = 0; sl < 3; sl++)
+        BMPC_UNROLL
+        for (int i = 0; i < 17; i++) E.put(c3[sl][i]);
+    // ---- second-order kinematic terms ----
+    if (A.o.hess == 2) {
+        double Fv[6];
+        BMPC_UNROLL
+        for (int a = 0; a < 6; a++) Fv[a] = g12[6 + a] + (a >= 3 ? hdt * PO.bpz[a] : 0.0);
+        curvature_emit(S.K, S.Jl, S.y + Z_DQ, PO.bpz, Fv, PA.Fc, E);
+    } else {
+        for (int i = 0; i < 98; i++) E.put(0.0);
+    }
+    // ---- diagonal rows + gradients ----
+    dg_emit_all<0>(A, pg, lbx, ubx, k, term, S.y, R, PA, PO, g17, E);
+    // ---- zeta-diagonal rows (k == 1) ----
+    {
+        double sg2[2] = {0, 0}, r2[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        if (k == 1) {
+            BMPC_UNROLL
+            for (int i = 0; i < 2; i++) {
+                double sg, r0, r1, zz;
+                R.row(S_RS1 + i, -S.zeta[i ? Z_PS : Z_RS], sg, r0, r1, zz);
+                sg2[i] = sg; r2[0][i] = r0; r2[1][i] = r1; r2[2][i] = zz;
+            }
+        }
+        E.put(sg2[0]); E.put(sg2[1]);
+        BMPC_UNROLL
+        for (int v = 0; v < 3; v++) { E.put(r2[v][0]); E.put(r2[v][1]); }
+    }
+    // ---- dynamics linearisation data, defect ----
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++)
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) E.put(G[3 + a][j]);
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++)
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) E.put(S.K.zx[j][a]);
+    {
+        double sz[3] = {0, 0, 0}, sufz[7][3];
+        BMPC_UNROLL
+        for (int j = 6; j >= 0; j--)
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) { sz[a] += S.K.zx[j][a] * S.y[Z_DQ + j]; sufz[j][a] = sz[a]; }
+        // sufz[m] for m = 1..7 (sufz[7] = 0)
+        BMPC_UNROLL
+        for (int mm = 1; mm < 8; mm++)
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) E.put(mm < 7 ? sufz[mm < 7 ? mm : 0][a] : 0.0);
+    }
+    double prim = R.prim, theta = R.theta;
+    {
+        double rdef[NX];
+        if (!term) {
+            double zn[NX];
+            BMPC_UNROLL
+            for (int i = 0; i < NX; i++) zn[i] = A.zeta_t[(size_t)i * A.NP + m.pi + 1];
+            defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+            BMPC_UNROLL
+            for (int i = 0; i < NX; i++) { prim = fmax(prim, fabs(rdef[i])); theta += fabs(rdef[i]); }
+        } else {
+            BMPC_UNROLL
+            for (int i = 0; i < NX; i++) rdef[i] = 0;
+        }
+        BMPC_UNROLL
+        for (int i = 0; i < NX; i++) E.put(rdef[i]);
+    }
+    E.pad_to(HREC);
+    if (k == 1) {
+        double x1fix[24];
+        x1fix_eval(lbx, N, dc.dt, x1fix);
+        BMPC_UNROLL
+        for (int i = 0; i < 24; i++) { double r = fabs(x1fix[i] - S.zeta[i]); prim = fmax(prim, r); theta += r; }
+    }
+    if (m.valid) {
+        double* P = A.part + m.pi;
+        P[PT_CMAX * A.NP] = R.cmax; P[PT_CSUM * A.NP] = R.csum; P[PT_CMIN * A.NP] = R.cmin; P[PT_ZSUM * A.NP] = R.zsum;
+        P[PT_PRIM * A.NP] = prim; P[PT_THETA * A.NP] = theta; P[PT_LOGS * A.NP] = R.logs; P[PT_NROWS * A.NP] = R.nrows;
+        P[PT_FVAL * A.NP] = S.C.fv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_step: row steps for the Newton direction dz (forward_sweep of bmpc_solver.hpp, row part)
+// ------------------------------------------------------------------------------------------
+struct StepVisitor {
+    const PipeArgs* A; size_t pi; bool valid;
+    double mu, tau;
+    const double* dy;     // natural step
+    const double* dzt;    // zeta step
+    double dloc[6], dpt[6][3];
+    double ap, ad, dbar;
+    BMPC_INL void fin(int s, double h, double adot) {
+        size_t o = (size_t)s * A->NP + pi;
+        double t = A->t[o], z = A->z[o];
+        double dti = -(h + t) - adot;
+        double dzi = (mu - t * z - z * dti) / t;
+        if (valid) { A->dt[o] = dti; A->dzr[o] = dzi; }
+        if (dti < 0) ap = fmin(ap, -tau * t / dti);
+        if (dzi < 0) ad = fmin(ad, -tau * z / dzi);
+        dbar -= mu * dti / t;
+    }
+    BMPC_INL void skip(int) {}
+    BMPC_INL void diag(int s, int pos, double coef, double h) { fin(s, h, coef * dy[pos]); }
+    BMPC_INL void zdiag(int s, int pos, double coef, double h) { fin(s, h, coef * dzt[pos]); }
+    BMPC_INL void pose(int s, const double* a, int sel, double h) {
+        double adot = 0;
+        BMPC_UNROLL
+        for (int c = 0; c < 6; c++) adot += a[c] * dloc[c];
+        if (sel == 1) adot -= dy[Z_PS];
+        else if (sel == 2) adot -= dy[Z_RS];
+        else if (sel == 3) adot -= dy[Z_D + 5];
+        fin(s, h, adot);
+    }
+    template <int C> BMPC_INL void point_begin() {}
+    template <int C> BMPC_INL void point(int s, const double* a, double h) {
+        fin(s, h, a[0] * dpt[C][0] + a[1] * dpt[C][1] + a[2] * dpt[C][2] - dy[Z_D + C]);
+    }
+    template <int C> BMPC_INL void point_end() {}
+};
+
+template <int C>
+BMPC_INL void point_dirs(const KinT& K, const double* dyq, double dpt[6][3]) {
+    if constexpr (C < 6) {
+        constexpr int nj = PointNJ<C>::value;
+        const double* pc = kin_point<C>(K);
+        double s[3] = {0, 0, 0};
+        BMPC_UNROLL
+        for (int i = 0; i < nj; i++) {
+            double r[3] = {pc[0] - K.o[i][0], pc[1] - K.o[i][1], pc[2] - K.o[i][2]}, c[3];
+            cross3r(K.zx[i], r, c);
+            s[0] += c[0] * dyq[i]; s[1] += c[1] * dyq[i]; s[2] += c[2] * dyq[i];
+        }
+        dpt[C][0] = s[0]; dpt[C][1] = s[1]; dpt[C][2] = s[2];
+        point_dirs<C + 1>(K, dyq, dpt);
+    }
+}
+
+BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
+    const int count = A.L.cnt[1], N = A.N;
+    if (wave * (64 / (N - 1)) >= count) return;
+    PairMap m = pair_map(A, A.L.step, count, wave, lane);
+    const int k = m.k, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
+    const DynC dc = make_dync(A.o.dt);
+    const double* lbx = A.lbx + (size_t)m.b * n_w;
+    const double* ubx = A.ubx + (size_t)m.b * n_w;
+    const double* pg = A.p + (size_t)m.b * NPAR;
+    const double* wts = pg + P_W;
+    const double mu = A.st[m.b].mu;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    StagePoint S;
+    load_zeta(A.zeta, A.NP, m.pi, S.zeta);
+    stage_point(A, pg, iw0, k, dc, S);
+    double G[6][7], g12[12];
+    kin_G(S.K, S.Jl, S.y + Z_DQ, G);
+    cost_grad12(pg, S.C, term, g12);
+    double dzt[NZ], dy[NZ];
+    load_zeta(A.dz, A.NP, m.pi, dzt);
+    nat_all(dzt, dc, dy);
+    StepVisitor V;
+    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu);
+    V.dy = dy; V.dzt = dzt; V.ap = 1.0; V.ad = 1.0; V.dbar = 0.0;
+    double dv[6];
+    BMPC_UNROLL
+    for (int a = 0; a < 6; a++) {
+        double s = 0;
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) s += G[a][j] * dy[Z_Q + j] + (a < 3 ? S.Jl[a][j] : S.K.zx[j][a - 3]) * dy[Z_DQ + j];
+        dv[a] = s;
+    }
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) {
+        double s = 0;
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) s += S.Jl[a][j] * dy[Z_Q + j];
+        V.dloc[a] = s;
+        V.dloc[3 + a] = dy[Z_PI + a] + 0.5 * dc.dt * dv[3 + a];
+    }
+    point_dirs<0>(S.K, dy + Z_Q, V.dpt);
+    // directional derivative of f
+    double dphi_f = 0;
+    BMPC_UNROLL
+    for (int a = 0; a < 6; a++) dphi_f += g12[a] * V.dloc[a] + g12[6 + a] * dv[a];
+    BMPC_UNROLL
+    for (int j = 2; j <= 4; j++) dphi_f += 2 * wts[6] * S.y[Z_DQ + j] * dy[Z_DQ + j];
+    BMPC_UNROLL
+    for (int j = 0; j < 7; j++) dphi_f += 2 * wts[7] * S.y[Z_U + j] * dy[Z_U + j];
+    dphi_f += 2 * wts[9] * S.y[Z_RS] * dy[Z_RS] + 2 * wts[10] * S.y[Z_DRS] * dy[Z_DRS] +
+              2 * wts[9] * S.y[Z_PS] * dy[Z_PS] + 2 * wts[10] * S.y[Z_DPS] * dy[Z_DPS];
+    if (term)
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) {
+            double gg = 2 * wts[10] * S.y[Z_D + i] + (i != 4 ? 2 * wts[8] * (pg[P_SLACKS0 + i] + S.y[Z_D + i]) : 0.0);
+            dphi_f += gg * dy[Z_D + i];
+        }
+    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    if (m.valid) {
+        double* P = A.part + m.pi;
+        P[PT_AP * A.NP] = V.ap; P[PT_AD * A.NP] = V.ad; P[PT_DBAR * A.NP] = V.dbar; P[PT_DPHIF * A.NP] = dphi_f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trial: zeta + alpha dz, t + alpha dt -> f, theta, sum log t
+// ------------------------------------------------------------------------------------------
+struct TrialVisitor {
+    const PipeArgs* A; size_t pi; bool valid; double alpha;
+    double th, ls;
+    BMPC_INL void fin(int s, double h) {
+        size_t o = (size_t)s * A->NP + pi;
+        double t = A->t[o] + alpha * A->dt[o];
+        if (valid) A->t_t[o] = t;
+        th += fabs(h + t); ls += log(t);
+    }
+    BMPC_INL void skip(int) {}
+    BMPC_INL void diag(int s, int, double, double h) { fin(s, h); }
+    BMPC_INL void zdiag(int s, int, double, double h) { fin(s, h); }
+    BMPC_INL void pose(int s, const double*, int, double h) { fin(s, h); }
+    template <int C> BMPC_INL void point_begin() {}
+    template <int C> BMPC_INL void point(int s, const double*, double h) { fin(s, h); }
+    template <int C> BMPC_INL void point_end() {}
+};
+
+BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
+    const int count = A.L.cnt[2], N = A.N;
+    if (wave * (64 / (N - 1)) >= count) return;
+    PairMap m = pair_map(A, A.L.trial, count, wave, lane);
+    const int k = m.k, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
+    const DynC dc = make_dync(A.o.dt);
+    const double* lbx = A.lbx + (size_t)m.b * n_w;
+    const double* ubx = A.ubx + (size_t)m.b * n_w;
+    const double* pg = A.p + (size_t)m.b * NPAR;
+    const double alpha = A.st[m.b].alpha;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    StagePoint S;
+    BMPC_UNROLL
+    for (int i = 0; i < NZ; i++) S.zeta[i] = A.zeta[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
+    if (m.valid)
+        BMPC_UNROLL
+        for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
+    stage_point(A, pg, iw0, k, dc, S);
+    TrialVisitor V;
+    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.th = 0; V.ls = 0;
+    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    double th = V.th;
+    if (!term) {
+        double zn[NX], rdef[NX];
+        BMPC_UNROLL
+        for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
+        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+        BMPC_UNROLL
+        for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
+    }
+    if (k == 1) {
+        double x1fix[24];
+        x1fix_eval(lbx, N, dc.dt, x1fix);
+        BMPC_UNROLL
+        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
+    }
+    if (m.valid) {
+        double* P = A.part + m.pi;
+        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th; P[PT_LS1 * A.NP] = V.ls;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_out: x in the reference layout, constraint vector g, violation partials
+// ------------------------------------------------------------------------------------------
+struct OutVisitor {
+    double viol;
+    double* gi;          // inequality rows of this stage in the reference order, or null
+    const double* pg; const SegCtx* C; const double* y; bool term;
+    BMPC_INL void rowv(int s, double h, bool lower) {
+        if (h > 1e-6) viol += h;
+        if (gi) gi[s - S_EE] = lower ? -h : h;
+    }
+    BMPC_INL void skip(int s) {
+        if (!gi || s < S_EE || s >= S_END || (s >= S_TSET && !term)) return;
+        double v;
+        if (s < S_ROTU) v = -pg[P_BSET + (s - S_EE) * 4 + C->s] - y[Z_PS];
+        else if (s < S_PHI) { int c = (s - S_COL) / 15, rr = (s - S_COL) - 15 * c; v = -pg[P_BSETJ + rr * 6 + c] - C->sl[c]; }
+        else v = -pg[P_BSET + (s - S_TSET) * 4 + C->n] - C->sl[5];
+        gi[s - S_EE] = v;
+    }
+    BMPC_INL void diag(int, int, double, double) {}     // box bounds are not part of g / viol
+    BMPC_INL void zdiag(int, int, double, double) {}
+    BMPC_INL void pose(int s, const double*, int, double h) { rowv(s, h, (s >= S_ROTL && s < S_COL) || (s >= S_TROTL)); }
+    template <int C_> BMPC_INL void point_begin() {}
+    template <int C_> BMPC_INL void point(int s, const double*, double h) { rowv(s, h, false); }
+    template <int C_> BMPC_INL void point_end() {}
+};
+
+BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane) {
+    const int count = A.B, N = A.N;
+    if (wave * (64 / (N - 1)) >= count) return;
+    // all instances, in order: list-free mapping
+    const int S_ = N - 1, ipw = 64 / S_;
+    int li = lane / S_, kk = lane - li * S_;
+    int b = wave * ipw + li;
+    if (li >= ipw || b >= count) return;
+    const int k = kk + 1, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
+    const size_t pi = pair_of(A, b, k);
+    const DynC dc = make_dync(A.o.dt);
+    const double* lbx = A.lbx + (size_t)b * n_w;
+    const double* ubx = A.ubx + (size_t)b * n_w;
+    const double* pg = A.p + (size_t)b * NPAR;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    StagePoint S;
+    load_zeta(A.zeta_t, A.NP, pi, S.zeta);     // the last evaluated point of the instance
+    stage_point(A, pg, iw0, k, dc, S);
+    double* x = A.x + (size_t)b * n_w;
+    BMPC_UNROLL
+    for (int j = 0; j < 7; j++) {
+        x[j * N + k] = S.y[Z_Q + j]; x[7 * N + j * N + k] = S.y[Z_DQ + j];
+        x[14 * N + j * N + k] = S.y[Z_DDQ + j]; x[21 * N + j * N + k] = S.y[Z_U + j];
+    }
+    BMPC_UNROLL
+    for (int c = 0; c < 6; c++) { x[28 * N + c * N + k] = S.C.pose[c]; x[34 * N + c * N + k] = S.C.v[c]; }
+    x[40 * N + 6 + k] = S.y[Z_RS]; x[41 * N + 6 + k] = S.y[Z_DRS];
+    x[42 * N + 6 + k] = S.y[Z_PS]; x[43 * N + 6 + k] = S.y[Z_DPS];
+    if (k == 1) {
+        // stage-0 column: the pins (lbx == ubx there), rs_0 / ps_0 from the eliminated stage-0 slacks
+        BMPC_UNROLL
+        for (int blk = 0; blk < 4; blk++)
+            BMPC_UNROLL
+            for (int j = 0; j < 7; j++) x[blk * 7 * N + j * N] = lbx[blk * 7 * N + j * N];
+        BMPC_UNROLL
+        for (int c = 0; c < 6; c++) { x[28 * N + c * N] = lbx[28 * N + c * N]; x[34 * N + c * N] = lbx[34 * N + c * N]; }
+        x[40 * N + 6] = S.zeta[Z_RS]; x[41 * N + 6] = 0.0; x[42 * N + 6] = S.zeta[Z_PS]; x[43 * N + 6] = 0.0;
+    }
+    if (term)
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) x[40 * N + i] = S.y[Z_D + i];
+    // violation as BoundMPC.py:613-615 (g rows only, 1e-6 dead band) and the g vector
+    double* g = A.g ? A.g + (size_t)b * (147 * (N - 1) + 21) : nullptr;
+    OutVisitor V;
+    V.viol = 0; V.gi = g ? g + 35 * (N - 1) + 112 * (k - 1) : nullptr; V.pg = pg; V.C = &S.C; V.y = S.y; V.term = term;
+    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    double rdef[NX];
+    if (!term) {
+        double zn[NX];
+        BMPC_UNROLL
+        for (int i = 0; i < NX; i++) zn[i] = A.zeta_t[(size_t)i * A.NP + pi + 1];
+        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+        BMPC_UNROLL
+        for (int i = 0; i < Z_D; i++) { double r = fabs(rdef[i]); if (r > 1e-6) V.viol += r; }
+        if (g) {
+            double* ge = g + 35 * k;
+            BMPC_UNROLL
+            for (int i = 0; i < 35; i++) ge[i] = 0.0;
+            BMPC_UNROLL
+            for (int i = 0; i < 21; i++) ge[i] = rdef[i];
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) ge[24 + a] = rdef[Z_PI + a];
+            ge[33] = rdef[Z_RS]; ge[34] = rdef[Z_PS];
+        }
+    }
+    if (k == 1) {
+        double x1fix[24];
+        x1fix_eval(lbx, N, dc.dt, x1fix);
+        BMPC_UNROLL
+        for (int i = 0; i < 24; i++) { double r = fabs(x1fix[i] - S.zeta[i]); if (r > 1e-6) V.viol += r; }
+        if (g) {
+            BMPC_UNROLL
+            for (int i = 0; i < 35; i++) g[i] = 0.0;
+            BMPC_UNROLL
+            for (int i = 0; i < 21; i++) g[i] = x1fix[i] - S.zeta[i];
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) g[24 + a] = x1fix[Z_PI + a] - S.zeta[Z_PI + a];
+        }
+    }
+    A.part[PT_F1 * A.NP + pi] = V.viol;      // reduced per instance by k_fin
+}
+
+}  // namespace bmpc

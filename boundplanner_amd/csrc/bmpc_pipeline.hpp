@@ -1,0 +1,148 @@
+// bmpc_pipeline.hpp -- batch-synchronous interior-point pipeline (device code, gfx950).
+//
+// The per-instance IP loop of bmpc_solver.hpp is split by parallelism:
+//   * everything that is independent per (instance, stage) pair -- kinematics, rows, Hessian
+//     assembly, row steps, line-search trial evaluation -- runs ONE THREAD PER PAIR
+//     (bmpc_stage.hpp), iterate and row data in SoA arrays [field][pair] so that consecutive
+//     lanes touch consecutive doubles (coalesced HBM access across the batch);
+//   * the only sequential part, the Riccati recursion over the horizon (banded KKT solve), runs
+//     ONE WAVEFRONT PER INSTANCE with the value-function Hessian P and the stage matrix W in LDS;
+//   * tiny per-instance control kernels (filter line search, barrier schedule) advance a state
+//     machine; work lists are compacted by atomic append, so finished instances cost nothing.
+// The algorithm (and every constant) is that of oracle/bmpc_solve.c; DESIGN.md documents the data
+// layout and the launch sequence.
+#pragma once
+#include "bmpc_stage.hpp"
+
+namespace bmpc {
+
+// ------------------------------------------------------------------------------------------
+// stage record written by k_eval (thread per pair), read by k_ric (wave per instance):
+// natural-coordinate Hessian pieces + gradients + dynamics linearisation, AoS [pair][HREC]
+// ------------------------------------------------------------------------------------------
+constexpr int F_CD = 0;                 // [c<5][i<7]    W[q_i][d_c]
+constexpr int F_H17 = F_CD + 35;        // columns j=0..16, rows i<=j   (q, dq, pi) block
+constexpr int F_C3 = F_H17 + 153;       // [sl<3][i<17]  W[pos17(i)][PS|RS|D5]
+constexpr int F_CQQ = F_C3 + 51;        // [a][b] second-order kinematic terms, q x q
+constexpr int F_CQD = F_CQQ + 49;       // [i][j] q_i x dq_j
+constexpr int F_DG = F_CQD + 49;        // [41 positions in DG order][D, g0, g1, gz]
+constexpr int F_DZ2 = F_DG + 164;       // zeta-diagonal rows (k == 1): sigma of rs~_1, ps~_1
+constexpr int F_GZ2 = F_DZ2 + 2;        // [r0, r1, zz][2]
+constexpr int F_EW = F_GZ2 + 6;         // G_ang[3][7], J_ang[3][7]
+constexpr int F_SUFZ = F_EW + 42;       // sufz[1..7][3] = sum_{j>=m} z_j dq_j
+constexpr int F_RDEF = F_SUFZ + 21;     // dynamics defect (32)
+constexpr int F_END = F_RDEF + 32;
+constexpr int HREC = 608;
+static_assert(F_END <= HREC && HREC % 16 == 0, "record layout");
+
+// DG order: q, dq, ddq, u, rs, drs, ps, dps, d, pi
+BMPC_HD int dg_pos(int i) {
+    if (i < 7) return Z_Q + i;
+    if (i < 14) return Z_DQ + i - 7;
+    if (i < 21) return Z_DDQ + i - 14;
+    if (i < 28) return Z_U + i - 21;
+    if (i == 28) return Z_RS;
+    if (i == 29) return Z_DRS;
+    if (i == 30) return Z_PS;
+    if (i == 31) return Z_DPS;
+    if (i < 38) return Z_D + i - 32;
+    return Z_PI + i - 38;
+}
+constexpr int dg_pos_c(int i) {
+    return i < 7 ? Z_Q + i : i < 14 ? Z_DQ + i - 7 : i < 21 ? Z_DDQ + i - 14 : i < 28 ? Z_U + i - 21 : i == 28 ? Z_RS
+           : i == 29 ? Z_DRS : i == 30 ? Z_PS : i == 31 ? Z_DPS : i < 38 ? Z_D + i - 32 : Z_PI + i - 38;
+}
+BMPC_HD int pos17(int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); }
+
+constexpr int KREC = 320;               // gains per pair: K (9x32) + kf (2x16)
+constexpr int NPART = 16;               // per-pair partial sums
+enum { PT_CMAX = 0, PT_CSUM, PT_CMIN, PT_ZSUM, PT_PRIM, PT_THETA, PT_LOGS, PT_NROWS, PT_FVAL,
+       PT_AP, PT_AD, PT_DBAR, PT_DPHIF, PT_F1, PT_TH1, PT_LS1 };
+
+enum { ST_EVAL = 0, ST_STEP = 1, ST_TRIAL = 2, ST_DONE = 3 };
+
+// per-instance solver state (AoS, one per instance)
+struct InstState {
+    int state, it, status, nfilt, hess_mode, bt, armijo, tries;
+    double mu, alpha, ad, ap, hreg, err_prev, filt_mu, theta_max, theta_min;
+    double f0, th0, ls0, D, phi0, fk;
+    double filt_th[8], filt_phi[8];
+};
+
+struct Lists {           // work lists (instance ids) with their counters
+    int *eval, *step, *trial, *eval_next, *trial_next;
+    int* cnt;            // [0] n_eval [1] n_step [2] n_trial [3] n_eval_next [4] n_trial_next [5] n_done
+};
+
+struct PipeArgs {
+    int B, N;
+    SolverOpts o;
+    const RobotConst* rc;
+    const double *x0, *lbx, *ubx, *p;
+    double *x, *f, *viol, *g;
+    int *iters, *status;
+    // workspace
+    size_t NP;                       // pair stride of the SoA arrays (>= B*(N-1))
+    double *zeta, *zeta_t, *dz;      // [41][NP]
+    double *t, *t_t, *z, *dt, *dzr;  // [NSLOT][NP]
+    double* hrec;                    // [pairs][HREC]
+    double* krec;                    // [pairs][KREC]
+    double* part;                    // [NPART][NP]
+    InstState* st;                   // [B]
+    Lists L;
+    const int* tbl;                  // scatter table of the stage record (3 ints per field)
+};
+
+BMPC_INL size_t pair_of(const PipeArgs& A, int b, int k) { return (size_t)b * (A.N - 1) + (k - 1); }
+
+// lanes -> pairs inside a wave: floor(64/(N-1)) instances per wave, lane = li*(N-1) + (k-1)
+struct PairMap { int b, k; bool valid; size_t pi; };
+BMPC_INL PairMap pair_map(const PipeArgs& A, const int* list, int count, int wave, int lane) {
+    const int S = A.N - 1, ipw = 64 / S;
+    int li = lane / S, kk = lane - li * S;
+    int e = wave * ipw + li;
+    PairMap m;
+    m.valid = (li < ipw) && (e < count);
+    if (!m.valid) { e = wave * ipw; kk = 0; }      // dummy work on a valid pair, no stores
+    m.b = list[e]; m.k = kk + 1;
+    m.pi = pair_of(A, m.b, m.k);
+    return m;
+}
+BMPC_INL int waves_for(int N, int count) { int ipw = 64 / (N - 1); return (count + ipw - 1) / ipw; }
+
+// ------------------------------------------------------------------------------------------
+// coalesced AoS output of per-thread records: 16 fields at a time through an LDS tile
+// ------------------------------------------------------------------------------------------
+constexpr int EM_LD = 66;                      // tile row stride (doubles): conflict-free both ways
+constexpr int EM_DOUBLES = 16 * EM_LD + 64;    // tile + per-lane record base (as double)
+struct Emitter {
+    LDSD* tile;        // [16][EM_LD]
+    double* out;       // record array base
+    int lane, f;
+    BMPC_INL void init(LDSD* lds, double* out_, int lane_, size_t pi, bool valid) {
+        tile = lds; out = out_; lane = lane_; f = 0;
+        // publish every lane's record base (exact in a double: < 2^53) for the transposed store;
+        // -1 = this lane must not store
+        lds[16 * EM_LD + lane] = valid ? (double)(pi * HREC) : -1.0;
+    }
+    BMPC_INL void put(double v) {
+        tile[(f & 15) * EM_LD + lane] = v;
+        f++;
+        if ((f & 15) == 0) flush();
+    }
+    BMPC_INL void flush() {
+        BMPC_SYNC();
+        const int ff = lane & 15, p0 = lane >> 4, c0 = f - 16;
+        BMPC_UNROLL
+        for (int i = 0; i < 16; i++) {
+            int pr = 4 * i + p0;
+            double base = tile[16 * EM_LD + pr];
+            double v = tile[ff * EM_LD + pr];
+            if (base >= 0.0) out[(size_t)base + c0 + ff] = v;
+        }
+        BMPC_SYNC();
+    }
+    BMPC_INL void pad_to(int n) { while (f < n) put(0.0); }
+};
+
+}  // namespace bmpc

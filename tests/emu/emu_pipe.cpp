@@ -1,0 +1,101 @@
+// CPU thread emulation of the batch-synchronous HIP pipeline -- TEST INFRASTRUCTURE ONLY.
+// Compiles the identical device source (bmpc_stage.hpp, bmpc_pair_kernels.hpp,
+// bmpc_ric_kernel.hpp) with 64 std::threads standing in for the 64 lanes of a wavefront and a
+// barrier for __syncthreads(); workgroups run one after the other.  Lets the kernel logic be
+// debugged against the oracle without a GPU.  Never shipped, never used by the product path.
+#include <barrier>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+static std::barrier<>* g_bar = nullptr;
+static thread_local int t_lane = 0;
+#define BMPC_DEV inline
+#define BMPC_INL inline
+#define BMPC_HD inline
+#define BMPC_NOINL
+typedef double LDSD;
+#define BMPC_SYNC() g_bar->arrive_and_wait()
+#define BMPC_LANE() t_lane
+#define BMPC_NT 64
+#define BMPC_BLOCK() 0
+#define BMPC_NBLOCKS() 1
+#define BMPC_ATOMIC_INC(ptr) __atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED)
+using std::fmax;
+using std::fmin;
+
+#include "../../boundplanner_amd/csrc/bmpc_pair_kernels.hpp"
+#include "../../boundplanner_amd/csrc/bmpc_ric_kernel.hpp"
+#include "../../boundplanner_amd/csrc/bmpc_robot.hpp"
+
+using namespace bmpc;
+
+template <class F> static void launch(int nblocks, F body) {
+    if (nblocks <= 0) return;
+    std::barrier<> bar(64);
+    g_bar = &bar;
+    std::vector<std::thread> th;
+    for (int l = 0; l < 64; l++)
+        th.emplace_back([&, l] {
+            t_lane = l;
+            for (int blk = 0; blk < nblocks; blk++) body(blk, l);
+        });
+    for (auto& t : th) t.join();
+}
+
+extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int hess, double hess_switch, double mu_init,
+                              double kappa_mu, double theta_mu, double kappa_eps, int B, const double* x0,
+                              const double* lbx, const double* ubx, const double* p, double* x, double* g, double* f,
+                              int* iters, int* status, double* viol, int verbose) {
+    RobotConst rc;
+    fill_robot_const(rc);
+    PipeArgs A;
+    A.B = B; A.N = N;
+    A.o = SolverOpts{N, dt, tol, max_iter, hess, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps};
+    A.rc = &rc;
+    A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.p = p;
+    A.x = x; A.f = f; A.viol = viol; A.g = g; A.iters = iters; A.status = status;
+    const size_t NP = ((size_t)B * (N - 1) + 63) / 64 * 64 + 64;
+    A.NP = NP;
+    std::vector<double> zeta(NZ * NP), zeta_t(NZ * NP), dz(NZ * NP), t(NSLOT * NP, 1.0), t_t(NSLOT * NP, 1.0),
+        z(NSLOT * NP), dtv(NSLOT * NP), dzr(NSLOT * NP), hrec(NP * HREC), krec(NP * KREC), part(NPART * NP);
+    std::vector<InstState> st(B);
+    std::vector<int> l_eval(B), l_step(B), l_trial(B), l_evn(B), l_trn(B), cnt(8, 0), tbl(3 * HREC);
+    build_scatter_table(tbl.data());
+    A.zeta = zeta.data(); A.zeta_t = zeta_t.data(); A.dz = dz.data();
+    A.t = t.data(); A.t_t = t_t.data(); A.z = z.data(); A.dt = dtv.data(); A.dzr = dzr.data();
+    A.hrec = hrec.data(); A.krec = krec.data(); A.part = part.data(); A.st = st.data();
+    A.L.eval = l_eval.data(); A.L.step = l_step.data(); A.L.trial = l_trial.data();
+    A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
+    A.tbl = tbl.data();
+    std::vector<double> lds(std::max(EM_DOUBLES, RIC_LDS_DOUBLES) + 64);
+    const int nb_inst = (B + 63) / 64, nw = waves_for(N, B);
+    cnt[0] = B;
+    launch(nb_inst, [&](int blk, int l) { k_init_inst_body(A, blk * 64 + l); });
+    launch(nw, [&](int blk, int l) { k_init_body(A, blk, l); });
+    int steps = 0;
+    for (; steps < 12 * (max_iter + 2); steps++) {
+        int nact = B - cnt[5];
+        if (nact <= 0) break;
+        if (verbose) printf("step %d: n_eval %d n_trial %d done %d\n", steps, cnt[0], cnt[2], cnt[5]);
+        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
+        launch(cnt[0], [&](int blk, int l) { k_ric_body(A, blk, l, lds.data()); });
+        launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l); });
+        launch((cnt[1] + 63) / 64, [&](int blk, int l) { k_ls0_body(A, blk * 64 + l); });
+        launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l); });
+        launch((cnt[2] + 63) / 64, [&](int blk, int l) { k_ls_body(A, blk * 64 + l); });
+        k_rotate_body(A);
+        std::swap(A.L.eval, A.L.eval_next);
+        std::swap(A.L.trial, A.L.trial_next);
+        if (verbose > 1)
+            for (int b = 0; b < B; b++)
+                printf("  inst %d: state %d it %d mu %.3e alpha %.3e err_prev %.3e hm %d hreg %.1e\n", b, st[b].state, st[b].it,
+                       st[b].mu, st[b].alpha, st[b].err_prev, st[b].hess_mode, st[b].hreg);
+    }
+    launch(nw, [&](int blk, int l) { k_out_body(A, blk, l); });
+    launch(nb_inst, [&](int blk, int l) { k_fin_body(A, blk * 64 + l); });
+    return steps;
+}
