@@ -2,7 +2,7 @@
 #include "bmpc_platform_hip.hpp"
 
 #define BMPC_NT 64
-#include "bmpc_device.hpp"
+#include "bmpc_pipeline.hpp"
 #include "bmpc_robot.hpp"
 
 #include <cstdio>
@@ -20,6 +20,12 @@ extern "C" hipError_t bmpc_launch_solve_nt256(const KernelArgs* A, int nblocks, 
 extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
                                      double* ee_rot, double* col_pts, double* jac, double* dvdq, hipStream_t st);
 
+extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_out(const PipeArgsH* A, hipStream_t st);
+extern "C" void bmpc_pipe_build_table(int* tbl);
+extern "C" size_t bmpc_pipe_state_bytes(void);
+
 struct bmpc_handle {
     bmpc_opts o;
     int n_w, n_g, n_cu, nblocks_max;
@@ -28,6 +34,14 @@ struct bmpc_handle {
     int* d_counter = nullptr;
     double* d_prof = nullptr;   // diagnostic builds only
     size_t ws_blocks = 0;
+    // pipeline engine workspace (grown on demand to the largest batch seen)
+    int pipe_cap = 0;
+    double* d_pipe = nullptr;      // one slab: SoA iterate/row arrays, stage records, gains, partials
+    void* d_pipe_st = nullptr;     // InstState[cap]
+    int* d_pipe_lists = nullptr;   // 5 lists of cap ints + 8 counters
+    int* d_pipe_tbl = nullptr;     // scatter table of the stage record
+    int* h_cnt = nullptr;          // pinned host copy of the counters
+    int last_steps = 0;
     // staging for the host-pointer entry
     double *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr, *d_x = nullptr, *d_g = nullptr,
            *d_f = nullptr, *d_viol = nullptr;
@@ -52,7 +66,7 @@ struct bmpc_handle {
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
     o->hess = 2; o->hess_switch = 0.1; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->max_batch = 0; o->blocks_per_cu = 0; o->waves_per_instance = 1;
+    o->max_batch = 0; o->blocks_per_cu = 0; o->waves_per_instance = 1; o->engine = 0;
 }
 
 extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
@@ -60,6 +74,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     *out = nullptr;
     if (o->N < 3 || o->N > 64 || o->nr_segs != 4 || !(o->dt > 0)) return 1;
     if (o->waves_per_instance != 1 && o->waves_per_instance != 2 && o->waves_per_instance != 4) return 1;
+    if (o->engine != 0 && o->engine != 1) return 1;
     bmpc_handle* h = new bmpc_handle();
     h->o = *o;
     h->n_w = 44 * o->N + 6;
@@ -79,10 +94,18 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     HIPCHK(h, hipMalloc((void**)&h->d_rc, sizeof(RobotConst)));
     HIPCHK(h, hipMemcpy(h->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
     h->ws_blocks = (size_t)h->nblocks_max;
-    HIPCHK(h, hipMalloc((void**)&h->d_ws, h->ws_blocks * (size_t)ws_doubles(o->N) * sizeof(double)));
+    if (o->engine == 1)
+        HIPCHK(h, hipMalloc((void**)&h->d_ws, h->ws_blocks * (size_t)ws_doubles(o->N) * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_counter, sizeof(int)));
     HIPCHK(h, hipMalloc((void**)&h->d_prof, (size_t)h->nblocks_max * 16 * sizeof(double)));
     HIPCHK(h, hipMemset(h->d_prof, 0, (size_t)h->nblocks_max * 16 * sizeof(double)));
+    {
+        std::vector<int> tbl(3 * HREC);
+        bmpc_pipe_build_table(tbl.data());
+        HIPCHK(h, hipMalloc((void**)&h->d_pipe_tbl, tbl.size() * sizeof(int)));
+        HIPCHK(h, hipMemcpy(h->d_pipe_tbl, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_cnt, 8 * sizeof(int)));
+    }
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -98,6 +121,11 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (h->d_rc) (void)hipFree(h->d_rc);
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_prof) (void)hipFree(h->d_prof);
+    if (h->d_pipe) (void)hipFree(h->d_pipe);
+    if (h->d_pipe_st) (void)hipFree(h->d_pipe_st);
+    if (h->d_pipe_lists) (void)hipFree(h->d_pipe_lists);
+    if (h->d_pipe_tbl) (void)hipFree(h->d_pipe_tbl);
+    if (h->h_cnt) (void)hipHostFree(h->h_cnt);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -128,9 +156,78 @@ extern "C" int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg) {
     return r == h->n_g ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// pipeline engine: workspace + launch sequence
+// ------------------------------------------------------------------------------------------
+static int pipe_ensure(bmpc_handle* h, int B) {
+    if (B <= h->pipe_cap) return 0;
+    int cap = B > h->o.max_batch ? B : h->o.max_batch;
+    if (h->d_pipe) { (void)hipFree(h->d_pipe); h->d_pipe = nullptr; }
+    if (h->d_pipe_st) { (void)hipFree(h->d_pipe_st); h->d_pipe_st = nullptr; }
+    if (h->d_pipe_lists) { (void)hipFree(h->d_pipe_lists); h->d_pipe_lists = nullptr; }
+    h->pipe_cap = 0;
+    const size_t NP = ((size_t)cap * (h->o.N - 1) + 63) / 64 * 64 + 64;
+    const size_t n = (3 * (size_t)NZ + 5 * (size_t)NSLOT + NPART + HREC + KREC) * NP;
+    HIPCHK(h, hipMalloc((void**)&h->d_pipe, n * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_pipe_st, (size_t)cap * bmpc_pipe_state_bytes()));
+    HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (5 * (size_t)cap + 8) * sizeof(int)));
+    h->pipe_cap = cap;
+    return 0;
+}
+
+static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
+                      const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
+                      double* d_viol, hipStream_t st) {
+    int rc = pipe_ensure(h, B);
+    if (rc) return rc;
+    const int N = h->o.N, cap = h->pipe_cap;
+    PipeArgsH A;
+    A.B = B; A.N = N;
+    A.o = SolverOpts{N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,
+                     h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps};
+    A.rc = h->d_rc;
+    A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
+    A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
+    const size_t NP = ((size_t)cap * (N - 1) + 63) / 64 * 64 + 64;
+    A.NP = NP;
+    double* w = h->d_pipe;
+    A.zeta = w; w += NZ * NP; A.zeta_t = w; w += NZ * NP; A.dz = w; w += NZ * NP;
+    A.t = w; w += NSLOT * NP; A.t_t = w; w += NSLOT * NP; A.z = w; w += NSLOT * NP; A.dt = w; w += NSLOT * NP;
+    A.dzr = w; w += NSLOT * NP;
+    A.part = w; w += NPART * NP;
+    A.hrec = w; w += HREC * NP; A.krec = w;
+    A.st = (InstState*)h->d_pipe_st;
+    int* L = h->d_pipe_lists;
+    A.L.eval = L; A.L.step = L + cap; A.L.trial = L + 2 * (size_t)cap; A.L.eval_next = L + 3 * (size_t)cap;
+    A.L.trial_next = L + 4 * (size_t)cap; A.L.cnt = L + 5 * (size_t)cap;
+    A.tbl = h->d_pipe_tbl;
+    A.prof = h->d_prof;
+    int cnt0[8] = {B, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(A.L.cnt, cnt0, sizeof cnt0, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    HIPCHK(h, bmpc_pipe_launch_init(&A, st));
+    // Every instance advances one stage of its own state machine per super-step; finished
+    // instances leave the work lists.  The host only needs the number still active to size the
+    // grids (an upper bound is enough) and to stop: read back every few super-steps.
+    int n_act = B, steps = 0;
+    const int max_steps = 12 * (h->o.max_iter + 2);
+    while (n_act > 0 && steps < max_steps) {
+        int burst = steps < 8 ? 8 : 4;
+        for (int i = 0; i < burst; i++, steps++) HIPCHK(h, bmpc_pipe_launch_step(&A, n_act, st));
+        HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        n_act = B - h->h_cnt[5];
+    }
+    h->last_steps = steps;
+    HIPCHK(h, bmpc_pipe_launch_out(&A, st));
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    return 0;
+}
+
 static int launch(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
                   const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
                   double* d_viol, hipStream_t st) {
+    if (h->o.engine == 0) return pipe_solve(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, st);
     KernelArgs A;
     A.B = B;
     A.o = SolverOpts{h->o.N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,

@@ -21,6 +21,10 @@
 
 namespace bmpc {
 
+#ifndef BMPC_AS1
+#define BMPC_AS1
+#endif
+
 constexpr int NX = 32, NU = 9, NZ = 41, LDW = 42, LDP = 33;
 constexpr int NSLOT = 208;      // inequality-row slots per stage
 constexpr int NPOSE = 43;       // rows living in pose space
@@ -60,6 +64,13 @@ struct RobotConst {           // iiwa14 chain constants (iiwa.urdf), rotations p
     double ee_rot[9];
     double l4c_xyz[3];
 };
+
+typedef BMPC_AS1 double* GD;               // pointers into global memory (device code of the pipeline)
+typedef BMPC_AS1 const double* GCD;
+typedef BMPC_AS1 int* GI;
+typedef BMPC_AS1 const int* GCI;
+
+typedef BMPC_AS1 const RobotConst* GRC;
 
 struct KernelArgs {
     int B;

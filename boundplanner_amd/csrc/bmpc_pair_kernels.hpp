@@ -21,13 +21,13 @@ struct StagePoint {
     SegCtx C;
 };
 
-BMPC_INL void load_zeta(const double* arr, size_t NP, size_t pi, double* z) {
+BMPC_INL void load_zeta(GCD arr, size_t NP, size_t pi, double* z) {
     BMPC_UNROLL
     for (int i = 0; i < NZ; i++) z[i] = arr[(size_t)i * NP + pi];
 }
 
 // kinematics + context at zeta (values only; Jacobian G computed by the caller when needed)
-BMPC_INL void stage_point(const PipeArgs& A, const double* pg, const double* iw0, int k, const DynC dc, StagePoint& S) {
+BMPC_INL void stage_point(const PipeArgs& A, GCD pg, const double* iw0, int k, const DynC dc, StagePoint& S) {
     nat_all(S.zeta, dc, S.y);
     kin_chain(A.rc, S.y + Z_Q, S.K);
     kin_jlin(S.K, S.Jl);
@@ -58,10 +58,13 @@ BMPC_INL void defect_all(const double* z, const double* zn, const double* vang, 
 // ------------------------------------------------------------------------------------------
 struct InitVisitor {
     const PipeArgs* A; size_t pi; bool valid;
+    double th, ls;
     BMPC_INL void set(int s, double h) {
+        double t = fmax(-h, 1e-2);
+        th += fabs(h + t); ls += log(t);
         if (!valid) return;
         size_t o = (size_t)s * A->NP + pi;
-        A->t_t[o] = fmax(-h, 1e-2); A->z[o] = 1.0; A->dzr[o] = 0.0;
+        A->t_t[o] = t; A->z[o] = 1.0; A->dzr[o] = 0.0;
     }
     BMPC_INL void skip(int s) {
         if (!valid) return;
@@ -82,10 +85,10 @@ BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane) {
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
     const int k = m.k, n_w = 44 * N + 6;
     const DynC dc = make_dync(A.o.dt);
-    const double* x0 = A.x0 + (size_t)m.b * n_w;
-    const double* lbx = A.lbx + (size_t)m.b * n_w;
-    const double* ubx = A.ubx + (size_t)m.b * n_w;
-    const double* pg = A.p + (size_t)m.b * NPAR;
+    GCD x0 = A.x0 + (size_t)m.b * n_w;
+    GCD lbx = A.lbx + (size_t)m.b * n_w;
+    GCD ubx = A.ubx + (size_t)m.b * n_w;
+    GCD pg = A.p + (size_t)m.b * NPAR;
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
@@ -122,10 +125,55 @@ BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane) {
     if (m.valid)
         BMPC_UNROLL
         for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
-    InitVisitor v{&A, m.pi, m.valid};
+    InitVisitor v{&A, m.pi, m.valid, 0.0, 0.0};
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, v);
     if (m.valid)
         for (int s = S_END; s < NSLOT; s++) v.skip(s);
+    // f, theta, sum log t of the initial point (later iterates get them from their accepted trial)
+    double th = v.th;
+    if (k < N - 1) {
+        // zeta_{k+1} is not available yet (written by another thread of this launch): rebuild its x part
+        double zn[NX];
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) {
+            double uu = x0[21 * N + j * N + k + 1];
+            zn[Z_Q + j] = x0[j * N + k + 1] - dc.c3 * uu;
+            zn[Z_DQ + j] = x0[7 * N + j * N + k + 1] - dc.c2 * uu;
+            zn[Z_DDQ + j] = x0[14 * N + j * N + k + 1] - dc.c1 * uu;
+        }
+        {
+            double yq[7], ydq[7];
+            BMPC_UNROLL
+            for (int j = 0; j < 7; j++) { double uu = x0[21 * N + j * N + k + 1]; yq[j] = zn[Z_Q + j] + dc.c3 * uu; ydq[j] = zn[Z_DQ + j] + dc.c2 * uu; }
+            KinT Kn;
+            kin_chain(A.rc, yq, Kn);
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) {
+                double w = 0;
+                BMPC_UNROLL
+                for (int j = 0; j < 7; j++) w += Kn.zx[j][a] * ydq[j];
+                zn[Z_PI + a] = x0[28 * N + (3 + a) * N + k + 1] - dc.dt / 2 * w;
+            }
+        }
+        zn[Z_RS] = x0[40 * N + 6 + k + 1] - dc.dt / 2 * x0[41 * N + 6 + k + 1];
+        zn[Z_PS] = x0[42 * N + 6 + k + 1] - dc.dt / 2 * x0[43 * N + 6 + k + 1];
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) zn[Z_D + i] = x0[40 * N + i];
+        double rdef[NX];
+        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+        BMPC_UNROLL
+        for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
+    }
+    if (k == 1) {
+        double x1fix[24];
+        x1fix_eval(lbx, N, dc.dt, x1fix);
+        BMPC_UNROLL
+        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
+    }
+    if (m.valid) {
+        GD P = A.part + m.pi;
+        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th; P[PT_LS1 * A.NP] = v.ls;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -133,10 +181,10 @@ BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane) {
 // ------------------------------------------------------------------------------------------
 struct RowAcc {   // row data access (accepting the trial values) + KKT partial sums
     const PipeArgs* A; size_t pi; bool valid; double ad;
-    double cmax, csum, cmin, zsum, prim, theta, logs, nrows;
+    double cmax, csum, cmin, zsum, prim, nrows;     // f, theta, sum log t of this point: k_trial / k_init
     BMPC_INL void init(const PipeArgs* A_, size_t pi_, bool valid_, double ad_) {
         A = A_; pi = pi_; valid = valid_; ad = ad_;
-        cmax = 0; csum = 0; cmin = 1e300; zsum = 0; prim = 0; theta = 0; logs = 0; nrows = 0;
+        cmax = 0; csum = 0; cmin = 1e300; zsum = 0; prim = 0; nrows = 0;
     }
     BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
         size_t o = (size_t)s * A->NP + pi;
@@ -144,10 +192,10 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
         zz = A->z[o];
         if (ad != 0.0) zz += ad * A->dzr[o];
         if (valid) { A->t[o] = t; A->z[o] = zz; }
-        sg = zz / t; r0 = sg * (h + t); r1 = 1.0 / t;
+        r1 = 1.0 / t; sg = zz * r1; r0 = sg * (h + t);
         double c = t * zz;
         cmax = fmax(cmax, c); csum += c; cmin = fmin(cmin, c); zsum += zz;
-        prim = fmax(prim, fabs(h + t)); theta += fabs(h + t); logs += log(t);
+        prim = fmax(prim, fabs(h + t));
         nrows += 1.0;
     }
 };
@@ -243,10 +291,10 @@ struct PoseAsm {
 
 // pose rows of one stage in slot order, for any visitor exposing add<NA, SEL>(s, a, h)
 template <class V>
-BMPC_INL void walk_pose_rows(const double* pg, int N, int k, const double* y, const SegCtx& C, V& v) {
+BMPC_INL void walk_pose_rows(GCD pg, int N, int k, const double* y, const SegCtx& C, V& v) {
     const bool term = (k == N - 1);
     {
-        const double* a = pg + P_ASET + 45 * C.s;
+        GCD a = pg + P_ASET + 45 * C.s;
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
             double a3[3] = {a[rr], a[rr + 15], a[rr + 30]};
@@ -265,7 +313,7 @@ BMPC_INL void walk_pose_rows(const double* pg, int N, int k, const double* y, co
     }
     v.template add<3, 0>(S_PHI, C.dpp, C.phi - (C.phiend + 0.005));
     if (term) {
-        const double* a = pg + P_ASET + 45 * C.n;
+        GCD a = pg + P_ASET + 45 * C.n;
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
             double an[3] = {a[rr], a[rr + 15], a[rr + 30]};
@@ -297,7 +345,7 @@ BMPC_INL void walk_pose_rows(const double* pg, int N, int k, const double* y, co
 
 // natural-diagonal rows of DG position I (dg_pos order); calls v.diag(s, coef, h) per active row
 template <int I, class V>
-BMPC_INL void walk_diag_pos(const double* lbx, const double* ubx, int N, int k, const double* y, V& v) {
+BMPC_INL void walk_diag_pos(GCD lbx, GCD ubx, int N, int k, const double* y, V& v) {
     if constexpr (I < 28) {
         constexpr int blk = I / 7, jj = I % 7;
         constexpr int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + jj;
@@ -378,11 +426,14 @@ BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][
         chain_all<J + 1>(K, Jl, G, hdt, M6, Hv, Hqq, E);
     }
 }
-// C3 and the chained gradients
+// P17 blocks: for position I of the (q, dq, pi) block emit the three slack-column couplings, then
+// D, g0, g1, gz of that position (its diagonal rows are walked here), 7 fields
 template <int I>
-BMPC_INL void chain_vecs(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const PoseAsm& P,
-                         const double* bv, const double* cd5, double c3[3][17], double g17[3][17]) {
+BMPC_INL void p17_emit_all(const PipeArgs& A, GCD pg, GCD lbx, GCD ubx, int k, const double* y, const KinT& K,
+                           const double Jl[3][7], const double G[6][7], double hdt, RowAcc& R, const PointAsm& PA,
+                           const PoseAsm& P, const double* bv, Emitter& E) {
     if constexpr (I < 17) {
+        GCD wts = pg + P_W;
         double cO[6], cV[6];
         chain_cols<I>(K, Jl, G, hdt, cO, cV);
         BMPC_UNROLL
@@ -390,18 +441,30 @@ BMPC_INL void chain_vecs(const KinT& K, const double Jl[3][7], const double G[6]
             double s = 0;
             BMPC_UNROLL
             for (int a = 0; a < 6; a++) s += cO[a] * P.mS[sl][a];
-            if (sl == 2 && I < 7) s += cd5[I < 7 ? I : 0];
-            c3[sl][I] = s;
+            if (sl == 2 && I < 7) s += PA.cd5[I < 7 ? I : 0];
+            E.put(s);
         }
-        double v0 = 0, v1 = 0, vz = 0;
+        double g0 = 0, g1 = 0, gz = 0;
         BMPC_UNROLL
         for (int a = 0; a < 6; a++) {
-            v0 += cO[a] * P.bp0[a] + cV[a] * bv[a];
-            v1 += cO[a] * P.bp1[a];
-            vz += cO[a] * P.bpz[a] + cV[a] * bv[a];
+            g0 += cO[a] * P.bp0[a] + cV[a] * bv[a];
+            g1 += cO[a] * P.bp1[a];
+            gz += cO[a] * P.bpz[a] + cV[a] * bv[a];
         }
-        g17[0][I] = v0; g17[1][I] = v1; g17[2][I] = vz;
-        chain_vecs<I + 1>(K, Jl, G, hdt, P, bv, cd5, c3, g17);
+        constexpr int DI = I < 14 ? I : 38 + (I - 14);      // dg index of this position
+        DiagAsm dgv;
+        dgv.R = &R;
+        dgv.begin();
+        walk_diag_pos<DI>(lbx, ubx, A.N, k, y, dgv);
+        double D = dgv.D;
+        g0 += dgv.g0; g1 += dgv.g1; gz += dgv.gz;
+        if constexpr (I < 7) { g0 += PA.gq0[I]; g1 += PA.gq1[I]; gz += PA.gqz[I]; }
+        if constexpr (I >= 7 + 2 && I <= 7 + 4) {            // joint-velocity cost (Q9)
+            const double w2 = 2 * wts[6], val = w2 * y[Z_DQ + I - 7];
+            D += w2; g0 += val; gz += val;
+        }
+        E.put(D); E.put(g0); E.put(g1); E.put(gz);
+        p17_emit_all<I + 1>(A, pg, lbx, ubx, k, y, K, Jl, G, hdt, R, PA, P, bv, E);
     }
 }
 
@@ -464,20 +527,15 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
 
 // DG entries: position I of the dg order
 template <int I>
-BMPC_INL void dg_emit_all(const PipeArgs& A, const double* pg, const double* lbx, const double* ubx, int k, bool term,
-                          const double* y, RowAcc& R, const PointAsm& PA, const PoseAsm& PO, const double g17[3][17],
-                          Emitter& E) {
-    if constexpr (I < 41) {
-        const double* wts = pg + P_W;
+BMPC_INL void dg_emit_all(const PipeArgs& A, GCD pg, GCD lbx, GCD ubx, int k, bool term,
+                          const double* y, RowAcc& R, const PointAsm& PA, const PoseAsm& PO, Emitter& E) {
+    if constexpr (I < 38) {
+        GCD wts = pg + P_W;
         DiagAsm dgv;
         dgv.R = &R;
         dgv.begin();
         walk_diag_pos<I>(lbx, ubx, A.N, k, y, dgv);
         double D = dgv.D, g0 = dgv.g0, g1 = dgv.g1, gz = dgv.gz;
-        // chained parts
-        if constexpr (I < 7) { g0 += g17[0][I] + PA.gq0[I]; g1 += g17[1][I] + PA.gq1[I]; gz += g17[2][I] + PA.gqz[I]; }
-        else if constexpr (I < 14) { g0 += g17[0][I]; g1 += g17[1][I]; gz += g17[2][I]; }
-        else if constexpr (I >= 38) { g0 += g17[0][14 + I - 38]; g1 += g17[1][14 + I - 38]; gz += g17[2][14 + I - 38]; }
         // slack columns of the pose rows (ps, rs, d5) and of the point rows (d_c)
         if constexpr (I == 30) { D += PO.sS[0]; g0 += PO.bS0[0]; g1 += PO.bS1[0]; gz += PO.bSz[0]; }
         if constexpr (I == 28) { D += PO.sS[1]; g0 += PO.bS0[1]; g1 += PO.bS1[1]; gz += PO.bSz[1]; }
@@ -490,8 +548,7 @@ BMPC_INL void dg_emit_all(const PipeArgs& A, const double* pg, const double* lbx
         {
             double w2 = 0, extra = 0;
             bool has = false;
-            if constexpr (I >= 7 + 2 && I <= 7 + 4) { w2 = 2 * wts[6]; has = true; }
-            else if constexpr (I >= 21 && I < 28) { w2 = 2 * wts[7]; has = true; }
+            if constexpr (I >= 21 && I < 28) { w2 = 2 * wts[7]; has = true; }
             else if constexpr (I == 28 || I == 30) { w2 = 2 * wts[9]; has = true; }
             else if constexpr (I == 29 || I == 31) { w2 = 2 * wts[10]; has = true; }
             else if constexpr (I >= 32 && I < 38) {
@@ -506,7 +563,7 @@ BMPC_INL void dg_emit_all(const PipeArgs& A, const double* pg, const double* lbx
             }
         }
         E.put(D); E.put(g0); E.put(g1); E.put(gz);
-        dg_emit_all<I + 1>(A, pg, lbx, ubx, k, term, y, R, PA, PO, g17, E);
+        dg_emit_all<I + 1>(A, pg, lbx, ubx, k, term, y, R, PA, PO, E);
     }
 }
 
@@ -518,9 +575,9 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
-    const double* lbx = A.lbx + (size_t)m.b * n_w;
-    const double* ubx = A.ubx + (size_t)m.b * n_w;
-    const double* pg = A.p + (size_t)m.b * NPAR;
+    GCD lbx = A.lbx + (size_t)m.b * n_w;
+    GCD ubx = A.ubx + (size_t)m.b * n_w;
+    GCD pg = A.p + (size_t)m.b * NPAR;
     const double ad = A.st[m.b].ad;
     double iw0[3];
     BMPC_UNROLL
@@ -536,9 +593,12 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     stage_point(A, pg, iw0, k, dc, S);
     double G[6][7];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);
-    double g12[12], Hp[21], Hv[21];
+    double g12[12], Hp[21];
     cost_grad12(pg, S.C, term, g12);
-    cost_hess(pg, S.C, term, Hp, Hv);
+    {
+        double HvX[21];
+        cost_hess(pg, S.C, term, Hp, HvX);
+    }
     RowAcc R;
     R.init(&A, m.pi, m.valid, ad);
     // ---- collision points -> q x q block, q x d columns ----
@@ -552,24 +612,28 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     PO.init(Hp, g12);
     walk_pose_rows(pg, N, k, S.y, S.C, PO);
     const double hdt = 0.5 * dc.dt;
-    chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA.Hqq, E);
-    double c3[3][17], g17[3][17];
-    chain_vecs<0>(S.K, S.Jl, G, hdt, PO, g12 + 6, PA.cd5, c3, g17);
-    BMPC_UNROLL
-    for (int sl = 0; sl < 3; sl++)
+    // generalised forces for the second-order kinematic terms (k_curv)
+    if (m.valid && A.o.hess == 2) {
+        GD F = A.part + (size_t)PT_FORCE * A.NP + m.pi;
         BMPC_UNROLL
-        for (int i = 0; i < 17; i++) E.put(c3[sl][i]);
-    // ---- second-order kinematic terms ----
-    if (A.o.hess == 2) {
-        double Fv[6];
+        for (int a = 0; a < 3; a++) F[(size_t)a * A.NP] = PO.bpz[a];
         BMPC_UNROLL
-        for (int a = 0; a < 6; a++) Fv[a] = g12[6 + a] + (a >= 3 ? hdt * PO.bpz[a] : 0.0);
-        curvature_emit(S.K, S.Jl, S.y + Z_DQ, PO.bpz, Fv, PA.Fc, E);
-    } else {
-        for (int i = 0; i < 98; i++) E.put(0.0);
+        for (int a = 0; a < 6; a++) F[(size_t)(3 + a) * A.NP] = g12[6 + a] + (a >= 3 ? hdt * PO.bpz[a] : 0.0);
+        BMPC_UNROLL
+        for (int c = 0; c < 6; c++)
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) F[(size_t)(9 + 3 * c + a) * A.NP] = PA.Fc[c][a];
     }
-    // ---- diagonal rows + gradients ----
-    dg_emit_all<0>(A, pg, lbx, ubx, k, term, S.y, R, PA, PO, g17, E);
+    // ---- slack-column couplings + gradients + diagonal rows of the 17 chained positions ----
+    p17_emit_all<0>(A, pg, lbx, ubx, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, g12 + 6, E);
+    // ---- chained (q, dq, pi) block ----
+    {
+        double HpX[21], Hv[21];
+        cost_hess(pg, S.C, term, HpX, Hv);
+        chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA.Hqq, E);
+    }
+    // ---- remaining diagonal rows + gradients: ddq, u, rs, drs, ps, dps, d ----
+    dg_emit_all<14>(A, pg, lbx, ubx, k, term, S.y, R, PA, PO, E);
     // ---- zeta-diagonal rows (k == 1) ----
     {
         double sg2[2] = {0, 0}, r2[3][2] = {{0, 0}, {0, 0}, {0, 0}};
@@ -606,7 +670,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             BMPC_UNROLL
             for (int a = 0; a < 3; a++) E.put(mm < 7 ? sufz[mm < 7 ? mm : 0][a] : 0.0);
     }
-    double prim = R.prim, theta = R.theta;
+    double prim = R.prim;
     {
         double rdef[NX];
         if (!term) {
@@ -615,7 +679,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             for (int i = 0; i < NX; i++) zn[i] = A.zeta_t[(size_t)i * A.NP + m.pi + 1];
             defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
             BMPC_UNROLL
-            for (int i = 0; i < NX; i++) { prim = fmax(prim, fabs(rdef[i])); theta += fabs(rdef[i]); }
+            for (int i = 0; i < NX; i++) prim = fmax(prim, fabs(rdef[i]));
         } else {
             BMPC_UNROLL
             for (int i = 0; i < NX; i++) rdef[i] = 0;
@@ -623,19 +687,56 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         BMPC_UNROLL
         for (int i = 0; i < NX; i++) E.put(rdef[i]);
     }
-    E.pad_to(HREC);
+    E.pad_to(512);
     if (k == 1) {
         double x1fix[24];
         x1fix_eval(lbx, N, dc.dt, x1fix);
         BMPC_UNROLL
-        for (int i = 0; i < 24; i++) { double r = fabs(x1fix[i] - S.zeta[i]); prim = fmax(prim, r); theta += r; }
+        for (int i = 0; i < 24; i++) prim = fmax(prim, fabs(x1fix[i] - S.zeta[i]));
     }
     if (m.valid) {
-        double* P = A.part + m.pi;
+        GD P = A.part + m.pi;
         P[PT_CMAX * A.NP] = R.cmax; P[PT_CSUM * A.NP] = R.csum; P[PT_CMIN * A.NP] = R.cmin; P[PT_ZSUM * A.NP] = R.zsum;
-        P[PT_PRIM * A.NP] = prim; P[PT_THETA * A.NP] = theta; P[PT_LOGS * A.NP] = R.logs; P[PT_NROWS * A.NP] = R.nrows;
-        P[PT_FVAL * A.NP] = S.C.fv;
+        P[PT_PRIM * A.NP] = prim; P[PT_NROWS * A.NP] = R.nrows;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_curv: second-order kinematic terms of the Lagrangian Hessian (record fields F_CQQ, F_CQD) for the
+// instances in hess_mode; forces from k_eval.  Skipped by wavefronts without such an instance.
+// ------------------------------------------------------------------------------------------
+BMPC_DEV void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
+    const int count = A.L.cnt[0], N = A.N;
+    if (A.o.hess != 2 || wave * (64 / (N - 1)) >= count) return;
+    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    if (lane == 0) lds[EM_DOUBLES] = 0.0;
+    BMPC_SYNC();
+    if (A.st[m.b].hess_mode) lds[EM_DOUBLES] = 1.0;
+    BMPC_SYNC();
+    if (lds[EM_DOUBLES] == 0.0) return;          // uniform over the wavefront
+    const DynC dc = make_dync(A.o.dt);
+    Emitter E;
+    E.init(lds, A.hrec, lane, m.pi, m.valid, F_CQQ);
+    BMPC_SYNC();
+    double zeta[NZ], y[NZ];
+    load_zeta(A.zeta, A.NP, m.pi, zeta);
+    nat_all(zeta, dc, y);
+    KinT K;
+    double Jl[3][7];
+    kin_chain(A.rc, y + Z_Q, K);
+    kin_jlin(K, Jl);
+    double Fp[3], Fv[6], Fc[6][3];
+    GCD F = A.part + (size_t)PT_FORCE * A.NP + m.pi;
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) Fp[a] = F[(size_t)a * A.NP];
+    BMPC_UNROLL
+    for (int a = 0; a < 6; a++) Fv[a] = F[(size_t)(3 + a) * A.NP];
+    BMPC_UNROLL
+    for (int c = 0; c < 6; c++)
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) Fc[c][a] = F[(size_t)(9 + 3 * c + a) * A.NP];
+    curvature_emit(K, Jl, y + Z_DQ, Fp, Fv, Fc, E);
+    E.pad_to(HREC);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -647,16 +748,18 @@ struct StepVisitor {
     const double* dy;     // natural step
     const double* dzt;    // zeta step
     double dloc[6], dpt[6][3];
-    double ap, ad, dbar;
+    double apn, apd, adn, add, dbar;    // max(-dt/t) = apn/apd, max(-dz/z) = adn/add
     BMPC_INL void fin(int s, double h, double adot) {
         size_t o = (size_t)s * A->NP + pi;
         double t = A->t[o], z = A->z[o];
+        double rt = 1.0 / t;
         double dti = -(h + t) - adot;
-        double dzi = (mu - t * z - z * dti) / t;
+        double dzi = (mu - t * z - z * dti) * rt;
         if (valid) { A->dt[o] = dti; A->dzr[o] = dzi; }
-        if (dti < 0) ap = fmin(ap, -tau * t / dti);
-        if (dzi < 0) ad = fmin(ad, -tau * z / dzi);
-        dbar -= mu * dti / t;
+        // fraction to the boundary: largest -dt/t and -dz/z, kept as fractions (no division per row)
+        if (-dti * apd > apn * t) { apn = -dti; apd = t; }
+        if (-dzi * add > adn * z) { adn = -dzi; add = z; }
+        dbar -= mu * dti * rt;
     }
     BMPC_INL void skip(int) {}
     BMPC_INL void diag(int s, int pos, double coef, double h) { fin(s, h, coef * dy[pos]); }
@@ -701,10 +804,10 @@ BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
-    const double* lbx = A.lbx + (size_t)m.b * n_w;
-    const double* ubx = A.ubx + (size_t)m.b * n_w;
-    const double* pg = A.p + (size_t)m.b * NPAR;
-    const double* wts = pg + P_W;
+    GCD lbx = A.lbx + (size_t)m.b * n_w;
+    GCD ubx = A.ubx + (size_t)m.b * n_w;
+    GCD pg = A.p + (size_t)m.b * NPAR;
+    GCD wts = pg + P_W;
     const double mu = A.st[m.b].mu;
     double iw0[3];
     BMPC_UNROLL
@@ -720,7 +823,7 @@ BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
     nat_all(dzt, dc, dy);
     StepVisitor V;
     V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu);
-    V.dy = dy; V.dzt = dzt; V.ap = 1.0; V.ad = 1.0; V.dbar = 0.0;
+    V.dy = dy; V.dzt = dzt; V.apn = 0.0; V.apd = 1.0; V.adn = 0.0; V.add = 1.0; V.dbar = 0.0;
     double dv[6];
     BMPC_UNROLL
     for (int a = 0; a < 6; a++) {
@@ -756,8 +859,10 @@ BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
         }
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
     if (m.valid) {
-        double* P = A.part + m.pi;
-        P[PT_AP * A.NP] = V.ap; P[PT_AD * A.NP] = V.ad; P[PT_DBAR * A.NP] = V.dbar; P[PT_DPHIF * A.NP] = dphi_f;
+        GD P = A.part + m.pi;
+        // step lengths tau / max(-d/x), capped at 1 by k_ls0
+        P[PT_AP * A.NP] = (V.apn > 0) ? V.tau * V.apd / V.apn : 1.0; P[PT_AD * A.NP] = (V.adn > 0) ? V.tau * V.add / V.adn : 1.0;
+        P[PT_DBAR * A.NP] = V.dbar; P[PT_DPHIF * A.NP] = dphi_f;
     }
 }
 
@@ -789,9 +894,9 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
-    const double* lbx = A.lbx + (size_t)m.b * n_w;
-    const double* ubx = A.ubx + (size_t)m.b * n_w;
-    const double* pg = A.p + (size_t)m.b * NPAR;
+    GCD lbx = A.lbx + (size_t)m.b * n_w;
+    GCD ubx = A.ubx + (size_t)m.b * n_w;
+    GCD pg = A.p + (size_t)m.b * NPAR;
     const double alpha = A.st[m.b].alpha;
     double iw0[3];
     BMPC_UNROLL
@@ -822,7 +927,7 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
         for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
     }
     if (m.valid) {
-        double* P = A.part + m.pi;
+        GD P = A.part + m.pi;
         P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th; P[PT_LS1 * A.NP] = V.ls;
     }
 }
@@ -832,8 +937,8 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
 // ------------------------------------------------------------------------------------------
 struct OutVisitor {
     double viol;
-    double* gi;          // inequality rows of this stage in the reference order, or null
-    const double* pg; const SegCtx* C; const double* y; bool term;
+    GD gi;               // inequality rows of this stage in the reference order, or null
+    GCD pg; const SegCtx* C; const double* y; bool term;
     BMPC_INL void rowv(int s, double h, bool lower) {
         if (h > 1e-6) viol += h;
         if (gi) gi[s - S_EE] = lower ? -h : h;
@@ -866,16 +971,16 @@ BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane) {
     const bool term = (k == N - 1);
     const size_t pi = pair_of(A, b, k);
     const DynC dc = make_dync(A.o.dt);
-    const double* lbx = A.lbx + (size_t)b * n_w;
-    const double* ubx = A.ubx + (size_t)b * n_w;
-    const double* pg = A.p + (size_t)b * NPAR;
+    GCD lbx = A.lbx + (size_t)b * n_w;
+    GCD ubx = A.ubx + (size_t)b * n_w;
+    GCD pg = A.p + (size_t)b * NPAR;
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     StagePoint S;
     load_zeta(A.zeta_t, A.NP, pi, S.zeta);     // the last evaluated point of the instance
     stage_point(A, pg, iw0, k, dc, S);
-    double* x = A.x + (size_t)b * n_w;
+    GD x = A.x + (size_t)b * n_w;
     BMPC_UNROLL
     for (int j = 0; j < 7; j++) {
         x[j * N + k] = S.y[Z_Q + j]; x[7 * N + j * N + k] = S.y[Z_DQ + j];
@@ -899,7 +1004,7 @@ BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane) {
         BMPC_UNROLL
         for (int i = 0; i < 6; i++) x[40 * N + i] = S.y[Z_D + i];
     // violation as BoundMPC.py:613-615 (g rows only, 1e-6 dead band) and the g vector
-    double* g = A.g ? A.g + (size_t)b * (147 * (N - 1) + 21) : nullptr;
+    GD g = A.g ? A.g + (size_t)b * (147 * (N - 1) + 21) : nullptr;
     OutVisitor V;
     V.viol = 0; V.gi = g ? g + 35 * (N - 1) + 112 * (k - 1) : nullptr; V.pg = pg; V.C = &S.C; V.y = S.y; V.term = term;
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
@@ -912,7 +1017,7 @@ BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane) {
         BMPC_UNROLL
         for (int i = 0; i < Z_D; i++) { double r = fabs(rdef[i]); if (r > 1e-6) V.viol += r; }
         if (g) {
-            double* ge = g + 35 * k;
+            GD ge = g + 35 * k;
             BMPC_UNROLL
             for (int i = 0; i < 35; i++) ge[i] = 0.0;
             BMPC_UNROLL

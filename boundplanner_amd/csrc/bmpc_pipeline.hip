@@ -1,0 +1,89 @@
+// Kernels of the batch-synchronous pipeline engine (gfx950) + their launch functions.
+// Device code: bmpc_stage.hpp / bmpc_pair_kernels.hpp / bmpc_ric_kernel.hpp.  Host sequencing:
+// bmpc_capi.hip (pipe_solve).
+#include "bmpc_platform_hip.hpp"
+
+#define BMPC_NT 64
+#include "bmpc_pair_kernels.hpp"
+#include "bmpc_ric_kernel.hpp"
+
+using namespace bmpc;
+
+// waves per SIMD the register allocator must leave room for (latency hiding vs spills)
+#ifndef BMPC_PAIR_WPS
+#define BMPC_PAIR_WPS 2
+#endif
+#ifndef BMPC_RIC_WPS
+#define BMPC_RIC_WPS 2
+#endif
+
+// the launch argument is the host view of the argument block; device code reads it through the
+// layout-identical view whose pointers are global-address-space qualified
+#define DV(H) (*reinterpret_cast<const PipeArgs*>(&(H)))
+
+// thread-per-pair kernels: one wavefront per workgroup, floor(64/(N-1)) instances per wavefront
+__global__ __launch_bounds__(64) void bmpc_k_init_inst(PipeArgsH H) { k_init_inst_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { k_init_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_eval(PipeArgsH H) {
+    __shared__ double lds[EM_DOUBLES + 8];
+    k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
+    __shared__ double lds[EM_DOUBLES + 8];
+    k_curv_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+#ifndef BMPC_RIC_NT
+#define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
+#endif
+__global__ __launch_bounds__(BMPC_RIC_NT, BMPC_RIC_WPS) void bmpc_k_ric(PipeArgsH H) {
+    __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
+    k_ric_body<BMPC_RIC_NT>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
+__global__ __launch_bounds__(64) void bmpc_k_ls0(PipeArgsH H) { k_ls0_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void bmpc_k_ls(PipeArgsH H) { k_ls_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
+__global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void bmpc_k_fin(PipeArgsH H) { k_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
+
+#define LAUNCH(kern, nb, nt)                                            \
+    do {                                                                \
+        if ((nb) > 0) hipLaunchKernelGGL(kern, dim3(nb), dim3(nt), 0, st, *A); \
+    } while (0)
+
+extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st) {
+    LAUNCH(bmpc_k_init_inst, (A->B + 63) / 64, 64);
+    LAUNCH(bmpc_k_init, waves_for(A->N, A->B), 64);
+    LAUNCH(bmpc_k_init_fin, (A->B + 63) / 64, 64);
+    return hipGetLastError();
+}
+
+// one super-step for at most n_act active instances; swaps the double-buffered lists in *A
+extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st) {
+    const int nw = waves_for(A->N, n_act), ni = (n_act + 63) / 64;
+    LAUNCH(bmpc_k_eval, nw, 64);
+    LAUNCH(bmpc_k_curv, nw, 64);
+    LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
+    LAUNCH(bmpc_k_step, nw, 64);
+    LAUNCH(bmpc_k_ls0, ni, 64);
+    LAUNCH(bmpc_k_trial, nw, 64);
+    LAUNCH(bmpc_k_ls, ni, 64);
+    LAUNCH(bmpc_k_rotate, 1, 64);
+    int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
+    t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;
+    return hipGetLastError();
+}
+
+extern "C" hipError_t bmpc_pipe_launch_out(const PipeArgsH* A, hipStream_t st) {
+    LAUNCH(bmpc_k_out, waves_for(A->N, A->B), 64);
+    LAUNCH(bmpc_k_fin, (A->B + 63) / 64, 64);
+    return hipGetLastError();
+}
+
+extern "C" void bmpc_pipe_build_table(int* tbl) { build_scatter_table(tbl); }
+extern "C" int bmpc_pipe_hrec(void) { return HREC; }
+extern "C" int bmpc_pipe_krec(void) { return KREC; }
+extern "C" int bmpc_pipe_npart(void) { return NPART; }
+extern "C" size_t bmpc_pipe_state_bytes(void) { return sizeof(InstState); }

@@ -21,19 +21,20 @@ namespace bmpc {
 // natural-coordinate Hessian pieces + gradients + dynamics linearisation, AoS [pair][HREC]
 // ------------------------------------------------------------------------------------------
 constexpr int F_CD = 0;                 // [c<5][i<7]    W[q_i][d_c]
-constexpr int F_H17 = F_CD + 35;        // columns j=0..16, rows i<=j   (q, dq, pi) block
-constexpr int F_C3 = F_H17 + 153;       // [sl<3][i<17]  W[pos17(i)][PS|RS|D5]
-constexpr int F_CQQ = F_C3 + 51;        // [a][b] second-order kinematic terms, q x q
-constexpr int F_CQD = F_CQQ + 49;       // [i][j] q_i x dq_j
-constexpr int F_DG = F_CQD + 49;        // [41 positions in DG order][D, g0, g1, gz]
-constexpr int F_DZ2 = F_DG + 164;       // zeta-diagonal rows (k == 1): sigma of rs~_1, ps~_1
+constexpr int F_P17 = F_CD + 35;        // [i<17]{C3[PS], C3[RS], C3[D5], D, g0, g1, gz} of position pos17(i)
+constexpr int F_H17 = F_P17 + 119;      // columns j=0..16, rows i<=j   (q, dq, pi) block
+constexpr int F_DGR = F_H17 + 153;      // [dg positions 14..37]{D, g0, g1, gz}: ddq, u, rs, drs, ps, dps, d
+constexpr int F_DZ2 = F_DGR + 96;       // zeta-diagonal rows (k == 1): sigma of rs~_1, ps~_1
 constexpr int F_GZ2 = F_DZ2 + 2;        // [r0, r1, zz][2]
 constexpr int F_EW = F_GZ2 + 6;         // G_ang[3][7], J_ang[3][7]
 constexpr int F_SUFZ = F_EW + 42;       // sufz[1..7][3] = sum_{j>=m} z_j dq_j
 constexpr int F_RDEF = F_SUFZ + 21;     // dynamics defect (32)
-constexpr int F_END = F_RDEF + 32;
-constexpr int HREC = 608;
-static_assert(F_END <= HREC && HREC % 16 == 0, "record layout");
+constexpr int F_MAIN_END = F_RDEF + 32; // 506: written by k_eval (padded to 512)
+constexpr int F_CQQ = 528;              // written by k_curv: [a][b] second-order kinematic terms, q x q
+constexpr int F_CQD = F_CQQ + 49;       // [i][j] q_i x dq_j
+constexpr int F_END = F_CQD + 49;
+constexpr int HREC = 640;               // multiple of 64: k_ric reads it with 10 unconditional loads per lane
+static_assert(F_MAIN_END <= 512 && F_CQQ % 16 == 0 && F_END <= HREC && HREC % 64 == 0, "record layout");
 
 // DG order: q, dq, ddq, u, rs, drs, ps, dps, d, pi
 BMPC_HD int dg_pos(int i) {
@@ -55,7 +56,8 @@ constexpr int dg_pos_c(int i) {
 BMPC_HD int pos17(int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); }
 
 constexpr int KREC = 320;               // gains per pair: K (9x32) + kf (2x16)
-constexpr int NPART = 16;               // per-pair partial sums
+constexpr int NPART = 48;               // per-pair partial sums (16) + generalised forces for k_curv (27)
+constexpr int PT_FORCE = 16;            // Fp[3], Fv[6], Fc[6][3]
 enum { PT_CMAX = 0, PT_CSUM, PT_CMIN, PT_ZSUM, PT_PRIM, PT_THETA, PT_LOGS, PT_NROWS, PT_FVAL,
        PT_AP, PT_AD, PT_DBAR, PT_DPHIF, PT_F1, PT_TH1, PT_LS1 };
 
@@ -69,35 +71,52 @@ struct InstState {
     double filt_th[8], filt_phi[8];
 };
 
-struct Lists {           // work lists (instance ids) with their counters
-    int *eval, *step, *trial, *eval_next, *trial_next;
-    int* cnt;            // [0] n_eval [1] n_step [2] n_trial [3] n_eval_next [4] n_trial_next [5] n_done
+// PipeArgsT<0>: plain pointers (host side, launch arguments); PipeArgsT<1>: the same layout with
+// global-address-space pointers, which is how the device code reads it
+template <int DEV> struct PtrT {
+    typedef double* D; typedef const double* CD; typedef int* I; typedef const int* CI;
+    typedef struct InstState* S; typedef const RobotConst* RC;
+};
+template <> struct PtrT<1> {
+    typedef GD D; typedef GCD CD; typedef GI I; typedef GCI CI;
+    typedef BMPC_AS1 struct InstState* S; typedef GRC RC;
 };
 
-struct PipeArgs {
+template <int DEV> struct ListsT {           // work lists (instance ids) with their counters
+    typename PtrT<DEV>::I eval, step, trial, eval_next, trial_next;
+    typename PtrT<DEV>::I cnt;   // [0] n_eval [1] n_step [2] n_trial [3] n_eval_next [4] n_trial_next [5] n_done
+};
+
+template <int DEV> struct PipeArgsT {
+    typedef PtrT<DEV> PT;
     int B, N;
     SolverOpts o;
-    const RobotConst* rc;
-    const double *x0, *lbx, *ubx, *p;
-    double *x, *f, *viol, *g;
-    int *iters, *status;
+    typename PT::RC rc;
+    typename PT::CD x0, lbx, ubx, p;
+    typename PT::D x, f, viol, g;
+    typename PT::I iters, status;
     // workspace
-    size_t NP;                       // pair stride of the SoA arrays (>= B*(N-1))
-    double *zeta, *zeta_t, *dz;      // [41][NP]
-    double *t, *t_t, *z, *dt, *dzr;  // [NSLOT][NP]
-    double* hrec;                    // [pairs][HREC]
-    double* krec;                    // [pairs][KREC]
-    double* part;                    // [NPART][NP]
-    InstState* st;                   // [B]
-    Lists L;
-    const int* tbl;                  // scatter table of the stage record (3 ints per field)
+    size_t NP;                           // pair stride of the SoA arrays (>= B*(N-1))
+    typename PT::D zeta, zeta_t, dz;     // [41][NP]
+    typename PT::D t, t_t, z, dt, dzr;   // [NSLOT][NP]
+    typename PT::D hrec;                 // [pairs][HREC]
+    typename PT::D krec;                 // [pairs][KREC]
+    typename PT::D part;                 // [NPART][NP]
+    typename PT::S st;                   // [B]
+    ListsT<DEV> L;
+    typename PT::CI tbl;                 // scatter table of the stage record (3 ints per field)
+    typename PT::D prof;                 // diagnostic builds (-DBMPC_PROFILE): phase cycle sums, else unused
 };
+typedef PipeArgsT<0> PipeArgsH;          // host view
+typedef PipeArgsT<1> PipeArgs;           // device view (same layout)
+static_assert(sizeof(PipeArgsH) == sizeof(PipeArgs), "host/device argument layouts differ");
+typedef BMPC_AS1 InstState* GST;
 
-BMPC_INL size_t pair_of(const PipeArgs& A, int b, int k) { return (size_t)b * (A.N - 1) + (k - 1); }
+template <class AT> BMPC_INL size_t pair_of(const AT& A, int b, int k) { return (size_t)b * (A.N - 1) + (k - 1); }
 
 // lanes -> pairs inside a wave: floor(64/(N-1)) instances per wave, lane = li*(N-1) + (k-1)
 struct PairMap { int b, k; bool valid; size_t pi; };
-BMPC_INL PairMap pair_map(const PipeArgs& A, const int* list, int count, int wave, int lane) {
+BMPC_INL PairMap pair_map(const PipeArgs& A, GCI list, int count, int wave, int lane) {
     const int S = A.N - 1, ipw = 64 / S;
     int li = lane / S, kk = lane - li * S;
     int e = wave * ipw + li;
@@ -108,7 +127,7 @@ BMPC_INL PairMap pair_map(const PipeArgs& A, const int* list, int count, int wav
     m.pi = pair_of(A, m.b, m.k);
     return m;
 }
-BMPC_INL int waves_for(int N, int count) { int ipw = 64 / (N - 1); return (count + ipw - 1) / ipw; }
+BMPC_HD int waves_for(int N, int count) { int ipw = 64 / (N - 1); return (count + ipw - 1) / ipw; }
 
 // ------------------------------------------------------------------------------------------
 // coalesced AoS output of per-thread records: 16 fields at a time through an LDS tile
@@ -117,10 +136,10 @@ constexpr int EM_LD = 66;                      // tile row stride (doubles): con
 constexpr int EM_DOUBLES = 16 * EM_LD + 64;    // tile + per-lane record base (as double)
 struct Emitter {
     LDSD* tile;        // [16][EM_LD]
-    double* out;       // record array base
+    GD out;            // record array base
     int lane, f;
-    BMPC_INL void init(LDSD* lds, double* out_, int lane_, size_t pi, bool valid) {
-        tile = lds; out = out_; lane = lane_; f = 0;
+    BMPC_INL void init(LDSD* lds, GD out_, int lane_, size_t pi, bool valid, int f0 = 0) {
+        tile = lds; out = out_; lane = lane_; f = f0;     // f0: multiple of 16
         // publish every lane's record base (exact in a double: < 2^53) for the transposed store;
         // -1 = this lane must not store
         lds[16 * EM_LD + lane] = valid ? (double)(pi * HREC) : -1.0;

@@ -11,7 +11,7 @@
 #define BMPC_BLOCK() ((int)blockIdx.x)
 #define BMPC_NBLOCKS() ((int)gridDim.x)
 #define BMPC_HD __host__ __device__ inline
-#define BMPC_ATOMIC_INC(ptr) atomicAdd((ptr), 1)
+#define BMPC_ATOMIC_INC(ptr) __hip_atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 // doubles that live in LDS: address-space-qualified so that every access is a ds_* instruction
 // (generic pointers to __shared__ memory compile to flat_* loads through the vector-memory path)
 typedef __attribute__((address_space(3))) double LDSD;
@@ -20,3 +20,31 @@ typedef __attribute__((address_space(3))) double LDSD;
 #else
 #define BMPC_NOINL __device__ __attribute__((noinline))
 #endif
+
+// 16-byte LDS vector access (ds_read_b128 / ds_write_b128) and fast reciprocal square root
+typedef double bmpc_v2d __attribute__((vector_size(16)));
+typedef __attribute__((address_space(3))) bmpc_v2d LDSV2;
+#define BMPC_RSQRT(x) rsqrt(x)
+// LDS atomic add without return (ds_add_f64): used where every address receives at most one add per
+// phase, so the result does not depend on the order
+#define BMPC_LDS_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// global-memory pointers are address-space qualified in device code so that every access is a
+// global_* instruction (generic pointers compile to flat_*, which also count against the LDS counter)
+#ifndef BMPC_AS1
+#define BMPC_AS1 __attribute__((address_space(1)))
+#endif
+// asynchronous global -> LDS copy of NCH chunks of 1 KiB (LDS-DMA, no registers) by a workgroup of NT
+// lanes: each wavefront instruction moves one chunk (lane L of the wavefront: 16 bytes to chunk + L*16).
+// Completion: BMPC_ASYNC_WAIT() in every wavefront, then a barrier.
+template <int NCH, int NT>
+__device__ __forceinline__ void bmpc_async_copy(__attribute__((address_space(1))) const double* gsrc, LDSD* lds_dst, int lane) {
+    const int wave = lane >> 6, wl = lane & 63;
+#pragma unroll
+    for (int i = 0; i < (NCH + NT / 64 - 1) / (NT / 64); i++) {
+        const int c = i * (NT / 64) + wave;
+        if (c < NCH)
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)(gsrc + 2 * wl + 128 * c),
+                                             (__attribute__((address_space(3))) void*)(lds_dst + 128 * c), 16, 0, 0);
+    }
+}
+#define BMPC_ASYNC_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

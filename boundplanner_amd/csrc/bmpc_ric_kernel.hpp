@@ -35,9 +35,13 @@ constexpr int R_r0 = R_dxn + NX;
 constexpr int R_x1fix = R_r0 + NX;
 constexpr int R_dzeta = R_x1fix + NX;       // 48
 constexpr int R_dy = R_dzeta + ZPAD;        // 48
-constexpr int R_red = R_dy + ZPAD;          // 64
-constexpr int R_misc = R_red + 64;          // 64
-constexpr int RIC_LDS_DOUBLES = R_misc + 64;
+constexpr int R_red = R_dy + ZPAD;          // up to 128 lanes
+constexpr int R_misc = R_red + 128;         // 48: junk targets of the scatter [0,32), phase timers [32,48)
+constexpr int R_acc = R_misc + 48;          // 2 x 128: per-lane |lambda| sums and dual-residual maxima
+constexpr int R_park = R_acc + 256;         // 16: uniform scalars parked across the sweep calls
+constexpr int R_stage = R_park + 16;        // HREC: the stage record, filled by LDS-DMA one stage ahead
+constexpr int RIC_LDS_DOUBLES = R_stage + HREC;
+static_assert(R_stage % 2 == 0 && RIC_LDS_DOUBLES * 8 <= 40960, "k_ric LDS: 4 workgroups per CU");
 
 // scatter table entry of one record field: pass (0 none, 1 store, 2 add, 3 add when hess_mode),
 // LDS offsets of the target and of its symmetric mirror (-1 = none)
@@ -54,20 +58,22 @@ inline void build_scatter_table(int* tbl /* 3*HREC */) {
             for (int i = 0; i <= j; i++, f++) set(f, 1, Wo(pos17(i), pos17(j)), i == j ? -1 : Wo(pos17(j), pos17(i)));
     }
     const int spos[3] = {Z_PS, Z_RS, Z_D + 5};
-    for (int sl = 0; sl < 3; sl++)
-        for (int i = 0; i < 17; i++) set(F_C3 + sl * 17 + i, 2, Wo(pos17(i), spos[sl]), Wo(spos[sl], pos17(i)));
+    for (int i = 0; i < 17; i++) {
+        const int f = F_P17 + 7 * i, pos = pos17(i);
+        for (int sl = 0; sl < 3; sl++) set(f + sl, 2, Wo(pos, spos[sl]), Wo(spos[sl], pos));
+        set(f + 3, 2, Wo(pos, pos), -1);
+        set(f + 4, 1, R_g0 + pos, -1); set(f + 5, 1, R_g1 + pos, -1); set(f + 6, 1, R_gz + pos, -1);
+    }
+    for (int I = 14; I < 38; I++) {
+        const int f = F_DGR + 4 * (I - 14), pos = dg_pos(I);
+        set(f, 2, Wo(pos, pos), -1);
+        set(f + 1, 1, R_g0 + pos, -1); set(f + 2, 1, R_g1 + pos, -1); set(f + 3, 1, R_gz + pos, -1);
+    }
     for (int a = 0; a < 7; a++)
         for (int b = 0; b < 7; b++) {
             set(F_CQQ + a * 7 + b, 3, Wo(Z_Q + a, Z_Q + b), -1);
             set(F_CQD + a * 7 + b, 3, Wo(Z_Q + a, Z_DQ + b), Wo(Z_DQ + b, Z_Q + a));
         }
-    for (int I = 0; I < 41; I++) {
-        int pos = dg_pos(I);
-        set(F_DG + 4 * I, 2, Wo(pos, pos), -1);
-        set(F_DG + 4 * I + 1, 1, R_g0 + pos, -1);
-        set(F_DG + 4 * I + 2, 1, R_g1 + pos, -1);
-        set(F_DG + 4 * I + 3, 1, R_gz + pos, -1);
-    }
     for (int i = 0; i < 8; i++) set(F_DZ2 + i, 1, R_dz2 + i, -1);
     for (int i = 0; i < 42; i++) set(F_EW + i, 1, R_ew + i, -1);
     for (int i = 0; i < 21; i++) set(F_SUFZ + i, 1, R_sufz + i, -1);
@@ -113,46 +119,154 @@ BMPC_INL void chol9r_solve(const double* Lc, double* b) {
 #undef LI
 }
 
+// 9x9 Cholesky of the control block, reciprocal form: Lc packed lower, invd[j] = 1 / L[j][j]
+BMPC_INL bool chol9i(const LDSD* W, double reg, double* Lc, double* invd) {
+    bool ok = true;
+#define LI(i, j) Lc[(i) * ((i) + 1) / 2 + (j)]
+    BMPC_UNROLL
+    for (int j = 0; j < NU; j++) {
+        double d = W[(NX + j) * LDW + NX + j] + reg;
+        BMPC_UNROLL
+        for (int l = 0; l < j; l++) d -= LI(j, l) * LI(j, l);
+        if (!(d > 0)) { ok = false; d = 1.0; }
+        double r = BMPC_RSQRT(d);
+        invd[j] = r;
+        LI(j, j) = d * r;
+        BMPC_UNROLL
+        for (int i = j + 1; i < NU; i++) {
+            double s = W[(NX + i) * LDW + NX + j];
+            BMPC_UNROLL
+            for (int l = 0; l < j; l++) s -= LI(i, l) * LI(j, l);
+            LI(i, j) = s * r;
+        }
+    }
+    return ok;
+}
+BMPC_INL void chol9i_solve(const double* Lc, const double* invd, double* b) {
+    BMPC_UNROLL
+    for (int i = 0; i < NU; i++) {
+        double s = b[i];
+        BMPC_UNROLL
+        for (int l = 0; l < i; l++) s -= LI(i, l) * b[l];
+        b[i] = s * invd[i];
+    }
+    BMPC_UNROLL
+    for (int i = NU - 1; i >= 0; i--) {
+        double s = b[i];
+        BMPC_UNROLL
+        for (int l = i + 1; l < NU; l++) s -= LI(l, i) * b[l];
+        b[i] = s * invd[i];
+    }
+#undef LI
+}
+
 #define RL(x) (lds + (x))
 
+// optional phase timing (diagnostic builds only: -DBMPC_PROFILE; never in the product build)
+#ifdef BMPC_PROFILE
+#define RPROF_START() long long rp_t0_ = clock64()
+#define RPROF(i) do { long long t1_ = clock64(); if (lane == 0) RL(R_misc)[32 + (i)] += (double)(t1_ - rp_t0_); rp_t0_ = t1_; } while (0)
+#else
+#define RPROF_START() do {} while (0)
+#define RPROF(i) do {} while (0)
+#endif
+
+// workgroup-wide reductions over NT lanes through LDS (fixed order -> reproducible)
+template <int NT> BMPC_DEV double rsum(double v, LDSD* red, int lane) {
+    BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
+    double s = 0;
+    for (int i = 0; i < NT; i++) s += red[i];
+    return s;
+}
+template <int NT> BMPC_DEV double rmax(double v, LDSD* red, int lane) {
+    BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
+    double s = red[0];
+    for (int i = 1; i < NT; i++) s = fmax(s, red[i]);
+    return s;
+}
+template <int NT> BMPC_DEV double rmin(double v, LDSD* red, int lane) {
+    BMPC_SYNC(); red[lane] = v; BMPC_SYNC();
+    double s = red[0];
+    for (int i = 1; i < NT; i++) s = fmin(s, red[i]);
+    return s;
+}
+
 // backward recursion over the horizon; returns false if a control block is not positive definite
-BMPC_DEV bool ric_backward(const PipeArgs& A, LDSD* lds, int b, int lane, int hess_mode, double reg, double hreg,
-                           double& lamsum_o, double& dual_o) {
+// The Riccati kernel reads the argument block through the plain-pointer view: with global-qualified
+// pointers this compiler (ROCm 7.2) mis-assigns an odd register pair when it reloads a spilled
+// 64-bit memory operand ("Subtarget requires even aligned vector registers")
+template <int NT>
+BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int hess_mode) {
+    // no floating-point arguments: an odd-aligned 64-bit argument pair that gets spilled trips a
+    // register-alignment bug of this compiler; scalars travel through LDS (R_park)
+    const double reg = 1e-9;      // fixed regularisation of the control block
+    const double hreg = lds[R_park + 12];
     const int N = A.N;
     const DynC dc = make_dync(A.o.dt);
     bool ok = true;
-    double lamsum = 0, dual = 0;
+    // per-lane accumulators of |lambda| and of the dual residual live in LDS (long live ranges in
+    // registers only get spilled): R_acc[lane], R_acc[128 + lane]
+    RL(R_acc)[lane] = 0.0; RL(R_acc)[128 + lane] = 0.0;
     if (lane < NX) { RL(R_lam)[lane] = 0; RL(R_pv0)[lane] = 0; RL(R_pv1)[lane] = 0; }
-    constexpr int NF = (HREC + 63) / 64;
-    int tps[NF], to1[NF], to2[NF];     // this lane's scatter-table entries (same for every stage)
+    constexpr int NF = HREC / NT;
+    static_assert(HREC % NT == 0, "record loads are unconditional");
+    // this lane's scatter-table entries (the same for every stage), packed: o1 | o2 << 13 | pass << 26
+    // (offset 8191 = none); stores of fields that are not in the store pass go to a junk slot
+    int tpk[NF];
+    const int junk = R_misc + (lane & 31);
     BMPC_UNROLL
     for (int i = 0; i < NF; i++) {
-        int f = lane + 64 * i;
-        tps[i] = (f < HREC) ? A.tbl[3 * f] : 0; to1[i] = (f < HREC) ? A.tbl[3 * f + 1] : 0; to2[i] = (f < HREC) ? A.tbl[3 * f + 2] : -1;
+        int f = lane + NT * i;
+        int ps = (f < HREC) ? A.tbl[3 * f] : 0, o1 = (f < HREC) ? A.tbl[3 * f + 1] : -1, o2 = (f < HREC) ? A.tbl[3 * f + 2] : -1;
+        if (ps == 0) { o1 = -1; o2 = -1; }
+        if (ps == 1 && o2 < 0) o2 = junk;
+        tpk[i] = (o1 < 0 ? 8191 : o1) | ((o2 < 0 ? 8191 : o2) << 13) | (ps << 26);
     }
+    constexpr int NE2 = (NZ * 9 + 27 + NT - 1) / NT;
+    static_assert((NT == 64 || NT == 128) && HREC % 128 == 0, "record DMA: 1 KiB per wavefront instruction");
+    bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + pair_of(A, b, N - 1) * HREC), RL(R_stage), lane);
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
         const size_t pi = pair_of(A, b, k);
-        const double* rec = A.hrec + pi * HREC;
+        RPROF_START();
         // ---- stage matrix from the record (natural coordinates) ----
+        {
+            const bmpc_v2d z2 = {0.0, 0.0};
+            for (int e = lane; e < NZ * LDW / 2; e += NT) *(LDSV2*)(RL(R_W) + 2 * e) = z2;
+        }
+        BMPC_ASYNC_WAIT();
+        BMPC_SYNC();
         double rv[NF];
         BMPC_UNROLL
-        for (int i = 0; i < NF; i++) { int f = lane + 64 * i; rv[i] = (f < HREC) ? rec[f] : 0.0; }
-        for (int e = lane; e < NZ * LDW; e += 64) RL(R_W)[e] = (e / LDW == e % LDW) ? hreg : 0.0;
-        BMPC_SYNC();
+        for (int i = 0; i < NF; i++) rv[i] = RL(R_stage)[lane + NT * i];
         BMPC_UNROLL
-        for (int pass = 1; pass <= 3; pass++) {
-            if (pass < 3 || hess_mode) {
-                BMPC_UNROLL
-                for (int i = 0; i < NF; i++) {
-                    if (tps[i] == pass) {
-                        if (pass == 1) { lds[to1[i]] = rv[i]; if (to2[i] >= 0) lds[to2[i]] = rv[i]; }
-                        else { lds[to1[i]] += rv[i]; if (to2[i] >= 0) lds[to2[i]] += rv[i]; }
-                    }
-                }
+        for (int i = 0; i < NF; i++) {
+            const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
+            lds[ps == 1 ? o1 : junk] = rv[i]; lds[ps == 1 ? o2 : junk] = rv[i];
+        }
+        BMPC_SYNC();
+        // adds: every address receives at most one add per pass (order-independent result)
+        BMPC_UNROLL
+        for (int i = 0; i < NF; i++) {
+            const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
+            if (ps == 2) { BMPC_LDS_ADD(lds + o1, rv[i]); if (o2 != 8191) BMPC_LDS_ADD(lds + o2, rv[i]); }
+        }
+        if (hreg != 0.0) {
+            BMPC_SYNC();
+            if (lane < NZ) RL(R_W)[lane * LDW + lane] += hreg;
+        }
+        BMPC_SYNC();
+        if (hess_mode) {
+            BMPC_UNROLL
+            for (int i = 0; i < NF; i++) {
+                const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
+                if (ps == 3) { BMPC_LDS_ADD(lds + o1, rv[i]); if (o2 != 8191) BMPC_LDS_ADD(lds + o2, rv[i]); }
             }
             BMPC_SYNC();
         }
+        // every lane has consumed the staged record: fetch the next stage's behind the rest of this stage
+        if (k > 1) bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + (pi - 1) * HREC), RL(R_stage), lane);
+        RPROF(0);
         // ---- second-order term of the pi dynamics: multiplier lam_pi(k+1) times d2(dt w)/d(q,dq)2 ----
         if (hess_mode && !term) {
             const double l0 = dc.dt * RL(R_lam)[Z_PI], l1 = dc.dt * RL(R_lam)[Z_PI + 1], l2 = dc.dt * RL(R_lam)[Z_PI + 2];
@@ -162,7 +276,7 @@ BMPC_DEV bool ric_backward(const PipeArgs& A, LDSD* lds, int b, int lane, int he
                 if (m >= 7) { s[0] = 0; s[1] = 0; s[2] = 0; }
                 else { s[0] = RL(R_sufz)[3 * (m - 1)]; s[1] = RL(R_sufz)[3 * (m - 1) + 1]; s[2] = RL(R_sufz)[3 * (m - 1) + 2]; }
             };
-            for (int e = lane; e < 98; e += 64) {
+            for (int e = lane; e < 98; e += NT) {
                 if (e < 49) {
                     int a = e / 7, bq = e % 7;
                     double za[3], zb[3], sa[3], sm[3], u1[3] = {0, 0, 0}, u2[3], tmp[3];
@@ -186,71 +300,152 @@ BMPC_DEV bool ric_backward(const PipeArgs& A, LDSD* lds, int b, int lane, int he
             }
             BMPC_SYNC();
         }
-        // ---- natural -> zeta coordinates: H = T^T Hy T (column pass, then row pass + vectors) ----
-        for (int e = lane; e < NZ * 9; e += 64) {
-            int i = e / 9, t = e % 9;
-            LDSD* row = RL(R_W) + i * LDW;
-            if (t < 7) row[Z_U + t] += dc.c3 * row[Z_Q + t] + dc.c2 * row[Z_DQ + t] + dc.c1 * row[Z_DDQ + t];
-            else if (t == 7) row[Z_DRS] += 0.5 * dc.dt * row[Z_RS];
-            else row[Z_DPS] += 0.5 * dc.dt * row[Z_PS];
-        }
-        BMPC_SYNC();
-        for (int e = lane; e < NZ * 9 + 27; e += 64) {
-            if (e < NZ * 9) {
-                int j = e / 9, t = e % 9;
-                LDSD* W = RL(R_W);
-                if (t < 7) W[(Z_U + t) * LDW + j] += dc.c3 * W[(Z_Q + t) * LDW + j] + dc.c2 * W[(Z_DQ + t) * LDW + j] + dc.c1 * W[(Z_DDQ + t) * LDW + j];
-                else if (t == 7) W[Z_DRS * LDW + j] += 0.5 * dc.dt * W[Z_RS * LDW + j];
-                else W[Z_DPS * LDW + j] += 0.5 * dc.dt * W[Z_PS * LDW + j];
-            } else {
-                int vsel = (e - NZ * 9) / 9, t = (e - NZ * 9) % 9;
-                LDSD* g = vsel == 0 ? RL(R_g0) : vsel == 1 ? RL(R_g1) : RL(R_gz);
-                if (t < 7) g[Z_U + t] += dc.c3 * g[Z_Q + t] + dc.c2 * g[Z_DQ + t] + dc.c1 * g[Z_DDQ + t];
-                else if (t == 7) g[Z_DRS] += 0.5 * dc.dt * g[Z_RS];
-                else g[Z_DPS] += 0.5 * dc.dt * g[Z_PS];
+        RPROF(1);
+        // ---- natural -> zeta coordinates: H = T^T Hy T.  Column pass, then row pass (+ the three
+        // gradient vectors); offsets precomputed per lane, every lane gathers the operands of all its
+        // entries before it stores ----
+        BMPC_UNROLL
+        for (int pass = 0; pass < 2; pass++) {
+            double s0[NE2], s1[NE2], s2[NE2], d0[NE2];
+            int od[NE2];
+            bool ij[NE2];
+            BMPC_UNROLL
+            for (int m = 0; m < NE2; m++) {
+                // entry e: (i, t) of the 41 x 9 grid (column pass: row i, transformed column t; row pass:
+                // column i, transformed row t), then the 27 vector entries (row pass only); branch-free
+                const int e = lane + NT * m;
+                const bool inw = e < NZ * 9, inv = !inw && (e < NZ * 9 + 27) && pass == 1;
+                const int ev = inw ? e : (inv ? e - NZ * 9 : 0);
+                const int i = ev / 9, t = ev - 9 * i;
+                const bool isj = t < 7;
+                const int sp = isj ? Z_Q + t : (t == 7 ? Z_RS : Z_PS), dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
+                // W entries: offset of (row, col); vector entries: i selects g0 / g1 / gz
+                const int str = pass ? LDW : 1, base = pass ? R_W + i : R_W + i * LDW;
+                const int vb = (i == 0 ? R_g0 : i == 1 ? R_g1 : R_gz);
+                int o_d = inw ? base + dp * str : vb + dp, o_s = inw ? base + sp * str : vb + sp;
+                const int st7 = inw ? 7 * str : 7;
+                if (!inw && !inv) { o_d = junk; o_s = junk; }
+                od[m] = o_d; ij[m] = isj;
+                d0[m] = lds[o_d]; s0[m] = lds[o_s];
+                s1[m] = lds[isj && (inw || inv) ? o_s + st7 : o_s]; s2[m] = lds[isj && (inw || inv) ? o_s + 2 * st7 : o_s];
             }
+            BMPC_UNROLL
+            for (int m = 0; m < NE2; m++)
+                lds[od[m]] = d0[m] + (ij[m] ? dc.c3 : 0.5 * dc.dt) * s0[m] + (ij[m] ? dc.c2 : 0.0) * s1[m] + (ij[m] ? dc.c1 : 0.0) * s2[m];
+            BMPC_SYNC();
         }
-        BMPC_SYNC();
         if (k == 1 && lane < 2) {   // zeta-diagonal rows rs~_1, ps~_1 >= 0
             int pos = lane ? Z_PS : Z_RS;
             RL(R_W)[pos * LDW + pos] += RL(R_dz2)[lane];
             RL(R_g0)[pos] -= RL(R_dz2)[2 + lane]; RL(R_g1)[pos] -= RL(R_dz2)[4 + lane]; RL(R_gz)[pos] -= RL(R_dz2)[6 + lane];
         }
-        // ---- coupling with stage k+1 ----
+        RPROF(2);
+        // ---- coupling with stage k+1:  W += Phi^T P Phi,  g += Phi^T (pv + P rdef),  gz += Phi^T lam,
+        // Phi = [A B] + the three pi rows E (dt * d w / d(q~, dq~, u)) ----
         if (!term) {
+            // C1: E^T (R_Et), Y~ = Phi0^T P[:, pi] + 1/2 E^T P[pi, pi] (R_Y), vt0 = pv0 + P rdef
             if (lane < NZ) {
-                int c = lane;
+                const int c = lane;
+                double et[3];
+                BMPC_UNROLL
                 for (int a = 0; a < 3; a++) {
                     double v = 0;
                     if (c < Z_DQ) v = dc.dt * RL(R_ew)[7 * a + c];
                     else if (c < Z_DDQ) v = dc.dt * RL(R_ew)[21 + 7 * a + c - 7];
                     else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * RL(R_ew)[7 * a + c - Z_U] + dc.c2 * RL(R_ew)[21 + 7 * a + c - Z_U]);
-                    RL(R_Et)[a * NZ + c] = v;
+                    et[a] = v;
                 }
                 PhiCol pc = phi_col(c, dc);
-                for (int a = 0; a < 3; a++)
-                    RL(R_Y)[c * 3 + a] = pc.c0 * RL(R_P)[pc.i0 * LDP + Z_PI + a] + pc.c1 * RL(R_P)[pc.i1 * LDP + Z_PI + a] +
-                                         pc.c2 * RL(R_P)[pc.i2 * LDP + Z_PI + a];
+                const LDSD* Pp = RL(R_P) + Z_PI * LDP + Z_PI;
+                double pr[3][3], pp[3][3];
+                BMPC_UNROLL
+                for (int a = 0; a < 3; a++) {
+                    pr[0][a] = RL(R_P)[pc.i0 * LDP + Z_PI + a]; pr[1][a] = RL(R_P)[pc.i1 * LDP + Z_PI + a]; pr[2][a] = RL(R_P)[pc.i2 * LDP + Z_PI + a];
+                    pp[0][a] = Pp[a]; pp[1][a] = Pp[LDP + a]; pp[2][a] = Pp[2 * LDP + a];
+                }
+                BMPC_UNROLL
+                for (int a = 0; a < 3; a++) {
+                    RL(R_Et)[a * NZ + c] = et[a];
+                    RL(R_Y)[c * 3 + a] = pc.c0 * pr[0][a] + pc.c1 * pr[1][a] + pc.c2 * pr[2][a] +
+                                         0.5 * (et[0] * pp[0][a] + et[1] * pp[1][a] + et[2] * pp[2][a]);
+                }
+            }
+            if (lane >= NT - 32) {
+                const int r = lane - (NT - 32);
+                double v = RL(R_pv0)[r];
+                BMPC_UNROLL
+                for (int j = 0; j < NX; j++) v += RL(R_P)[r * LDP + j] * RL(R_rdef)[j];
+                RL(R_vt0)[r] = v;
             }
             BMPC_SYNC();
-            if (lane < NX) {
-                double v = RL(R_pv0)[lane];
-                for (int j = 0; j < NX; j++) v += RL(R_P)[lane * LDP + j] * RL(R_rdef)[j];
-                RL(R_vt0)[lane] = v;
-            } else if (lane < 2 * NX) {
-                RL(R_vt1)[lane - NX] = RL(R_pv1)[lane - NX];
-            }
-            BMPC_SYNC();
+            // C2: structured part Phi0^T P Phi0.  Every lane first gathers the operands of ALL its
+            // entries (joint x joint block, two joint x single entries, two single x single entries),
+            // then computes and scatters: one LDS latency instead of five
             {
                 const double al[4][3] = {{1.0, 0.0, 0.0}, {dc.dt, 1.0, 0.0}, {0.5 * dc.dt * dc.dt, dc.dt, 1.0}, {dc.b3, dc.b2, dc.b1}};
                 const int gpos[4] = {Z_Q, Z_DQ, Z_DDQ, Z_U};
-                for (int e = lane; e < 49; e += 64) {
-                    int a = e / 7, bq = e - 7 * a;
-                    double Pb[3][3];
+                LDSD* W = RL(R_W);
+                const LDSD* P = RL(R_P);
+                // (a) joint x joint: lane < 49 -> pair (a, bq)
+                const bool hasA = lane < 49;
+                const int aA = hasA ? lane / 7 : 0, bA = hasA ? lane - 7 * aA : 0;
+                double Pb[3][3], w[4][4];
+                // (b) joint rows x single columns c in [Z_PI, Z_U): 77 (a, c) pairs, lanes 49..63 take 0..14,
+                // lanes 0..61 take 15..76
+                constexpr int UB = (77 + 49 + NT - 1) / NT, UC = (121 + NT - 1) / NT;
+                int eB[UB], aB[UB], cB[UB], cwB[UB];
+                bool hasB[UB], slB[UB];
+                double pB[UB][3], wr[UB][4], wc[UB][4], xr[UB][4], xc[UB][4];
+                // (c) single x single: 121 pairs
+                int c1C[UC], c2C[UC], w1C[UC], w2C[UC];
+                bool hasC[UC], s1C[UC], s2C[UC];
+                double vC[UC], aC[UC][4];
+                if (hasA) {
                     BMPC_UNROLL
                     for (int r = 0; r < 3; r++)
                         BMPC_UNROLL
-                        for (int s = 0; s < 3; s++) Pb[r][s] = RL(R_P)[(7 * r + a) * LDP + 7 * s + bq];
+                        for (int s2 = 0; s2 < 3; s2++) Pb[r][s2] = P[(7 * r + aA) * LDP + 7 * s2 + bA];
+                    BMPC_UNROLL
+                    for (int gi = 0; gi < 4; gi++)
+                        BMPC_UNROLL
+                        for (int gj = 0; gj < 4; gj++) w[gi][gj] = W[(gpos[gi] + aA) * LDW + gpos[gj] + bA];
+                }
+                BMPC_UNROLL
+                for (int u = 0; u < UB; u++) {
+                    eB[u] = lane - 49 + NT * u;
+                    hasB[u] = eB[u] >= 0 && eB[u] < 77;
+                    const int e = hasB[u] ? eB[u] : 0;
+                    aB[u] = e / 11; cB[u] = Z_PI + (e - 11 * aB[u]);
+                    slB[u] = (cB[u] == Z_RS || cB[u] == Z_PS);
+                    cwB[u] = (cB[u] == Z_RS) ? Z_DRS : Z_DPS;
+                    if (hasB[u]) {
+                        pB[u][0] = P[aB[u] * LDP + cB[u]]; pB[u][1] = P[(7 + aB[u]) * LDP + cB[u]]; pB[u][2] = P[(14 + aB[u]) * LDP + cB[u]];
+                        BMPC_UNROLL
+                        for (int gi = 0; gi < 4; gi++) {
+                            const int r = gpos[gi] + aB[u];
+                            wr[u][gi] = W[r * LDW + cB[u]]; wc[u][gi] = W[cB[u] * LDW + r];
+                            xr[u][gi] = slB[u] ? W[r * LDW + cwB[u]] : 0.0; xc[u][gi] = slB[u] ? W[cwB[u] * LDW + r] : 0.0;
+                        }
+                    }
+                }
+                BMPC_UNROLL
+                for (int u = 0; u < UC; u++) {
+                    const int ec = lane + NT * u;
+                    hasC[u] = ec < 121;
+                    const int q1 = hasC[u] ? ec / 11 : 0;
+                    c1C[u] = Z_PI + q1; c2C[u] = Z_PI + (hasC[u] ? ec - 11 * q1 : 0);
+                    s1C[u] = (c1C[u] == Z_RS || c1C[u] == Z_PS); s2C[u] = (c2C[u] == Z_RS || c2C[u] == Z_PS);
+                    w1C[u] = (c1C[u] == Z_RS) ? Z_DRS : Z_DPS; w2C[u] = (c2C[u] == Z_RS) ? Z_DRS : Z_DPS;
+                    if (hasC[u]) {
+                        vC[u] = P[c1C[u] * LDP + c2C[u]];
+                        aC[u][0] = W[c1C[u] * LDW + c2C[u]];
+                        aC[u][1] = s2C[u] ? W[c1C[u] * LDW + w2C[u]] : 0.0;
+                        aC[u][2] = s1C[u] ? W[w1C[u] * LDW + c2C[u]] : 0.0;
+                        aC[u][3] = (s1C[u] && s2C[u]) ? W[w1C[u] * LDW + w2C[u]] : 0.0;
+                    }
+                }
+                // compute + scatter (all targets of one lane and of different lanes are distinct)
+                if (hasA) {
                     BMPC_UNROLL
                     for (int gi = 0; gi < 4; gi++) {
                         double t0 = al[gi][0] * Pb[0][0] + al[gi][1] * Pb[1][0] + al[gi][2] * Pb[2][0];
@@ -258,83 +453,102 @@ BMPC_DEV bool ric_backward(const PipeArgs& A, LDSD* lds, int b, int lane, int he
                         double t2 = al[gi][0] * Pb[0][2] + al[gi][1] * Pb[1][2] + al[gi][2] * Pb[2][2];
                         BMPC_UNROLL
                         for (int gj = 0; gj < 4; gj++)
-                            RL(R_W)[(gpos[gi] + a) * LDW + gpos[gj] + bq] += t0 * al[gj][0] + t1 * al[gj][1] + t2 * al[gj][2];
+                            W[(gpos[gi] + aA) * LDW + gpos[gj] + bA] = w[gi][gj] + t0 * al[gj][0] + t1 * al[gj][1] + t2 * al[gj][2];
                     }
                 }
-                for (int e = lane; e < 7 * 11; e += 64) {
-                    int a = e / 11, c = Z_PI + (e - 11 * a);
-                    double p0 = RL(R_P)[a * LDP + c], p1 = RL(R_P)[(7 + a) * LDP + c], p2 = RL(R_P)[(14 + a) * LDP + c];
-                    BMPC_UNROLL
-                    for (int gi = 0; gi < 4; gi++) {
-                        double v = al[gi][0] * p0 + al[gi][1] * p1 + al[gi][2] * p2;
-                        int r = gpos[gi] + a;
-                        RL(R_W)[r * LDW + c] += v; RL(R_W)[c * LDW + r] += v;
-                        if (c == Z_RS || c == Z_PS) {
-                            int cw = (c == Z_RS) ? Z_DRS : Z_DPS;
-                            RL(R_W)[r * LDW + cw] += dc.dt * v; RL(R_W)[cw * LDW + r] += dc.dt * v;
+                BMPC_UNROLL
+                for (int u = 0; u < UB; u++) {
+                    if (hasB[u]) {
+                        BMPC_UNROLL
+                        for (int gi = 0; gi < 4; gi++) {
+                            const int r = gpos[gi] + aB[u];
+                            double v = al[gi][0] * pB[u][0] + al[gi][1] * pB[u][1] + al[gi][2] * pB[u][2];
+                            W[r * LDW + cB[u]] = wr[u][gi] + v; W[cB[u] * LDW + r] = wc[u][gi] + v;
+                            if (slB[u]) { W[r * LDW + cwB[u]] = xr[u][gi] + dc.dt * v; W[cwB[u] * LDW + r] = xc[u][gi] + dc.dt * v; }
                         }
                     }
                 }
-                for (int e = lane; e < 11 * 11; e += 64) {
-                    int c1 = Z_PI + e / 11, c2 = Z_PI + e % 11;
-                    double v = RL(R_P)[c1 * LDP + c2];
-                    RL(R_W)[c1 * LDW + c2] += v;
-                    bool s1 = (c1 == Z_RS || c1 == Z_PS), s2 = (c2 == Z_RS || c2 == Z_PS);
-                    int w1 = (c1 == Z_RS) ? Z_DRS : Z_DPS, w2 = (c2 == Z_RS) ? Z_DRS : Z_DPS;
-                    if (s2) RL(R_W)[c1 * LDW + w2] += dc.dt * v;
-                    if (s1) RL(R_W)[w1 * LDW + c2] += dc.dt * v;
-                    if (s1 && s2) RL(R_W)[w1 * LDW + w2] += dc.dt * dc.dt * v;
+                BMPC_UNROLL
+                for (int u = 0; u < UC; u++) {
+                    if (hasC[u]) {
+                        W[c1C[u] * LDW + c2C[u]] = aC[u][0] + vC[u];
+                        if (s2C[u]) W[c1C[u] * LDW + w2C[u]] = aC[u][1] + dc.dt * vC[u];
+                        if (s1C[u]) W[w1C[u] * LDW + c2C[u]] = aC[u][2] + dc.dt * vC[u];
+                        if (s1C[u] && s2C[u]) W[w1C[u] * LDW + w2C[u]] = aC[u][3] + dc.dt * dc.dt * vC[u];
+                    }
                 }
             }
             BMPC_SYNC();
-            for (int e = lane; e < NZ * 21; e += 64) {
-                int i = e / 21, jj = e - 21 * i;
-                int j = jj < 14 ? jj : Z_U + jj - 14;
-                bool i_in = (i < Z_DDQ) || (i >= Z_U && i < Z_DRS);
-                double ej0 = RL(R_Et)[j], ej1 = RL(R_Et)[NZ + j], ej2 = RL(R_Et)[2 * NZ + j];
-                double v = RL(R_Y)[i * 3] * ej0 + RL(R_Y)[i * 3 + 1] * ej1 + RL(R_Y)[i * 3 + 2] * ej2;
-                if (i_in) {
-                    double ei0 = RL(R_Et)[i], ei1 = RL(R_Et)[NZ + i], ei2 = RL(R_Et)[2 * NZ + i];
-                    const LDSD* Pp = RL(R_P) + Z_PI * LDP + Z_PI;
-                    v += ei0 * RL(R_Y)[j * 3] + ei1 * RL(R_Y)[j * 3 + 1] + ei2 * RL(R_Y)[j * 3 + 2];
-                    v += ei0 * (Pp[0] * ej0 + Pp[1] * ej1 + Pp[2] * ej2) + ei1 * (Pp[LDP] * ej0 + Pp[LDP + 1] * ej1 + Pp[LDP + 2] * ej2) +
-                         ei2 * (Pp[2 * LDP] * ej0 + Pp[2 * LDP + 1] * ej1 + Pp[2 * LDP + 2] * ej2);
-                    RL(R_W)[i * LDW + j] += v;
-                } else {
-                    RL(R_W)[i * LDW + j] += v;
-                    RL(R_W)[j * LDW + i] += v;
+            // C3: rank-3 part  D[i][j] = Y~[i] . E[:, j] + Y~[j] . E[:, i]  on the 21 columns j where E is
+            // nonzero: lane = column (three lane groups split the rows), two rows per batch
+            {
+                constexpr int G3 = NT / 21, NR = (NZ + G3 - 1) / G3, RB = 4, NB = (NR + RB - 1) / RB;   // row groups, rows per lane, rows per batch, batches
+                const bool act = lane < 21 * G3;
+                const int g3 = act ? lane / 21 : 0, jj = act ? lane - 21 * g3 : 0;
+                const int j = jj < 14 ? jj : Z_U + jj - 14;
+                LDSD* W = RL(R_W);
+                const double ej0 = RL(R_Et)[j], ej1 = RL(R_Et)[NZ + j], ej2 = RL(R_Et)[2 * NZ + j];
+                const double yj0 = RL(R_Y)[3 * j], yj1 = RL(R_Y)[3 * j + 1], yj2 = RL(R_Y)[3 * j + 2];
+                BMPC_UNROLL
+                for (int mb = 0; mb < NB; mb++) {
+                    double yi[RB][3], ei[RB][3], w0[RB], w1[RB];
+                    bool in_[RB], val[RB];
+                    int ii[RB];
+                    BMPC_UNROLL
+                    for (int u = 0; u < RB; u++) {
+                        const int i = g3 + G3 * (RB * mb + u);
+                        ii[u] = i; val[u] = act && (i < NZ);
+                        const int ic = val[u] ? i : 0;
+                        in_[u] = (ic < Z_DDQ) || (ic >= Z_U && ic < Z_DRS);
+                        BMPC_UNROLL
+                        for (int a = 0; a < 3; a++) { yi[u][a] = RL(R_Y)[3 * ic + a]; ei[u][a] = RL(R_Et)[a * NZ + ic]; }
+                        w0[u] = W[ic * LDW + j]; w1[u] = W[j * LDW + ic];
+                    }
+                    BMPC_UNROLL
+                    for (int u = 0; u < RB; u++) {
+                        if (val[u]) {
+                            double v = yi[u][0] * ej0 + yi[u][1] * ej1 + yi[u][2] * ej2 + yj0 * ei[u][0] + yj1 * ei[u][1] + yj2 * ei[u][2];
+                            W[ii[u] * LDW + j] = w0[u] + v;
+                            if (!in_[u]) W[j * LDW + ii[u]] = w1[u] + v;
+                        }
+                    }
                 }
             }
             if (lane < NZ) {
-                int c = lane;
+                const int c = lane;
                 PhiCol pc = phi_col(c, dc);
-                double gl = pc.c0 * RL(R_lam)[pc.i0] + pc.c1 * RL(R_lam)[pc.i1] + pc.c2 * RL(R_lam)[pc.i2];
-                double a0 = pc.c0 * RL(R_vt0)[pc.i0] + pc.c1 * RL(R_vt0)[pc.i1] + pc.c2 * RL(R_vt0)[pc.i2];
-                double a1 = pc.c0 * RL(R_vt1)[pc.i0] + pc.c1 * RL(R_vt1)[pc.i1] + pc.c2 * RL(R_vt1)[pc.i2];
-                for (int a = 0; a < 3; a++) {
-                    double ea = RL(R_Et)[a * NZ + c];
-                    gl += ea * RL(R_lam)[Z_PI + a]; a0 += ea * RL(R_vt0)[Z_PI + a]; a1 += ea * RL(R_vt1)[Z_PI + a];
-                }
+                double l3[3], v03[3], v13[3], lp[3], v0p[3], v1p[3], ea[3];
+                l3[0] = RL(R_lam)[pc.i0]; l3[1] = RL(R_lam)[pc.i1]; l3[2] = RL(R_lam)[pc.i2];
+                v03[0] = RL(R_vt0)[pc.i0]; v03[1] = RL(R_vt0)[pc.i1]; v03[2] = RL(R_vt0)[pc.i2];
+                v13[0] = RL(R_pv1)[pc.i0]; v13[1] = RL(R_pv1)[pc.i1]; v13[2] = RL(R_pv1)[pc.i2];
+                BMPC_UNROLL
+                for (int a = 0; a < 3; a++) { ea[a] = RL(R_Et)[a * NZ + c]; lp[a] = RL(R_lam)[Z_PI + a]; v0p[a] = RL(R_vt0)[Z_PI + a]; v1p[a] = RL(R_pv1)[Z_PI + a]; }
+                double gl = pc.c0 * l3[0] + pc.c1 * l3[1] + pc.c2 * l3[2];
+                double a0 = pc.c0 * v03[0] + pc.c1 * v03[1] + pc.c2 * v03[2];
+                double a1 = pc.c0 * v13[0] + pc.c1 * v13[1] + pc.c2 * v13[2];
+                BMPC_UNROLL
+                for (int a = 0; a < 3; a++) { gl += ea[a] * lp[a]; a0 += ea[a] * v0p[a]; a1 += ea[a] * v1p[a]; }
                 RL(R_gz)[c] += gl; RL(R_g0)[c] += a0; RL(R_g1)[c] += a1;
             }
         }
         BMPC_SYNC();
+        RPROF(3);
         // ---- adjoint multipliers + dual residual (gz now holds the Lagrangian gradient) ----
         if (lane < NZ) {
             double gl = RL(R_gz)[lane];
-            if (lane >= NX || (k == 1 && lane >= 24)) dual = fmax(dual, fabs(gl));
-            if (lane < NX) { RL(R_lam)[lane] = gl; lamsum += fabs(gl); }
+            if (lane >= NX || (k == 1 && lane >= 24)) RL(R_acc)[128 + lane] = fmax(RL(R_acc)[128 + lane], fabs(gl));
+            if (lane < NX) { RL(R_lam)[lane] = gl; RL(R_acc)[lane] += fabs(gl); }
         }
         // ---- control block factorisation, gains, Schur complement ----
-        double Lc[45];
-        if (!chol9r(RL(R_W), reg, Lc)) ok = false;
+        double Lc[45], invd[NU];
+        if (!chol9i(RL(R_W), reg, Lc, invd)) ok = false;
         double* krec = A.krec + pi * KREC;
         if (lane < NX + 2) {
             double rhs[NU];
             BMPC_UNROLL
             for (int l = 0; l < NU; l++)
                 rhs[l] = (lane < NX) ? RL(R_W)[(NX + l) * LDW + lane] : (lane == NX ? RL(R_g0)[NX + l] : RL(R_g1)[NX + l]);
-            chol9r_solve(Lc, rhs);
+            chol9i_solve(Lc, invd, rhs);
             BMPC_UNROLL
             for (int l = 0; l < NU; l++) {
                 if (lane < NX) { RL(R_Kl)[l * NX + lane] = -rhs[l]; krec[l * NX + lane] = -rhs[l]; }
@@ -342,32 +556,62 @@ BMPC_DEV bool ric_backward(const PipeArgs& A, LDSD* lds, int b, int lane, int he
             }
         }
         BMPC_SYNC();
-        for (int e = lane; e < NX * NX; e += 64) {
-            int i = e / NX, j = e % NX;
-            if (j < i) continue;
-            double v = RL(R_W)[i * LDW + j];
-            for (int l = 0; l < NU; l++) v += RL(R_W)[(NX + l) * LDW + i] * RL(R_Kl)[l * NX + j];
-            RL(R_P)[i * LDP + j] = v;
-            RL(R_P)[j * LDP + i] = v;
-        }
+        RPROF(4);
+        // P = W_xx + W_xu K: lane = column j (two half-waves split the rows), K[:, j] in registers,
+        // W_ux rows fetched two at a time as broadcast 16-byte reads; loads of a batch precede its stores
         {
-            int i = lane & (NX - 1);
-            const LDSD* g = (lane < NX) ? RL(R_g0) : RL(R_g1);
-            const LDSD* kf = RL(R_kf) + ((lane < NX) ? 0 : 16);
-            double v = g[i];
-            for (int l = 0; l < NU; l++) v += RL(R_W)[(NX + l) * LDW + i] * kf[l];
-            ((lane < NX) ? RL(R_pv0) : RL(R_pv1))[i] = v;
+            constexpr int NH = NT / 32, RPH = NX / NH;      // row blocks, rows per block
+            const int j = lane & 31, h = lane >> 5;
+            double kj[NU];
+            BMPC_UNROLL
+            for (int l = 0; l < NU; l++) kj[l] = RL(R_Kl)[l * NX + j];
+            const LDSD* W = RL(R_W);
+            {
+                BMPC_UNROLL
+                for (int ib = 0; ib < RPH / 4; ib++) {
+                    const int i0 = RPH * h + 4 * ib;
+                    bmpc_v2d wa[NU], wb[NU];
+                    BMPC_UNROLL
+                    for (int l = 0; l < NU; l++) {
+                        wa[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0);
+                        wb[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0 + 2);
+                    }
+                    double p0 = W[i0 * LDW + j], p1 = W[(i0 + 1) * LDW + j], p2 = W[(i0 + 2) * LDW + j], p3 = W[(i0 + 3) * LDW + j];
+                    BMPC_UNROLL
+                    for (int l = 0; l < NU; l++) { p0 += wa[l][0] * kj[l]; p1 += wa[l][1] * kj[l]; p2 += wb[l][0] * kj[l]; p3 += wb[l][1] * kj[l]; }
+                    RL(R_P)[i0 * LDP + j] = p0; RL(R_P)[(i0 + 1) * LDP + j] = p1;
+                    RL(R_P)[(i0 + 2) * LDP + j] = p2; RL(R_P)[(i0 + 3) * LDP + j] = p3;
+                }
+            }
+            // pv = g_x + W_xu kf (two right-hand sides)
+            if (lane < 2 * NX) {
+                const int i = lane & (NX - 1);
+                const LDSD* g = (lane < NX) ? RL(R_g0) : RL(R_g1);
+                const LDSD* kf = RL(R_kf) + ((lane < NX) ? 0 : 16);
+                double wv[NU], kv[NU];
+                BMPC_UNROLL
+                for (int l = 0; l < NU; l++) { wv[l] = W[(NX + l) * LDW + i]; kv[l] = kf[l]; }
+                double v = g[i];
+                BMPC_UNROLL
+                for (int l = 0; l < NU; l++) v += wv[l] * kv[l];
+                ((lane < NX) ? RL(R_pv0) : RL(R_pv1))[i] = v;
+            }
         }
         BMPC_SYNC();
+        RPROF(5);
     }
-    lamsum_o = wg_sum(lamsum, RL(R_red), lane);
-    dual_o = wg_max(dual, RL(R_red), lane);
+    double lamsum = rsum<NT>(RL(R_acc)[lane], RL(R_red), lane);
+    double dual = rmax<NT>(RL(R_acc)[128 + lane], RL(R_red), lane);
+    if (lane == 0) { RL(R_park)[9] = lamsum; RL(R_park)[10] = dual; }     // results through LDS (see k_ric_body)
+    BMPC_SYNC();
     return ok;
 }
 
 // forward recursion: Newton direction dz for barrier parameter mu; false if the free part of the
 // stage-1 value function is not positive definite
-BMPC_DEV bool ric_forward(const PipeArgs& A, LDSD* lds, int b, int lane, double mu) {
+template <int NT>
+BMPC_NOINL bool ric_forward(const PipeArgsH& A, LDSD* lds, int b, int lane) {
+    const double mu = lds[R_park + 11];
     const int N = A.N;
     const DynC dc = make_dync(A.o.dt);
     bool ok = true;
@@ -400,14 +644,27 @@ BMPC_DEV bool ric_forward(const PipeArgs& A, LDSD* lds, int b, int lane, double 
         BMPC_SYNC();
     }
     if (!ok) return false;
-    for (int k = 1; k < N; k++) {
+    constexpr int NK = (NU * NX + NT - 1) / NT;
+    double fK[NK], fkf = 0, few = 0, frd = 0;      // stage data in flight (prefetched one stage ahead)
+    auto fetch = [&](int k) {
         const size_t pi = pair_of(A, b, k);
         const double* krec = A.krec + pi * KREC;
         const double* rec = A.hrec + pi * HREC;
-        for (int e = lane; e < NU * NX; e += 64) RL(R_Kl)[e] = krec[e];
-        if (lane < 32) RL(R_kf)[lane] = krec[NU * NX + lane];
-        if (lane < 42) RL(R_ew)[lane] = rec[F_EW + lane];
-        if (lane < NX) RL(R_rdef)[lane] = rec[F_RDEF + lane];
+        BMPC_UNROLL
+        for (int m = 0; m < NK; m++) { int e = lane + NT * m; fK[m] = (e < NU * NX) ? krec[e] : 0.0; }
+        if (lane < 32) fkf = krec[NU * NX + lane];
+        if (lane < 42) few = rec[F_EW + lane];
+        if (lane < NX) frd = rec[F_RDEF + lane];
+    };
+    fetch(1);
+    for (int k = 1; k < N; k++) {
+        const size_t pi = pair_of(A, b, k);
+        BMPC_UNROLL
+        for (int m = 0; m < NK; m++) { int e = lane + NT * m; if (e < NU * NX) RL(R_Kl)[e] = fK[m]; }
+        if (lane < 32) RL(R_kf)[lane] = fkf;
+        if (lane < 42) RL(R_ew)[lane] = few;
+        if (lane < NX) RL(R_rdef)[lane] = frd;
+        if (k < N - 1) fetch(k + 1);
         BMPC_SYNC();
         if (lane < NX) RL(R_dzeta)[lane] = RL(R_dx)[lane];
         else if (lane < NZ) {
@@ -449,7 +706,8 @@ BMPC_DEV bool ric_forward(const PipeArgs& A, LDSD* lds, int b, int lane, double 
 }
 
 // lds: RIC_LDS_DOUBLES.  One workgroup (one wavefront) per entry of the eval list.
-BMPC_DEV void k_ric_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
+template <int NT>
+BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
     const int count = A.L.cnt[0];
     if (blk >= count) return;
     const int b = A.L.eval[blk];
@@ -460,40 +718,51 @@ BMPC_DEV void k_ric_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
     // pinned part of x_1 and its defect
     if (lane == 0) {
         double x1fix[24];
-        x1fix_eval(lbx, N, o.dt, x1fix);
+        x1fix_eval((GCD)lbx, N, o.dt, x1fix);
         for (int i = 0; i < 24; i++) RL(R_x1fix)[i] = x1fix[i];
     }
     BMPC_SYNC();
     if (lane < 24) RL(R_r0)[lane] = RL(R_x1fix)[lane] - A.zeta[(size_t)lane * A.NP + pair_of(A, b, 1)];
     // KKT partial sums of the pairs (fixed order)
-    double cmax = 0, csum = 0, cmin = 1e300, zsum = 0, prim = 0, theta = 0, logs = 0, nrows = 0, fsum = 0;
+    double cmax = 0, csum = 0, cmin = 1e300, zsum = 0, prim = 0, nrows = 0;
     if (lane < N - 1) {
         const double* P = A.part + pair_of(A, b, 1) + lane;
         cmax = P[PT_CMAX * A.NP]; csum = P[PT_CSUM * A.NP]; cmin = P[PT_CMIN * A.NP]; zsum = P[PT_ZSUM * A.NP];
-        prim = P[PT_PRIM * A.NP]; theta = P[PT_THETA * A.NP]; logs = P[PT_LOGS * A.NP]; nrows = P[PT_NROWS * A.NP];
-        fsum = P[PT_FVAL * A.NP];
+        prim = P[PT_PRIM * A.NP]; nrows = P[PT_NROWS * A.NP];
     }
-    cmax = wg_max(cmax, RL(R_red), lane); csum = wg_sum(csum, RL(R_red), lane); cmin = wg_min(cmin, RL(R_red), lane);
-    zsum = wg_sum(zsum, RL(R_red), lane); prim = wg_max(prim, RL(R_red), lane); theta = wg_sum(theta, RL(R_red), lane);
-    logs = wg_sum(logs, RL(R_red), lane); nrows = wg_sum(nrows, RL(R_red), lane); fsum = wg_sum(fsum, RL(R_red), lane);
+    cmax = rmax<NT>(cmax, RL(R_red), lane); csum = rsum<NT>(csum, RL(R_red), lane); cmin = rmin<NT>(cmin, RL(R_red), lane);
+    zsum = rsum<NT>(zsum, RL(R_red), lane); prim = rmax<NT>(prim, RL(R_red), lane);
+    nrows = rsum<NT>(nrows, RL(R_red), lane);
+    // park the (uniform) sums in LDS across the sweep calls instead of keeping them live in registers
+    if (lane == 0) {
+        LDSD* pk = RL(R_park);
+        pk[0] = cmax; pk[1] = csum; pk[2] = cmin; pk[3] = zsum; pk[4] = prim; pk[7] = nrows; pk[8] = st->f0;
+    }
+    BMPC_SYNC();
 
+#ifdef BMPC_PROFILE
+    if (lane < 16) RL(R_misc)[32 + lane] = 0.0;
+#endif
     int hess_mode = st->hess_mode, it = st->it, tries = 0;
     double hreg = st->hreg, mu = st->mu;
-    const double reg = 1e-9;
     bool first = true;
     int status = -1;
     for (;;) {
-        double lamsum, dual;
-        bool ok = ric_backward(A, lds, b, lane, hess_mode, reg, hreg, lamsum, dual);
+        if (lane == 0) RL(R_park)[12] = hreg;
+        BMPC_SYNC();
+        bool ok = ric_backward<NT>(A, lds, b, lane, hess_mode);
+        const double lamsum = RL(R_park)[9], dual = RL(R_park)[10];
         if (first) {
             first = false;
+            const LDSD* pk = RL(R_park);
+            const double cmax = pk[0], cmin = pk[2], zsum = pk[3], prim = pk[4], nrows = pk[7];
             const int neq = NX * (N - 2) + 24;
             double sd = fmax(100.0, (lamsum + zsum) / ((double)neq + nrows)) / 100.0;
             double sc = fmax(100.0, zsum / nrows) / 100.0;
             double err = fmax(fmax(dual / sd, prim), cmax / sc);
             if (err <= o.tol && dual <= 1.0 && prim <= 1e-4 && cmax <= 1e-4) { status = 0; break; }
             if (it >= o.max_iter) { status = 1; break; }
-            if (lane == 0) { st->err_prev = err; st->f0 = fsum; st->th0 = theta; st->ls0 = logs; }
+            if (lane == 0) st->err_prev = err;
             // monotone Fiacco-McCormick barrier update
             double emu = fmax(fmax(dual / sd, prim), fmax(fabs(cmax - mu), fabs(cmin - mu)) / sc);
             while (emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
@@ -501,7 +770,9 @@ BMPC_DEV void k_ric_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
                 emu = fmax(fmax(dual / sd, prim), fmax(cmax - mu, 0.0) / sc);
             }
         }
-        if (ok) ok = ric_forward(A, lds, b, lane, mu);
+        if (lane == 0) RL(R_park)[11] = mu;
+        BMPC_SYNC();
+        { RPROF_START(); if (ok) ok = ric_forward<NT>(A, lds, b, lane); RPROF(6); }
         if (ok) break;
         if (hess_mode) { hess_mode = 0; ++tries; }       // second-order terms not convex here: Gauss-Newton
         else {
@@ -509,9 +780,13 @@ BMPC_DEV void k_ric_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
             if (++tries > 12) { status = 3; break; }
         }
     }
+#ifdef BMPC_PROFILE
+    BMPC_SYNC();
+    if (lane < 16) atomicAdd(A.prof + lane, RL(R_misc)[32 + lane]);
+#endif
     if (lane == 0) {
         if (status >= 0) {
-            st->state = ST_DONE; st->status = status; st->fk = fsum;
+            st->state = ST_DONE; st->status = status; st->fk = RL(R_park)[8];
             BMPC_ATOMIC_INC(A.L.cnt + 5);
         } else {
             if (tries == 0) hreg = (hreg < 1e-8) ? 0.0 : hreg / 3;
@@ -527,19 +802,29 @@ BMPC_DEV void k_ric_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
 // ------------------------------------------------------------------------------------------
 BMPC_DEV void k_init_inst_body(const PipeArgs& A, int i) {
     if (i >= A.B) return;
-    InstState* st = A.st + i;
+    GST st = A.st + i;
     st->state = ST_EVAL; st->it = 0; st->status = 1; st->nfilt = 0; st->hess_mode = 0; st->bt = 0; st->armijo = 0; st->tries = 0;
     st->mu = A.o.mu_init; st->alpha = 0; st->ad = 0; st->ap = 0; st->hreg = 0; st->err_prev = 1e300; st->filt_mu = -1;
     st->theta_max = 1e300; st->theta_min = 0; st->fk = 0;
     A.L.eval[i] = i;
 }
 
+// after k_init: merit pieces (f, theta, sum log t) of the initial point
+BMPC_DEV void k_init_fin_body(const PipeArgs& A, int b) {
+    if (b >= A.B) return;
+    GST st = A.st + b;
+    GCD P = A.part + pair_of(A, b, 1);
+    double f1 = 0, th1 = 0, ls1 = 0;
+    for (int k = 0; k < A.N - 1; k++) { f1 += P[PT_F1 * A.NP + k]; th1 += P[PT_TH1 * A.NP + k]; ls1 += P[PT_LS1 * A.NP + k]; }
+    st->f0 = f1; st->th0 = th1; st->ls0 = ls1;
+}
+
 // after k_step: fraction-to-boundary step lengths, merit derivative, line-search start
 BMPC_DEV void k_ls0_body(const PipeArgs& A, int i) {
     if (i >= A.L.cnt[1]) return;
     const int b = A.L.step[i], N = A.N;
-    InstState* st = A.st + b;
-    const double* P = A.part + pair_of(A, b, 1);
+    GST st = A.st + b;
+    GCD P = A.part + pair_of(A, b, 1);
     double ap = 1.0, ad = 1.0, dbar = 0, dphif = 0;
     for (int k = 0; k < N - 1; k++) {
         ap = fmin(ap, P[PT_AP * A.NP + k]); ad = fmin(ad, P[PT_AD * A.NP + k]);
@@ -560,8 +845,8 @@ BMPC_DEV void k_ls0_body(const PipeArgs& A, int i) {
 BMPC_DEV void k_ls_body(const PipeArgs& A, int i) {
     if (i >= A.L.cnt[2]) return;
     const int b = A.L.trial[i], N = A.N;
-    InstState* st = A.st + b;
-    const double* P = A.part + pair_of(A, b, 1);
+    GST st = A.st + b;
+    GCD P = A.part + pair_of(A, b, 1);
     double f1 = 0, th1 = 0, ls1 = 0;
     for (int k = 0; k < N - 1; k++) { f1 += P[PT_F1 * A.NP + k]; th1 += P[PT_TH1 * A.NP + k]; ls1 += P[PT_LS1 * A.NP + k]; }
     const double mu = st->mu, th0 = st->th0, D = st->D, phi0 = st->phi0, alpha = st->alpha;
@@ -584,6 +869,7 @@ BMPC_DEV void k_ls_body(const PipeArgs& A, int i) {
             st->filt_phi[nf] = phi0 - 1e-5 * th0;
             st->nfilt = nf + 1;
         }
+        st->f0 = f1; st->th0 = th1; st->ls0 = ls1;      // merit pieces of the accepted point
         st->it += 1;
         st->hess_mode = (A.o.hess == 2 && st->err_prev < A.o.hess_switch) ? 1 : 0;
         st->state = ST_EVAL;
@@ -598,15 +884,15 @@ BMPC_DEV void k_ls_body(const PipeArgs& A, int i) {
 
 // rotate the list counters between super-steps (one thread)
 BMPC_DEV void k_rotate_body(const PipeArgs& A) {
-    int* c = A.L.cnt;
+    GI c = A.L.cnt;
     c[0] = c[3]; c[3] = 0; c[1] = 0; c[2] = c[4]; c[4] = 0;
 }
 
 // per-instance outputs after k_out
 BMPC_DEV void k_fin_body(const PipeArgs& A, int b) {
     if (b >= A.B) return;
-    const InstState* st = A.st + b;
-    const double* P = A.part + pair_of(A, b, 1);
+    const GST st = A.st + b;
+    GCD P = A.part + pair_of(A, b, 1);
     double v = 0;
     for (int k = 0; k < A.N - 1; k++) v += P[PT_F1 * A.NP + k];
     A.viol[b] = v;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libboundmpc_hip.so")
+LIB_PATH = os.environ.get("BMPC_LIB") or os.path.join(_HERE, "csrc", "libboundmpc_hip.so")   # BMPC_LIB: experiment builds
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 
@@ -20,7 +20,8 @@ class BmpcOpts(ctypes.Structure):
                 ("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("device", ctypes.c_int),
                 ("hess", ctypes.c_int), ("hess_switch", ctypes.c_double), ("mu_init", ctypes.c_double),
                 ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
-                ("max_batch", ctypes.c_int), ("blocks_per_cu", ctypes.c_int), ("waves_per_instance", ctypes.c_int)]
+                ("max_batch", ctypes.c_int), ("blocks_per_cu", ctypes.c_int), ("waves_per_instance", ctypes.c_int),
+                ("engine", ctypes.c_int)]
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",

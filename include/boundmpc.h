@@ -38,7 +38,9 @@ typedef struct {
     double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule */
     int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
     int blocks_per_cu;  /* resident workgroups per CU (0 = default 3) */
-    int waves_per_instance; /* 1 (one wavefront per instance, default), 2 or 4 wavefronts sharing one LDS image */
+    int waves_per_instance; /* engine 1 only: 1, 2 or 4 wavefronts sharing one LDS image */
+    int engine;         /* 0 (default) batch-synchronous pipeline: thread-per-(instance,stage) evaluation kernels +
+                           wavefront-per-instance LDS Riccati kernel; 1 persistent one-wavefront-per-instance kernel */
 } bmpc_opts;
 
 void bmpc_default_opts(bmpc_opts* o, int N);
@@ -66,7 +68,9 @@ int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double* lbx, const
                const double* p, double* x, double* g, double* lam_g, double* lam_x, double* f,
                int* iters, int* status, double* viol);
 
-/* Same with DEVICE pointers, asynchronous on `stream` (a hipStream_t); no host sync. */
+/* Same with DEVICE pointers; all work is enqueued on `stream` (a hipStream_t).  The call returns
+ * when the batch is solved: the interior-point iteration count is data dependent, so the host
+ * polls the number of unfinished instances between bursts of launches (engine 0). */
 int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
                    const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
                    int* d_iters, int* d_status, double* d_viol, void* stream);

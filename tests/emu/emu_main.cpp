@@ -18,6 +18,7 @@ static thread_local int t_lane = 0;
 #define BMPC_HD inline
 #define BMPC_NOINL
 typedef double LDSD;
+#define BMPC_AS1
 #define BMPC_SYNC() g_bar->arrive_and_wait()
 #define BMPC_LANE() t_lane
 #ifndef BMPC_NT

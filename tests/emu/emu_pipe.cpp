@@ -18,6 +18,19 @@ static thread_local int t_lane = 0;
 #define BMPC_HD inline
 #define BMPC_NOINL
 typedef double LDSD;
+typedef double bmpc_v2d __attribute__((vector_size(16)));
+typedef bmpc_v2d LDSV2;
+#define BMPC_RSQRT(x) (1.0 / std::sqrt(x))
+#define BMPC_LDS_ADD(ptr, v) (*(ptr) += (v))
+#define BMPC_AS1
+template <int NCH, int NT> static inline void bmpc_async_copy(const double* gsrc, double* lds_dst, int lane) {
+    const int wave = lane >> 6, wl = lane & 63;
+    for (int i = 0; i < (NCH + NT / 64 - 1) / (NT / 64); i++) {
+        const int c = i * (NT / 64) + wave;
+        if (c < NCH) { lds_dst[128 * c + 2 * wl] = gsrc[128 * c + 2 * wl]; lds_dst[128 * c + 2 * wl + 1] = gsrc[128 * c + 2 * wl + 1]; }
+    }
+}
+#define BMPC_ASYNC_WAIT() do {} while (0)
 #define BMPC_SYNC() g_bar->arrive_and_wait()
 #define BMPC_LANE() t_lane
 #define BMPC_NT 64
@@ -32,13 +45,16 @@ using std::fmin;
 #include "../../boundplanner_amd/csrc/bmpc_robot.hpp"
 
 using namespace bmpc;
+#ifndef EMU_RIC_NT
+#define EMU_RIC_NT 128
+#endif
 
-template <class F> static void launch(int nblocks, F body) {
+template <class F> static void launch(int nblocks, F body, int nt = 64) {
     if (nblocks <= 0) return;
-    std::barrier<> bar(64);
+    std::barrier<> bar(nt);
     g_bar = &bar;
     std::vector<std::thread> th;
-    for (int l = 0; l < 64; l++)
+    for (int l = 0; l < nt; l++)
         th.emplace_back([&, l] {
             t_lane = l;
             for (int blk = 0; blk < nblocks; blk++) body(blk, l);
@@ -52,7 +68,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
                               int* iters, int* status, double* viol, int verbose) {
     RobotConst rc;
     fill_robot_const(rc);
-    PipeArgs A;
+    PipeArgs A;   // emulation: BMPC_AS1 is empty, host and device views coincide
     A.B = B; A.N = N;
     A.o = SolverOpts{N, dt, tol, max_iter, hess, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps};
     A.rc = &rc;
@@ -71,18 +87,20 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     A.L.eval = l_eval.data(); A.L.step = l_step.data(); A.L.trial = l_trial.data();
     A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
     A.tbl = tbl.data();
-    std::vector<double> lds(std::max(EM_DOUBLES, RIC_LDS_DOUBLES) + 64);
+    std::vector<double> lds(std::max(EM_DOUBLES + 8, RIC_LDS_DOUBLES) + 64);
     const int nb_inst = (B + 63) / 64, nw = waves_for(N, B);
     cnt[0] = B;
     launch(nb_inst, [&](int blk, int l) { k_init_inst_body(A, blk * 64 + l); });
     launch(nw, [&](int blk, int l) { k_init_body(A, blk, l); });
+    launch(nb_inst, [&](int blk, int l) { k_init_fin_body(A, blk * 64 + l); });
     int steps = 0;
     for (; steps < 12 * (max_iter + 2); steps++) {
         int nact = B - cnt[5];
         if (nact <= 0) break;
         if (verbose) printf("step %d: n_eval %d n_trial %d done %d\n", steps, cnt[0], cnt[2], cnt[5]);
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
-        launch(cnt[0], [&](int blk, int l) { k_ric_body(A, blk, l, lds.data()); });
+        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
+        launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l); });
         launch((cnt[1] + 63) / 64, [&](int blk, int l) { k_ls0_body(A, blk * 64 + l); });
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l); });
