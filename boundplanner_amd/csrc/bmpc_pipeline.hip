@@ -11,10 +11,10 @@ using namespace bmpc;
 
 // waves per SIMD the register allocator must leave room for (latency hiding vs spills)
 #ifndef BMPC_PAIR_WPS
-#define BMPC_PAIR_WPS 2
+#define BMPC_PAIR_WPS 1
 #endif
 #ifndef BMPC_RIC_WPS
-#define BMPC_RIC_WPS 2
+#define BMPC_RIC_WPS 1
 #endif
 
 // the launch argument is the host view of the argument block; device code reads it through the
