@@ -7,7 +7,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/boundmpc.h"
@@ -42,6 +44,10 @@ struct bmpc_handle {
     int* d_pipe_tbl = nullptr;     // scatter table of the stage record
     int* h_cnt = nullptr;          // pinned host copy of the counters
     int last_steps = 0;
+    // asynchronous solves: one in flight per handle, driven by a worker thread on the handle's stream
+    std::thread worker;
+    int worker_rc = 0;
+    std::atomic<int> n_active{0};  // unfinished instances of the solve in flight (updated at every readback)
     // staging for the host-pointer entry
     double *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr, *d_x = nullptr, *d_g = nullptr,
            *d_f = nullptr, *d_viol = nullptr;
@@ -62,6 +68,8 @@ struct bmpc_handle {
             return 2;                                                                     \
         }                                                                                 \
     } while (0)
+
+static int pipe_ensure(bmpc_handle* h, int B);
 
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
@@ -109,11 +117,13 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
+    if (o->engine == 0 && o->max_batch > 0) return pipe_ensure(h, o->max_batch);   // workspace up front
     return 0;
 }
 
 extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (!h) return;
+    if (h->worker.joinable()) h->worker.join();
     double* bufs[] = {h->d_x0, h->d_lbx, h->d_ubx, h->d_p, h->d_x, h->d_g, h->d_f, h->d_viol, h->d_ws};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->d_iters) (void)hipFree(h->d_iters);
@@ -210,6 +220,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     // instances leave the work lists.  The host only needs the number still active to size the
     // grids (an upper bound is enough) and to stop: read back every few super-steps.
     int n_act = B, steps = 0;
+    h->n_active.store(B);
     const int max_steps = 12 * (h->o.max_iter + 2);
     while (n_act > 0 && steps < max_steps) {
         int burst = steps < 8 ? 8 : 4;
@@ -217,6 +228,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
         HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         n_act = B - h->h_cnt[5];
+        h->n_active.store(n_act);
     }
     h->last_steps = steps;
     HIPCHK(h, bmpc_pipe_launch_out(&A, st));
@@ -259,6 +271,41 @@ extern "C" int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const d
     }
     HIPCHK(h, hipSetDevice(h->o.device));
     return launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, (hipStream_t)stream);
+}
+
+// Asynchronous form of bmpc_solve_dev: returns at once; the data-dependent launch sequence is driven by
+// a worker thread on the handle's own stream.  One solve in flight per handle (a second call waits for
+// the first).  Two handles used alternately overlap the straggler tail of one batch (few active
+// instances, launch-latency bound) with the bulk of the next.
+// unfinished instances of the solve in flight on this handle (0 when idle): lets a caller that keeps
+// several batches in flight start the next one when the previous has left its bulk phase
+extern "C" int bmpc_active(bmpc_handle* h) { return h ? h->n_active.load() : 0; }
+
+extern "C" int bmpc_wait(bmpc_handle* h) {
+    if (!h) return 1;
+    if (h->worker.joinable()) h->worker.join();
+    int rc = h->worker_rc;
+    h->worker_rc = 0;
+    return rc;
+}
+
+extern "C" int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
+                                    const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
+                                    int* d_iters, int* d_status, double* d_viol) {
+    if (!h || B < 0 || !d_x0 || !d_lbx || !d_ubx || !d_p || !d_x || !d_f || !d_iters || !d_status || !d_viol) {
+        if (h) h->err = "bmpc_solve_dev_async: null argument";
+        return 1;
+    }
+    int rc = bmpc_wait(h);
+    if (rc) return rc;
+    h->n_active.store(B);
+    h->worker = std::thread([=]() {
+        if (hipSetDevice(h->o.device) != hipSuccess) { h->err = "hipSetDevice failed in the worker"; h->worker_rc = 2; return; }
+        int r = launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, h->stream);
+        if (r == 0 && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed in the worker"; r = 2; }
+        h->worker_rc = r;
+    });
+    return 0;
 }
 
 static int ensure_cap(bmpc_handle* h, int B, bool want_g) {

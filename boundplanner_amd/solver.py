@@ -25,7 +25,8 @@ class BmpcOpts(ctypes.Structure):
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
-           "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_fk", "bmpc_last_kernel_ms",
+           "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_solve_dev_async", "bmpc_wait", "bmpc_active", "bmpc_fk",
+           "bmpc_last_kernel_ms",
            "bmpc_debug_phase_cycles"]
 
 _lib = None
@@ -46,6 +47,9 @@ def load_library():
         lib.bmpc_gbounds.argtypes = [ctypes.c_void_p, _dp, _dp]
         lib.bmpc_solve.argtypes = [ctypes.c_void_p, ctypes.c_int] + [_dp] * 4 + [_dp] * 4 + [_dp, _ip, _ip, _dp]
         lib.bmpc_solve_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_void_p]
+        lib.bmpc_solve_dev_async.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10
+        lib.bmpc_wait.argtypes = [ctypes.c_void_p]
+        lib.bmpc_active.argtypes = [ctypes.c_void_p]
         lib.bmpc_fk.argtypes = [ctypes.c_void_p, ctypes.c_int] + [_dp] * 7
         lib.bmpc_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
         _lib = lib
@@ -110,6 +114,19 @@ class HipBoundMPC:
         rc = self.lib.bmpc_solve_dev(self._h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g or None, d_f, d_iters, d_status,
                                      d_viol, stream or None)
         self._chk(rc, "bmpc_solve_dev")
+
+    def solve_dev_async(self, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_f, d_iters, d_status, d_viol, d_g=0):
+        """Returns at once; the solve runs on the handle's own stream (one in flight per handle)."""
+        rc = self.lib.bmpc_solve_dev_async(self._h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g or None, d_f, d_iters,
+                                           d_status, d_viol)
+        self._chk(rc, "bmpc_solve_dev_async")
+
+    def wait(self):
+        self._chk(self.lib.bmpc_wait(self._h), "bmpc_wait")
+
+    def active(self):
+        """Unfinished instances of the solve in flight (0 when idle)."""
+        return self.lib.bmpc_active(self._h)
 
     def last_kernel_ms(self):
         ms = ctypes.c_float()

@@ -75,6 +75,17 @@ int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lb
                    const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
                    int* d_iters, int* d_status, double* d_viol, void* stream);
 
+/* Asynchronous form: returns at once, the solve runs on the handle's own stream driven by a worker
+ * thread; inputs must already be complete on the device.  One solve in flight per handle;
+ * bmpc_wait() blocks until it has finished and returns its status.  Two handles used alternately
+ * overlap the straggler tail of one batch with the bulk of the next (bench.py). */
+int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
+                         const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
+                         int* d_iters, int* d_status, double* d_viol);
+int bmpc_wait(bmpc_handle* h);
+/* unfinished instances of the solve in flight on this handle (0 when idle) */
+int bmpc_active(bmpc_handle* h);
+
 /* Batched kinematics (RobotModel.py:146-267): ee_pos [B][3], ee_rot [B][9] row-major,
  * col_pts [B][18] (joint_3..joint_7 origins, link4_col_link), jac [B][42] (6x7 geometric,
  * LOCAL_WORLD_ALIGNED), dvdq [B][42] = d(J dq)/dq.  Host pointers; outputs may be NULL. */
