@@ -261,10 +261,18 @@ def norm_2(x):
     return M(np.sqrt(np.sum(a * a)))
 
 
-def exp(x): return M(np.exp(_arr(x)))
-def sqrt(x): return M(np.sqrt(_arr(x)))
-def sin(x): return M(np.sin(_arr(x)))
-def cos(x): return M(np.cos(_arr(x)))
+def _elem(fn, x):
+    # like CasADi on plain numbers: numeric in, numeric out (the host-side numpy code of the reference
+    # calls ca.sin / ca.cos on floats, optimization_functions.py:101-103)
+    if isinstance(x, M):
+        return M(fn(_arr(x)))
+    return fn(np.asarray(x, dtype=float)) if np.ndim(x) else float(fn(x))
+
+
+def exp(x): return _elem(np.exp, x)
+def sqrt(x): return _elem(np.sqrt, x)
+def sin(x): return _elem(np.sin, x)
+def cos(x): return _elem(np.cos, x)
 
 
 def if_else(c, a, b):

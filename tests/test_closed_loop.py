@@ -1,0 +1,128 @@
+"""Rows a9, a11, a12, a13, a15 of SURVEY.md section 8: the host logic around the solver call.
+
+tests/golden/closed_loop.npz is a 37-step closed-loop trace of the REFERENCE's own BoundMPC.update /
+BoundMPC.step (prep + compute_return_data), ReferencePath and integrate_joint, produced by
+tests/golden/gen/gen_closed_loop.py with the CPU oracle in the solver slot.  Replaying the recorded
+solutions through this package's mirror (BoundMPC.prepare -> solver -> post.compute_return_data ->
+MPCNode.step) must reproduce, step by step, the solver-call arguments the reference built (start
+vector, bounds, the 875 parameters), the post-processed trajectories and all carried state
+(split indices, segment switch with via-point adaptation, rotation reference, path parameter)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from boundplanner_amd.mpc_node import MPCNode
+from boundplanner_amd.params import Params, get_default_params
+from boundplanner_amd.robot_model import RobotModel
+
+
+class _DM:
+    def __init__(self, a):
+        self.a = np.asarray(a, float)
+
+    def full(self):
+        return self.a.reshape(-1, 1)
+
+
+class ReplaySolver:
+    """Returns the recorded solution of step `k` after checking that the call arguments equal the
+    ones the reference produced at that step."""
+
+    def __init__(self, g, tol):
+        self.g, self.k, self.tol, self.maxdiff = g, 0, tol, {}
+        self._stats = {}
+
+    def __call__(self, x0, lbx, ubx, p, lbg=None, ubg=None):
+        k = self.k
+        big = lambda a: np.nan_to_num(np.asarray(a, float), posinf=1e20, neginf=-1e20)
+        for name, mine in (("x0", x0), ("lbx", lbx), ("ubx", ubx), ("p", p)):
+            d = np.abs(big(mine) - big(self.g["call_" + name][k])).max()
+            self.maxdiff[name] = max(self.maxdiff.get(name, 0.0), d)
+            assert d < self.tol, f"step {k}: solver argument {name} differs from the reference's by {d}"
+        self._stats = {"iter_count": int(self.g["iters"][k]), "success": int(self.g["status"][k]) == 0,
+                       "return_status": "replay", "g_viol": float(self.g["viol"][k])}
+        self.k += 1
+        x = self.g["call_x"][k]
+        return {"x": _DM(x), "g": _DM(self.g["call_g"][k]), "lam_g": _DM(0 * self.g["call_g"][k]), "lam_x": _DM(0 * x),
+                "f": _DM([0.0])}
+
+    def stats(self):
+        return dict(self._stats)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "closed_loop.npz"))
+
+
+def _fk(q, dq=None):
+    return O.fk_batch(q, dq)
+
+
+def test_closed_loop_replay_matches_reference(golden):
+    g = golden
+    N = int(g["N"])
+    base = get_default_params()
+    assert np.array_equal(base.weights, g["weights"])
+    params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    solver = ReplaySolver(g, tol=1e-9)
+    q0 = g["in_q"][0]
+    node = MPCNode(q0, RobotModel(_fk), lambda n, dt: solver, params=params)
+    n_steps, n_update = g["in_q"].shape[0], int(g["n_update"])
+    for k in range(n_steps):
+        if k == n_update:      # MPCNode.update_reference with the planned via path
+            node.update_reference([p.copy() for p in g["via_p_via"]], [r.copy() for r in g["via_r_via"]],
+                                  [b.copy() for b in g["via_bp1"]], [b.copy() for b in g["via_br1"]],
+                                  [e.copy() for e in g["via_e_r_bound"]], [a.copy() for a in g["via_a_sets"]],
+                                  [b.copy() for b in g["via_b_sets"]], [])
+        for key in ("q", "dq", "ddq", "jerk", "v", "qf"):
+            assert np.abs(getattr(node, key) - g["in_" + key][k]).max() < 1e-9, (k, key)
+        traj = node.step()
+        for key in ("p", "v", "q", "dq", "ddq", "dddq", "phi", "dphi"):
+            assert np.abs(traj[key] - g["traj_" + key][k]).max() < 1e-9, (k, key)
+        m = node.mpc
+        assert list(m.split_idxs) == list(g["split_idxs"][k]), k
+        assert int(m.switch) == int(g["switch"][k]) and m.error_count == int(g["error_count"][k]), k
+        assert m.ref_path.sector == int(g["sector"][k]), k
+        for mine, key in ((m.pr_ref, "pr_ref"), (m.iw_ref, "iw_ref"), (m.phi_current, "phi_current"),
+                          (m.dphi_current, "dphi_current"), (m.phi_max, "phi_max"), (m.slacks0, "slacks0"),
+                          (m.ref_path.pd, "rp_pd"), (m.ref_path.phi_switch, "rp_phi_switch"),
+                          (node.ref_data["p"][1], "ref_p1"), (node.ref_data["p"][0], "ref_p0")):
+            assert np.abs(np.asarray(mine) - g[key][k]).max() < 1e-9, (k, key)
+        for key in ("q", "dq", "ddq", "jerk", "v", "qf", "p_lie"):
+            assert np.abs(getattr(node, key) - g["out_" + key][k]).max() < 1e-9, (k, key)
+    # the scenario exercises a set switch with via-point adaptation and ends at the path end
+    assert g["switch"].sum() >= 1 and g["sector"][-1] == 1
+    assert node.mpc.phi_current[0] >= node.mpc.phi_max[0] - 0.001
+    print("max |argument - reference argument| over the run:", solver.maxdiff)
+
+
+@pytest.mark.gpu
+def test_closed_loop_hip_tracks_reference_trace(golden):
+    """The same closed loop with the HIP solver in the solver slot: same number of steps to the path
+    end, same switching step, trajectories within the stated solver tolerance of the golden trace
+    (the trace was produced with the CPU oracle as NLP solver)."""
+    from boundplanner_amd.solver import HipBoundMPC, HipNlpSolver
+    g = golden
+    N = int(g["N"])
+    base = get_default_params()
+    params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    be = HipBoundMPC(N)
+    node = MPCNode(g["in_q"][0], RobotModel(be.fk), lambda n, dt: HipNlpSolver(n, dt, backend=be), params=params)
+    n_steps, n_update = g["in_q"].shape[0], int(g["n_update"])
+    dmax = 0.0
+    for k in range(n_steps):
+        if k == n_update:
+            node.update_reference([p.copy() for p in g["via_p_via"]], [r.copy() for r in g["via_r_via"]],
+                                  [b.copy() for b in g["via_bp1"]], [b.copy() for b in g["via_br1"]],
+                                  [e.copy() for e in g["via_e_r_bound"]], [a.copy() for a in g["via_a_sets"]],
+                                  [b.copy() for b in g["via_b_sets"]], [])
+        traj = node.step()
+        dmax = max(dmax, np.abs(traj["p"] - g["traj_p"][k]).max())
+        assert list(node.mpc.split_idxs) == list(g["split_idxs"][k]), k
+        assert node.mpc.error_count == 0
+    assert dmax < 1e-3, dmax      # task-space trajectories over 37 closed-loop steps
+    assert node.mpc.phi_current[0] >= node.mpc.phi_max[0] - 0.001
+    assert abs(np.mean(node.iters) - g["iters"].mean()) < 1.0
