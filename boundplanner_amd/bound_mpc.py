@@ -164,9 +164,16 @@ class BoundMPC:
         w_curr = sol["x"].full().flatten()
         time_elapsed = time.perf_counter() - t0
         stats = self.solver.stats()
-        iters = stats["iter_count"]
+        traj_data, ref_data, err_data = self.finish(q0, dq0, ddq0, jerk_current, p0, w_curr, stats["success"],
+                                                    stats["g_viol"], aux, lam_g=sol["lam_g"], lam_x=sol["lam_x"])
+        return traj_data, ref_data, err_data, time_elapsed, stats["iter_count"]
+
+    # ------------------------------------------------------------------ step: after the solve
+    def finish(self, q0, dq0, ddq0, jerk_current, p0, w_curr, solver_success, g_viol, aux, lam_g=0, lam_x=0):
+        """BoundMPC.py:604-676 + compute_return_data: acceptance test, fallback to the previous solution,
+        post-processing.  Split from step() so that a batch of instances can share ONE batched solve."""
         self.slacks0 += w_curr[-6:]          # Q1: adds the last six dpslacks
-        success = stats["success"] or stats["g_viol"] < 1e-4   # Q8 (BoundMPC.py:613-617)
+        success = solver_success or g_viol < 1e-4   # Q8 (BoundMPC.py:613-617)
         using_previous = False
         if not success:
             self.error_count += 1
@@ -180,8 +187,6 @@ class BoundMPC:
             self.error_count = 0
             w_opt = w_curr
             self.prev_solution = cp.deepcopy(w_opt)
-            self.lam_g0, self.lam_x0 = sol["lam_g"], sol["lam_x"]
+            self.lam_g0, self.lam_x0 = lam_g, lam_x
         from .post import compute_return_data
-        traj_data, ref_data, err_data = compute_return_data(self, q0, dq0, ddq0, jerk_current, p0,
-                                                            w_opt, using_previous, aux)
-        return traj_data, ref_data, err_data, time_elapsed, iters
+        return compute_return_data(self, q0, dq0, ddq0, jerk_current, p0, w_opt, using_previous, aux)

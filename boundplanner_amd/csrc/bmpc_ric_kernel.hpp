@@ -600,9 +600,15 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
         BMPC_SYNC();
         RPROF(5);
     }
-    double lamsum = rsum<NT>(RL(R_acc)[lane], RL(R_red), lane);
-    double dual = rmax<NT>(RL(R_acc)[128 + lane], RL(R_red), lane);
-    if (lane == 0) { RL(R_park)[9] = lamsum; RL(R_park)[10] = dual; }     // results through LDS (see k_ric_body)
+    // |lambda| sum (lanes < 32 contribute) and dual-residual maximum (lanes < 41), in lane order
+    BMPC_SYNC();
+    if (lane < 2) {
+        double v = RL(R_acc)[128 * lane];
+        const int n = lane ? NZ : NX;
+#pragma unroll 4
+        for (int i = 1; i < n; i++) { double x = RL(R_acc)[128 * lane + i]; v = lane ? fmax(v, x) : v + x; }
+        RL(R_park)[9 + lane] = v;                         // results through LDS (see k_ric_body)
+    }
     BMPC_SYNC();
     return ok;
 }
@@ -617,30 +623,51 @@ BMPC_NOINL bool ric_forward(const PipeArgsH& A, LDSD* lds, int b, int lane) {
     bool ok = true;
     {
         double Pf[36], rhs[8];
+        BMPC_UNROLL
         for (int i = 0; i < 8; i++) {
             double s = RL(R_pv0)[24 + i] + mu * RL(R_pv1)[24 + i];
+            BMPC_UNROLL
             for (int j = 0; j < 24; j++) s += RL(R_P)[(24 + i) * LDP + j] * RL(R_r0)[j];
             rhs[i] = -s;
         }
 #define PF(i, j) Pf[(i) * ((i) + 1) / 2 + (j)]
+        BMPC_UNROLL
         for (int j = 0; j < 8; j++) {
             double d = RL(R_P)[(24 + j) * LDP + 24 + j];
+            BMPC_UNROLL
             for (int l = 0; l < j; l++) d -= PF(j, l) * PF(j, l);
             if (!(d > 0)) { ok = false; d = 1.0; }
             d = sqrt(d);
             PF(j, j) = d;
+            BMPC_UNROLL
             for (int i = j + 1; i < 8; i++) {
                 double s = RL(R_P)[(24 + i) * LDP + 24 + j];
+                BMPC_UNROLL
                 for (int l = 0; l < j; l++) s -= PF(i, l) * PF(j, l);
                 PF(i, j) = s / d;
             }
         }
-        for (int i = 0; i < 8; i++) { double s = rhs[i]; for (int l = 0; l < i; l++) s -= PF(i, l) * rhs[l]; rhs[i] = s / PF(i, i); }
-        for (int i = 7; i >= 0; i--) { double s = rhs[i]; for (int l = i + 1; l < 8; l++) s -= PF(l, i) * rhs[l]; rhs[i] = s / PF(i, i); }
+        BMPC_UNROLL
+        for (int i = 0; i < 8; i++) {
+            double s = rhs[i];
+            BMPC_UNROLL
+            for (int l = 0; l < i; l++) s -= PF(i, l) * rhs[l];
+            rhs[i] = s / PF(i, i);
+        }
+        BMPC_UNROLL
+        for (int i = 7; i >= 0; i--) {
+            double s = rhs[i];
+            BMPC_UNROLL
+            for (int l = i + 1; l < 8; l++) s -= PF(l, i) * rhs[l];
+            rhs[i] = s / PF(i, i);
+        }
 #undef PF
         BMPC_SYNC();
         if (lane < 24) RL(R_dx)[lane] = RL(R_r0)[lane];
-        if (lane == 0) for (int i = 0; i < 8; i++) RL(R_dx)[24 + i] = rhs[i];
+        if (lane == 0) {
+            BMPC_UNROLL
+            for (int i = 0; i < 8; i++) RL(R_dx)[24 + i] = rhs[i];
+        }
         BMPC_SYNC();
     }
     if (!ok) return false;
@@ -723,23 +750,29 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
     }
     BMPC_SYNC();
     if (lane < 24) RL(R_r0)[lane] = RL(R_x1fix)[lane] - A.zeta[(size_t)lane * A.NP + pair_of(A, b, 1)];
-    // KKT partial sums of the pairs (fixed order)
-    double cmax = 0, csum = 0, cmin = 1e300, zsum = 0, prim = 0, nrows = 0;
-    if (lane < N - 1) {
-        const double* P = A.part + pair_of(A, b, 1) + lane;
-        cmax = P[PT_CMAX * A.NP]; csum = P[PT_CSUM * A.NP]; cmin = P[PT_CMIN * A.NP]; zsum = P[PT_ZSUM * A.NP];
-        prim = P[PT_PRIM * A.NP]; nrows = P[PT_NROWS * A.NP];
+    // KKT partial sums of the pairs: staged in LDS [quantity][pair], then one lane per quantity adds them
+    // in pair order (fixed order -> reproducible; N - 1 <= 63 pairs)
+    {
+        LDSD* stg = RL(R_W);          // free until the backward sweep
+        if (lane < N - 1) {
+            const double* P = A.part + pair_of(A, b, 1) + lane;
+            stg[0 * 64 + lane] = P[PT_CMAX * A.NP]; stg[1 * 64 + lane] = P[PT_CSUM * A.NP]; stg[2 * 64 + lane] = P[PT_CMIN * A.NP];
+            stg[3 * 64 + lane] = P[PT_ZSUM * A.NP]; stg[4 * 64 + lane] = P[PT_PRIM * A.NP]; stg[5 * 64 + lane] = P[PT_NROWS * A.NP];
+        }
+        BMPC_SYNC();
+        if (lane < 6) {
+            const int kind = (lane == 0 || lane == 4) ? 1 : (lane == 2 ? 2 : 0);      // 0 sum, 1 max, 2 min
+            double v = stg[lane * 64];
+#pragma unroll 4
+            for (int k = 1; k < N - 1; k++) {
+                double x = stg[lane * 64 + k];
+                v = kind == 0 ? v + x : (kind == 1 ? fmax(v, x) : fmin(v, x));
+            }
+            RL(R_park)[lane == 5 ? 7 : lane] = v;        // cmax, csum, cmin, zsum, prim -> [0..4], nrows -> [7]
+        }
+        if (lane == 6) RL(R_park)[8] = st->f0;
+        BMPC_SYNC();
     }
-    cmax = rmax<NT>(cmax, RL(R_red), lane); csum = rsum<NT>(csum, RL(R_red), lane); cmin = rmin<NT>(cmin, RL(R_red), lane);
-    zsum = rsum<NT>(zsum, RL(R_red), lane); prim = rmax<NT>(prim, RL(R_red), lane);
-    nrows = rsum<NT>(nrows, RL(R_red), lane);
-    // park the (uniform) sums in LDS across the sweep calls instead of keeping them live in registers
-    if (lane == 0) {
-        LDSD* pk = RL(R_park);
-        pk[0] = cmax; pk[1] = csum; pk[2] = cmin; pk[3] = zsum; pk[4] = prim; pk[7] = nrows; pk[8] = st->f0;
-    }
-    BMPC_SYNC();
-
 #ifdef BMPC_PROFILE
     if (lane < 16) RL(R_misc)[32 + lane] = 0.0;
 #endif
