@@ -27,7 +27,7 @@ BMPC_INL void load_zeta(GCD arr, size_t NP, size_t pi, double* z) {
 }
 
 // kinematics + context at zeta (values only; Jacobian G computed by the caller when needed)
-BMPC_INL void stage_point(const PipeArgs& A, GCD pg, const double* iw0, int k, const DynC dc, StagePoint& S) {
+BMPC_INL void stage_point(const PipeArgs& A, PGP pg, const double* iw0, int k, const DynC dc, StagePoint& S) {
     nat_all(S.zeta, dc, S.y);
     kin_chain(A.rc, S.y + Z_Q, S.K);
     kin_jlin(S.K, S.Jl);
@@ -79,16 +79,16 @@ struct InitVisitor {
     template <int C> BMPC_INL void point_end() {}
 };
 
-BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane) {
+BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.B, N = A.N;
-    if (wave * (64 / (N - 1)) >= count) return;
+    if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
     const int k = m.k, n_w = 44 * N + 6;
     const DynC dc = make_dync(A.o.dt);
     GCD x0 = A.x0 + (size_t)m.b * n_w;
     GCD lbx = A.lbx + (size_t)m.b * n_w;
     GCD ubx = A.ubx + (size_t)m.b * n_w;
-    GCD pg = A.p + (size_t)m.b * NPAR;
+    PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds_par);
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
@@ -188,10 +188,8 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
     }
     BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
         size_t o = (size_t)s * A->NP + pi;
-        double t = A->t_t[o];
+        double t = A->t[o];          // read-only here: k_accept made t, z current (loads can run ahead)
         zz = A->z[o];
-        if (ad != 0.0) zz += ad * A->dzr[o];
-        if (valid) { A->t[o] = t; A->z[o] = zz; }
         r1 = 1.0 / t; sg = zz * r1; r0 = sg * (h + t);
         double c = t * zz;
         cmax = fmax(cmax, c); csum += c; cmin = fmin(cmin, c); zsum += zz;
@@ -291,10 +289,10 @@ struct PoseAsm {
 
 // pose rows of one stage in slot order, for any visitor exposing add<NA, SEL>(s, a, h)
 template <class V>
-BMPC_INL void walk_pose_rows(GCD pg, int N, int k, const double* y, const SegCtx& C, V& v) {
+BMPC_INL void walk_pose_rows(PGP pg, int N, int k, const double* y, const SegCtx& C, V& v) {
     const bool term = (k == N - 1);
     {
-        GCD a = pg + P_ASET + 45 * C.s;
+        PGP a = pg + P_ASET + 45 * C.s;
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
             double a3[3] = {a[rr], a[rr + 15], a[rr + 30]};
@@ -313,7 +311,7 @@ BMPC_INL void walk_pose_rows(GCD pg, int N, int k, const double* y, const SegCtx
     }
     v.template add<3, 0>(S_PHI, C.dpp, C.phi - (C.phiend + 0.005));
     if (term) {
-        GCD a = pg + P_ASET + 45 * C.n;
+        PGP a = pg + P_ASET + 45 * C.n;
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
             double an[3] = {a[rr], a[rr + 15], a[rr + 30]};
@@ -429,11 +427,11 @@ BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][
 // P17 blocks: for position I of the (q, dq, pi) block emit the three slack-column couplings, then
 // D, g0, g1, gz of that position (its diagonal rows are walked here), 7 fields
 template <int I>
-BMPC_INL void p17_emit_all(const PipeArgs& A, GCD pg, GCD lbx, GCD ubx, int k, const double* y, const KinT& K,
+BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, const double* y, const KinT& K,
                            const double Jl[3][7], const double G[6][7], double hdt, RowAcc& R, const PointAsm& PA,
                            const PoseAsm& P, const double* bv, Emitter& E) {
     if constexpr (I < 17) {
-        GCD wts = pg + P_W;
+        PGP wts = pg + P_W;
         double cO[6], cV[6];
         chain_cols<I>(K, Jl, G, hdt, cO, cV);
         BMPC_UNROLL
@@ -527,10 +525,10 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
 
 // DG entries: position I of the dg order
 template <int I>
-BMPC_INL void dg_emit_all(const PipeArgs& A, GCD pg, GCD lbx, GCD ubx, int k, bool term,
+BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, bool term,
                           const double* y, RowAcc& R, const PointAsm& PA, const PoseAsm& PO, Emitter& E) {
     if constexpr (I < 38) {
-        GCD wts = pg + P_W;
+        PGP wts = pg + P_W;
         DiagAsm dgv;
         dgv.R = &R;
         dgv.begin();
@@ -570,14 +568,14 @@ BMPC_INL void dg_emit_all(const PipeArgs& A, GCD pg, GCD lbx, GCD ubx, int k, bo
 // lds: EM_DOUBLES doubles per wave
 BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const int count = A.L.cnt[0], N = A.N;
-    if (wave * (64 / (N - 1)) >= count) return;
+    if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
     GCD lbx = A.lbx + (size_t)m.b * n_w;
     GCD ubx = A.ubx + (size_t)m.b * n_w;
-    GCD pg = A.p + (size_t)m.b * NPAR;
+    PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds + EM_DOUBLES + 8);
     const double ad = A.st[m.b].ad;
     double iw0[3];
     BMPC_UNROLL
@@ -586,10 +584,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     E.init(lds, A.hrec, lane, m.pi, m.valid);
     BMPC_SYNC();
     StagePoint S;
-    load_zeta(A.zeta_t, A.NP, m.pi, S.zeta);
-    if (m.valid)
-        BMPC_UNROLL
-        for (int i = 0; i < NZ; i++) A.zeta[(size_t)i * A.NP + m.pi] = S.zeta[i];
+    load_zeta(A.zeta, A.NP, m.pi, S.zeta);
     stage_point(A, pg, iw0, k, dc, S);
     double G[6][7];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);
@@ -676,7 +671,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         if (!term) {
             double zn[NX];
             BMPC_UNROLL
-            for (int i = 0; i < NX; i++) zn[i] = A.zeta_t[(size_t)i * A.NP + m.pi + 1];
+            for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1];
             defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
             BMPC_UNROLL
             for (int i = 0; i < NX; i++) prim = fmax(prim, fabs(rdef[i]));
@@ -707,7 +702,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
 // ------------------------------------------------------------------------------------------
 BMPC_DEV void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const int count = A.L.cnt[0], N = A.N;
-    if (A.o.hess != 2 || wave * (64 / (N - 1)) >= count) return;
+    if (A.o.hess != 2 || wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
     if (lane == 0) lds[EM_DOUBLES] = 0.0;
     BMPC_SYNC();
@@ -748,18 +743,9 @@ struct StepVisitor {
     const double* dy;     // natural step
     const double* dzt;    // zeta step
     double dloc[6], dpt[6][3];
-    double apn, apd, adn, add, dbar;    // max(-dt/t) = apn/apd, max(-dz/z) = adn/add
     BMPC_INL void fin(int s, double h, double adot) {
-        size_t o = (size_t)s * A->NP + pi;
-        double t = A->t[o], z = A->z[o];
-        double rt = 1.0 / t;
-        double dti = -(h + t) - adot;
-        double dzi = (mu - t * z - z * dti) * rt;
-        if (valid) { A->dt[o] = dti; A->dzr[o] = dzi; }
-        // fraction to the boundary: largest -dt/t and -dz/z, kept as fractions (no division per row)
-        if (-dti * apd > apn * t) { apn = -dti; apd = t; }
-        if (-dzi * add > adn * z) { adn = -dzi; add = z; }
-        dbar -= mu * dti * rt;
+        // dt = -(h + t) - a.d = c - t: the part that needs no row data, finished by k_rowstep
+        if (valid) A->dt[(size_t)s * A->NP + pi] = -h - adot;
     }
     BMPC_INL void skip(int) {}
     BMPC_INL void diag(int s, int pos, double coef, double h) { fin(s, h, coef * dy[pos]); }
@@ -797,17 +783,17 @@ BMPC_INL void point_dirs(const KinT& K, const double* dyq, double dpt[6][3]) {
     }
 }
 
-BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
+BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[1], N = A.N;
-    if (wave * (64 / (N - 1)) >= count) return;
+    if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.step, count, wave, lane);
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
     GCD lbx = A.lbx + (size_t)m.b * n_w;
     GCD ubx = A.ubx + (size_t)m.b * n_w;
-    GCD pg = A.p + (size_t)m.b * NPAR;
-    GCD wts = pg + P_W;
+    PGP pg = stage_params(A, A.L.step, count, wave, lane, m, lds_par);
+    PGP wts = pg + P_W;
     const double mu = A.st[m.b].mu;
     double iw0[3];
     BMPC_UNROLL
@@ -823,7 +809,7 @@ BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
     nat_all(dzt, dc, dy);
     StepVisitor V;
     V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu);
-    V.dy = dy; V.dzt = dzt; V.apn = 0.0; V.apd = 1.0; V.adn = 0.0; V.add = 1.0; V.dbar = 0.0;
+    V.dy = dy; V.dzt = dzt;
     double dv[6];
     BMPC_UNROLL
     for (int a = 0; a < 6; a++) {
@@ -860,9 +846,7 @@ BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
     if (m.valid) {
         GD P = A.part + m.pi;
-        // step lengths tau / max(-d/x), capped at 1 by k_ls0
-        P[PT_AP * A.NP] = (V.apn > 0) ? V.tau * V.apd / V.apn : 1.0; P[PT_AD * A.NP] = (V.adn > 0) ? V.tau * V.add / V.adn : 1.0;
-        P[PT_DBAR * A.NP] = V.dbar; P[PT_DPHIF * A.NP] = dphi_f;
+        P[PT_DPHIF * A.NP] = dphi_f;
     }
 }
 
@@ -870,13 +854,9 @@ BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane) {
 // k_trial: zeta + alpha dz, t + alpha dt -> f, theta, sum log t
 // ------------------------------------------------------------------------------------------
 struct TrialVisitor {
-    const PipeArgs* A; size_t pi; bool valid; double alpha;
-    double th, ls;
+    const PipeArgs* A; size_t pi; bool valid;
     BMPC_INL void fin(int s, double h) {
-        size_t o = (size_t)s * A->NP + pi;
-        double t = A->t[o] + alpha * A->dt[o];
-        if (valid) A->t_t[o] = t;
-        th += fabs(h + t); ls += log(t);
+        if (valid) A->t_t[(size_t)s * A->NP + pi] = h;     // finished in place by k_rowtrial: t + alpha dt
     }
     BMPC_INL void skip(int) {}
     BMPC_INL void diag(int s, int, double, double h) { fin(s, h); }
@@ -887,16 +867,16 @@ struct TrialVisitor {
     template <int C> BMPC_INL void point_end() {}
 };
 
-BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
+BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[2], N = A.N;
-    if (wave * (64 / (N - 1)) >= count) return;
+    if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.trial, count, wave, lane);
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
     GCD lbx = A.lbx + (size_t)m.b * n_w;
     GCD ubx = A.ubx + (size_t)m.b * n_w;
-    GCD pg = A.p + (size_t)m.b * NPAR;
+    PGP pg = stage_params(A, A.L.trial, count, wave, lane, m, lds_par);
     const double alpha = A.st[m.b].alpha;
     double iw0[3];
     BMPC_UNROLL
@@ -909,9 +889,9 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
         for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
     stage_point(A, pg, iw0, k, dc, S);
     TrialVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.th = 0; V.ls = 0;
+    V.A = &A; V.pi = m.pi; V.valid = m.valid;
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
-    double th = V.th;
+    double th = 0;     // dynamics / initial-state part of theta; the row part is added by k_rowtrial
     if (!term) {
         double zn[NX], rdef[NX];
         BMPC_UNROLL
@@ -928,7 +908,92 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
     }
     if (m.valid) {
         GD P = A.part + m.pi;
-        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th; P[PT_LS1 * A.NP] = V.ls;
+        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming row kernels: 256 threads = 64 pairs x 4 slot groups; a thread walks slots g, g+4, ...
+// These carry every load-modify-store on the row arrays (t, z, dt, dz_row): little register state, so
+// they run at full occupancy and hide the HBM latency that a thread-per-pair kernel cannot.
+// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 3 * 256 doubles.
+// ------------------------------------------------------------------------------------------
+constexpr int ROW_GROUPS = 4;
+
+// k_accept: the accepted trial becomes the iterate: zeta = zeta_t, t = t_t, z += alpha_dual * dz_row
+BMPC_DEV void k_accept_body(const PipeArgs& A, int wave, int tid) {
+    const int count = A.L.cnt[0], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    const int lane = tid & 63, g = tid >> 6;
+    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    if (!m.valid) return;
+    const double ad = A.st[m.b].ad;
+    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
+        size_t o = (size_t)s * A.NP + m.pi;
+        double z = A.z[o];
+        if (z > 0.0) {
+            A.t[o] = A.t_t[o];
+            if (ad != 0.0) A.z[o] = z + ad * A.dzr[o];
+        }
+    }
+    for (int i = g; i < NZ; i += ROW_GROUPS) A.zeta[(size_t)i * A.NP + m.pi] = A.zeta_t[(size_t)i * A.NP + m.pi];
+}
+
+// k_rowstep: dt = c - t (c from k_step), dz_row = (mu - t z - z dt) / t, fraction-to-boundary step
+// lengths and the barrier part of the merit derivative, reduced over the pair in slot-group order
+BMPC_DEV void k_rowstep_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
+    const int count = A.L.cnt[1], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    const int lane = tid & 63, g = tid >> 6;
+    PairMap m = pair_map(A, A.L.step, count, wave, lane);
+    const double mu = A.st[m.b].mu, tau = fmax(0.99, 1.0 - mu);
+    double rp = 0.0, rd = 0.0, dbar = 0.0;       // max(-dt/t), max(-dz/z), -mu sum dt/t
+    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
+        size_t o = (size_t)s * A.NP + m.pi;
+        double z = A.z[o];
+        if (z > 0.0) {
+            double t = A.t[o], rt = 1.0 / t;
+            double dti = A.dt[o] - t;
+            double dzi = (mu - t * z - z * dti) * rt;
+            if (m.valid) { A.dt[o] = dti; A.dzr[o] = dzi; }
+            rp = fmax(rp, -dti * rt); rd = fmax(rd, -dzi / z);
+            dbar -= mu * dti * rt;
+        }
+    }
+    lds[tid] = rp; lds[256 + tid] = rd; lds[512 + tid] = dbar;
+    BMPC_SYNC();
+    if (g == 0 && m.valid) {
+        double db = 0.0;
+        for (int q = 0; q < ROW_GROUPS; q++) { rp = fmax(rp, lds[64 * q + lane]); rd = fmax(rd, lds[256 + 64 * q + lane]); db += lds[512 + 64 * q + lane]; }
+        GD P = A.part + m.pi;
+        P[PT_AP * A.NP] = (rp > 0) ? tau / rp : 1.0; P[PT_AD * A.NP] = (rd > 0) ? tau / rd : 1.0; P[PT_DBAR * A.NP] = db;
+    }
+}
+
+// k_rowtrial: t_t = t + alpha dt (in place over the h values k_trial left there), theta += |h + t_t|,
+// sum log t_t, reduced over the pair in slot-group order and added to k_trial's partials
+BMPC_DEV void k_rowtrial_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
+    const int count = A.L.cnt[2], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    const int lane = tid & 63, g = tid >> 6;
+    PairMap m = pair_map(A, A.L.trial, count, wave, lane);
+    const double alpha = A.st[m.b].alpha;
+    double th = 0.0, ls = 0.0;
+    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
+        size_t o = (size_t)s * A.NP + m.pi;
+        if (A.z[o] > 0.0) {
+            double tn = A.t[o] + alpha * A.dt[o];
+            th += fabs(A.t_t[o] + tn); ls += log(tn);
+            if (m.valid) A.t_t[o] = tn;
+        }
+    }
+    lds[tid] = th; lds[256 + tid] = ls;
+    BMPC_SYNC();
+    if (g == 0 && m.valid) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < ROW_GROUPS; q++) { a += lds[64 * q + lane]; b += lds[256 + 64 * q + lane]; }
+        GD P = A.part + m.pi;
+        P[PT_TH1 * A.NP] += a; P[PT_LS1 * A.NP] = b;
     }
 }
 
@@ -938,7 +1003,7 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane) {
 struct OutVisitor {
     double viol;
     GD gi;               // inequality rows of this stage in the reference order, or null
-    GCD pg; const SegCtx* C; const double* y; bool term;
+    PGP pg; const SegCtx* C; const double* y; bool term;
     BMPC_INL void rowv(int s, double h, bool lower) {
         if (h > 1e-6) viol += h;
         if (gi) gi[s - S_EE] = lower ? -h : h;
@@ -959,21 +1024,27 @@ struct OutVisitor {
     template <int C_> BMPC_INL void point_end() {}
 };
 
-BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane) {
+BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.B, N = A.N;
-    if (wave * (64 / (N - 1)) >= count) return;
-    // all instances, in order: list-free mapping
-    const int S_ = N - 1, ipw = 64 / S_;
-    int li = lane / S_, kk = lane - li * S_;
-    int b = wave * ipw + li;
-    if (li >= ipw || b >= count) return;
-    const int k = kk + 1, n_w = 44 * N + 6;
+    if (wave * ipw_of(N) >= count) return;
+    // all instances, in order: list-free mapping (a null list means instance = entry index)
+    PairMap m;
+    {
+        const int S_ = N - 1, ipw = ipw_of(N);
+        int li = lane / S_, kk = lane - li * S_;
+        int e = wave * ipw + li;
+        m.valid = (li < ipw) && (e < count);
+        if (!m.valid) { e = wave * ipw; kk = 0; li = 0; }
+        m.b = e; m.k = kk + 1; m.li = li; m.pi = pair_of(A, m.b, m.k);
+    }
+    PGP pg = stage_params(A, (GCI)nullptr, count, wave, lane, m, lds_par);
+    if (!m.valid) return;
+    const int b = m.b, k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
-    const size_t pi = pair_of(A, b, k);
+    const size_t pi = m.pi;
     const DynC dc = make_dync(A.o.dt);
     GCD lbx = A.lbx + (size_t)b * n_w;
     GCD ubx = A.ubx + (size_t)b * n_w;
-    GCD pg = A.p + (size_t)b * NPAR;
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];

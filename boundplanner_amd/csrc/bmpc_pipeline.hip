@@ -23,10 +23,11 @@ using namespace bmpc;
 
 // thread-per-pair kernels: one wavefront per workgroup, floor(64/(N-1)) instances per wavefront
 __global__ __launch_bounds__(64) void bmpc_k_init_inst(PipeArgsH H) { k_init_inst_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { k_init_body(DV(H), blockIdx.x, threadIdx.x); }
+// dynamic LDS of the thread-per-pair kernels: [emitter tile (k_eval, k_curv)] [staged parameter vectors]
+extern __shared__ __attribute__((aligned(16))) double bmpc_dyn_lds[];
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { k_init_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_eval(PipeArgsH H) {
-    __shared__ double lds[EM_DOUBLES + 8];
-    k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
+    k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
     __shared__ double lds[EM_DOUBLES + 8];
@@ -39,23 +40,37 @@ __global__ __launch_bounds__(BMPC_RIC_NT, BMPC_RIC_WPS) void bmpc_k_ric(PipeArgs
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
     k_ric_body<BMPC_RIC_NT>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+// streaming row kernels: 64 pairs x 4 slot groups per workgroup
+__global__ __launch_bounds__(256) void bmpc_k_accept(PipeArgsH H) { k_accept_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(256) void bmpc_k_rowstep(PipeArgsH H) {
+    __shared__ double lds[768];
+    k_rowstep_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+__global__ __launch_bounds__(256) void bmpc_k_rowtrial(PipeArgsH H) {
+    __shared__ double lds[512];
+    k_rowtrial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
 __global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64) void bmpc_k_ls0(PipeArgsH H) { k_ls0_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64) void bmpc_k_ls(PipeArgsH H) { k_ls_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64) void bmpc_k_fin(PipeArgsH H) { k_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 
 #define LAUNCH(kern, nb, nt)                                            \
     do {                                                                \
         if ((nb) > 0) hipLaunchKernelGGL(kern, dim3(nb), dim3(nt), 0, st, *A); \
     } while (0)
+#define LAUNCH_DYN(kern, nb, nt, lds_doubles)                           \
+    do {                                                                \
+        if ((nb) > 0) hipLaunchKernelGGL(kern, dim3(nb), dim3(nt), (lds_doubles) * sizeof(double), st, *A); \
+    } while (0)
 
 extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st) {
     LAUNCH(bmpc_k_init_inst, (A->B + 63) / 64, 64);
-    LAUNCH(bmpc_k_init, waves_for(A->N, A->B), 64);
+    LAUNCH_DYN(bmpc_k_init, waves_for(A->N, A->B), 64, pair_lds_doubles(A->N, false));
     LAUNCH(bmpc_k_init_fin, (A->B + 63) / 64, 64);
     return hipGetLastError();
 }
@@ -63,12 +78,15 @@ extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st) 
 // one super-step for at most n_act active instances; swaps the double-buffered lists in *A
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st) {
     const int nw = waves_for(A->N, n_act), ni = (n_act + 63) / 64;
-    LAUNCH(bmpc_k_eval, nw, 64);
+    LAUNCH(bmpc_k_accept, nw, 256);
+    LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
     LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
-    LAUNCH(bmpc_k_step, nw, 64);
+    LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
+    LAUNCH(bmpc_k_rowstep, nw, 256);
     LAUNCH(bmpc_k_ls0, ni, 64);
-    LAUNCH(bmpc_k_trial, nw, 64);
+    LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false));
+    LAUNCH(bmpc_k_rowtrial, nw, 256);
     LAUNCH(bmpc_k_ls, ni, 64);
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
@@ -77,7 +95,7 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
 }
 
 extern "C" hipError_t bmpc_pipe_launch_out(const PipeArgsH* A, hipStream_t st) {
-    LAUNCH(bmpc_k_out, waves_for(A->N, A->B), 64);
+    LAUNCH_DYN(bmpc_k_out, waves_for(A->N, A->B), 64, pair_lds_doubles(A->N, false));
     LAUNCH(bmpc_k_fin, (A->B + 63) / 64, 64);
     return hipGetLastError();
 }

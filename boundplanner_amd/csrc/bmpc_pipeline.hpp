@@ -114,26 +114,50 @@ typedef BMPC_AS1 InstState* GST;
 
 template <class AT> BMPC_INL size_t pair_of(const AT& A, int b, int k) { return (size_t)b * (A.N - 1) + (k - 1); }
 
-// lanes -> pairs inside a wave: floor(64/(N-1)) instances per wave, lane = li*(N-1) + (k-1)
-struct PairMap { int b, k; bool valid; size_t pi; };
+// parameters of the instances of a wavefront are staged in LDS (every thread reads ~500 of them):
+// pointer type of the staged copy
+constexpr int EM_DOUBLES_C = 16 * 66 + 64;     // = EM_DOUBLES (emitter tile, below)
+constexpr int IPW_MAX = 8;       // instances per wavefront (bounds the LDS staging area)
+BMPC_HD int ipw_of(int N) { int i = 64 / (N - 1); return i < IPW_MAX ? i : IPW_MAX; }
+
+// lanes -> pairs inside a wave: ipw_of(N) instances per wave, lane = li*(N-1) + (k-1)
+struct PairMap { int b, k, li; bool valid; size_t pi; };
 BMPC_INL PairMap pair_map(const PipeArgs& A, GCI list, int count, int wave, int lane) {
-    const int S = A.N - 1, ipw = 64 / S;
+    const int S = A.N - 1, ipw = ipw_of(A.N);
     int li = lane / S, kk = lane - li * S;
     int e = wave * ipw + li;
     PairMap m;
     m.valid = (li < ipw) && (e < count);
-    if (!m.valid) { e = wave * ipw; kk = 0; }      // dummy work on a valid pair, no stores
+    if (!m.valid) { e = wave * ipw; kk = 0; li = 0; }      // dummy work on a valid pair, no stores
+    m.li = li;
     m.b = list[e]; m.k = kk + 1;
     m.pi = pair_of(A, m.b, m.k);
     return m;
 }
-BMPC_HD int waves_for(int N, int count) { int ipw = 64 / (N - 1); return (count + ipw - 1) / ipw; }
+BMPC_HD int waves_for(int N, int count) { int ipw = ipw_of(N); return (count + ipw - 1) / ipw; }
+
+// stage the parameter vectors of this wavefront's instances: lds_par[li][NPAR]; returns the calling
+// lane's copy.  All 64 lanes must call it (contains a barrier).
+BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int lane, const PairMap& m, LDSD* lds_par) {
+    const int ipw = ipw_of(A.N);
+    for (int li = 0; li < ipw; li++) {
+        const int e = wave * ipw + li;
+        if (e < count) {
+            GCD src = A.p + (size_t)(list ? list[e] : e) * NPAR;
+            for (int i = lane; i < NPAR; i += 64) lds_par[li * NPAR + i] = src[i];
+        }
+    }
+    BMPC_SYNC();
+    return lds_par + m.li * NPAR;
+}
+BMPC_HD size_t pair_lds_doubles(int N, bool with_tile) { return (size_t)ipw_of(N) * NPAR + (with_tile ? EM_DOUBLES_C + 8 : 0); }
 
 // ------------------------------------------------------------------------------------------
 // coalesced AoS output of per-thread records: 16 fields at a time through an LDS tile
 // ------------------------------------------------------------------------------------------
 constexpr int EM_LD = 66;                      // tile row stride (doubles): conflict-free both ways
 constexpr int EM_DOUBLES = 16 * EM_LD + 64;    // tile + per-lane record base (as double)
+static_assert(EM_DOUBLES == EM_DOUBLES_C, "emitter tile size");
 struct Emitter {
     LDSD* tile;        // [16][EM_LD]
     GD out;            // record array base

@@ -15,6 +15,7 @@
 namespace bmpc {
 
 #define BMPC_UNROLL _Pragma("unroll")
+typedef const LDSD* PGP;       // parameter vector of the thread's instance, staged in LDS (bmpc_pipeline.hpp)
 
 // ------------------------------------------------------------------------------------------
 // kinematics
@@ -177,7 +178,7 @@ struct SegCtx {
 #define PTAB(off, seg, c) pg[(off) + (c) * 4 + (seg)]
 
 // pose = [p_ee, p_rot], v = J dq; y = natural stage variables; iw0 = pinned stage-0 p_rot
-BMPC_INL void seg_ctx_eval(GCD pg, int N, int k, const double* y, const double* iw0, SegCtx& C) {
+BMPC_INL void seg_ctx_eval(PGP pg, int N, int k, const double* y, const double* iw0, SegCtx& C) {
     const bool term = (k == N - 1);
     int s = 0;
     if ((double)k > pg[P_SPLIT + 1]) s = 1;
@@ -185,7 +186,7 @@ BMPC_INL void seg_ctx_eval(GCD pg, int N, int k, const double* y, const double* 
     const int n = (pg[P_SPLIT + 1] == (double)N) ? 1 : ((pg[P_SPLIT + 2] == (double)N) ? 2 : 3);
     C.s = s; C.n = n;
     const bool iw_param = ((double)k <= pg[P_SPLIT + 1]);
-    GCD wts = pg + P_W;
+    PGP wts = pg + P_W;
     double dpr[3], d[3], tmp[3], delta[3], jrdpr[3];
     BMPC_UNROLL
     for (int a = 0; a < 3; a++) { C.dpp[a] = PTAB(P_DPREF, s, a); dpr[a] = PTAB(P_DPREF, s, 3 + a); d[a] = C.pose[a] - PTAB(P_PREF, s, a); }
@@ -294,8 +295,8 @@ BMPC_INL void seg_ctx_eval(GCD pg, int N, int k, const double* y, const double* 
 }
 
 // output-space cost gradient g12 = d f / d(pose, v) (E7)
-BMPC_INL void cost_grad12(GCD pg, const SegCtx& C, bool term, double* g12) {
-    GCD wts = pg + P_W;
+BMPC_INL void cost_grad12(PGP pg, const SegCtx& C, bool term, double* g12) {
+    PGP wts = pg + P_W;
     const double sig = C.sig, dsig = C.dsig;
     BMPC_UNROLL
     for (int b = 0; b < 6; b++) {
@@ -317,8 +318,8 @@ BMPC_INL void cost_grad12(GCD pg, const SegCtx& C, bool term, double* g12) {
 // Gauss-Newton/convex output-space Hessians: Hp (pose x pose, 21 packed upper), Hv (v x v)
 BMPC_INL constexpr int sym6(int i, int j) { return i <= j ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j)); }
 
-BMPC_INL void cost_hess(GCD pg, const SegCtx& C, bool term, double* Hp /*21*/, double* Hv /*21*/) {
-    GCD wts = pg + P_W;
+BMPC_INL void cost_hess(PGP pg, const SegCtx& C, bool term, double* Hp /*21*/, double* Hv /*21*/) {
+    PGP wts = pg + P_W;
     const double sig = C.sig, dsig = C.dsig;
     double R1[3][6], R2[3][6];
     BMPC_UNROLL
@@ -366,10 +367,10 @@ BMPC_INL void cost_hess(GCD pg, const SegCtx& C, bool term, double* Hp /*21*/, d
 // and v.skip(s) for inactive slots.  Slot numbering: bmpc_device.hpp (S_*).
 // ------------------------------------------------------------------------------------------
 template <class V, int C0>
-BMPC_INL void walk_points(GCD pg, const KinT& K, const SegCtx& C, V& v) {
+BMPC_INL void walk_points(PGP pg, const KinT& K, const SegCtx& C, V& v) {
     if constexpr (C0 < 6) {
         v.template point_begin<C0>();
-        GCD a = pg + P_ASETJ + 45 * C0;
+        PGP a = pg + P_ASETJ + 45 * C0;
         const double* pc = kin_point<C0>(K);
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
@@ -385,7 +386,7 @@ BMPC_INL void walk_points(GCD pg, const KinT& K, const SegCtx& C, V& v) {
 }
 
 template <class V>
-BMPC_INL void walk_rows(GCD pg, GCD lbx, GCD ubx, int N, int k, const double* y,
+BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
                         const double* zeta, const KinT& K, const SegCtx& C, V& v) {
     const bool term = (k == N - 1);
     // box bounds on q, dq, ddq, u (BoundMPC.py:171-186, 544-589)
@@ -416,7 +417,7 @@ BMPC_INL void walk_rows(GCD pg, GCD lbx, GCD ubx, int N, int k, const double* y,
     }
     // EE in current set (ocp :304)
     {
-        GCD a = pg + P_ASET + 45 * C.s;
+        PGP a = pg + P_ASET + 45 * C.s;
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
             double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = pg[P_BSET + rr * 4 + C.s];
@@ -443,7 +444,7 @@ BMPC_INL void walk_rows(GCD pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         v.pose(S_PHI, a6, 0, C.phi - (C.phiend + 0.005));
     }
     if (term) {
-        GCD a = pg + P_ASET + 45 * C.n;
+        PGP a = pg + P_ASET + 45 * C.n;
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
             double an[3] = {a[rr], a[rr + 15], a[rr + 30]};

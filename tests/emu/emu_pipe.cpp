@@ -87,23 +87,26 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     A.L.eval = l_eval.data(); A.L.step = l_step.data(); A.L.trial = l_trial.data();
     A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
     A.tbl = tbl.data();
-    std::vector<double> lds(std::max(EM_DOUBLES + 8, RIC_LDS_DOUBLES) + 64);
+    std::vector<double> lds(std::max<size_t>(pair_lds_doubles(N, true), RIC_LDS_DOUBLES) + 64);
     const int nb_inst = (B + 63) / 64, nw = waves_for(N, B);
     cnt[0] = B;
     launch(nb_inst, [&](int blk, int l) { k_init_inst_body(A, blk * 64 + l); });
-    launch(nw, [&](int blk, int l) { k_init_body(A, blk, l); });
+    launch(nw, [&](int blk, int l) { k_init_body(A, blk, l, lds.data()); });
     launch(nb_inst, [&](int blk, int l) { k_init_fin_body(A, blk * 64 + l); });
     int steps = 0;
     for (; steps < 12 * (max_iter + 2); steps++) {
         int nact = B - cnt[5];
         if (nact <= 0) break;
         if (verbose) printf("step %d: n_eval %d n_trial %d done %d\n", steps, cnt[0], cnt[2], cnt[5]);
+        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_accept_body(A, blk, l); }, 256);
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
         launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
-        launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l); });
+        launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
+        launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_rowstep_body(A, blk, l, lds.data()); }, 256);
         launch((cnt[1] + 63) / 64, [&](int blk, int l) { k_ls0_body(A, blk * 64 + l); });
-        launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l); });
+        launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l, lds.data()); });
+        launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_rowtrial_body(A, blk, l, lds.data()); }, 256);
         launch((cnt[2] + 63) / 64, [&](int blk, int l) { k_ls_body(A, blk * 64 + l); });
         k_rotate_body(A);
         std::swap(A.L.eval, A.L.eval_next);
@@ -113,7 +116,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
                 printf("  inst %d: state %d it %d mu %.3e alpha %.3e err_prev %.3e hm %d hreg %.1e\n", b, st[b].state, st[b].it,
                        st[b].mu, st[b].alpha, st[b].err_prev, st[b].hess_mode, st[b].hreg);
     }
-    launch(nw, [&](int blk, int l) { k_out_body(A, blk, l); });
+    launch(nw, [&](int blk, int l) { k_out_body(A, blk, l, lds.data()); });
     launch(nb_inst, [&](int blk, int l) { k_fin_body(A, blk * 64 + l); });
     return steps;
 }
