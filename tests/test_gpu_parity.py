@@ -149,3 +149,68 @@ def test_nlpsolver_object_matches_reference_call_convention(backends):
     st = s.stats()
     assert st["success"] and st["iter_count"] > 0 and st["return_status"] == "Solve_Succeeded"
     assert sol["x"].full().shape == (44 * N + 6, 1) and sol["g"].full().shape == (147 * (N - 1) + 21, 1)
+
+
+def test_engines_and_async_entry_agree(backends):
+    """The pipeline engine (default), the persistent one-wavefront-per-instance engine and the asynchronous
+    device-pointer entry solve the same batch: identical results between the synchronous and the asynchronous
+    entry of one engine (bitwise), same iteration counts and iterates within the stated tolerance between engines."""
+    import torch
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N, B = 10, 96
+    be0 = backends(N)
+    be1 = backends(N, engine=1)
+    batch = scenes.make_batch(B, N, 77, be0.fk, randomize_sets=True)
+    r0 = be0.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    r1 = be1.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    conv = (r0["status"] == 0) & (r1["status"] == 0)
+    assert conv.mean() > 0.95
+    assert np.abs(r0["iters"][conv] - r1["iters"][conv]).max() <= 1
+    same = conv & (r0["iters"] == r1["iters"])
+    assert np.abs(r0["x"][same][:, 28 * N:40 * N] - r1["x"][same][:, 28 * N:40 * N]).max() < 2e-5
+    # asynchronous entry, device pointers
+    dev = torch.device("cuda", 0)
+    big = lambda a: np.nan_to_num(a, posinf=1e20, neginf=-1e20)
+    d = {k: torch.from_numpy(big(batch[k])).to(dev) for k in ("x0", "lbx", "ubx", "p")}
+    x = torch.empty((B, be0.n_w), dtype=torch.float64, device=dev)
+    f = torch.empty(B, dtype=torch.float64, device=dev); viol = torch.empty(B, dtype=torch.float64, device=dev)
+    it = torch.empty(B, dtype=torch.int32, device=dev); st = torch.empty(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    be2 = HipBoundMPC(N, max_batch=B)
+    be2.solve_dev_async(B, d["x0"].data_ptr(), d["lbx"].data_ptr(), d["ubx"].data_ptr(), d["p"].data_ptr(), x.data_ptr(),
+                        f.data_ptr(), it.data_ptr(), st.data_ptr(), viol.data_ptr())
+    assert be2.active() >= 0
+    be2.wait()
+    assert be2.active() == 0
+    assert np.array_equal(x.cpu().numpy(), r0["x"]) and np.array_equal(it.cpu().numpy(), r0["iters"])
+    assert np.array_equal(st.cpu().numpy(), r0["status"]) and np.array_equal(viol.cpu().numpy(), r0["viol"])
+
+
+def test_full_size_batch_properties(backends):
+    """BASELINE configs[2] at full size (8192 instances, N=20, randomized convex sets): properties that do
+    not need the oracle.  (1) an instance's result does not depend on the batch it is solved in: the first
+    512 instances solved alone are bitwise equal to their rows in the full batch (what makes sharding over
+    GPUs exact); (2) every accepted solution satisfies the reference's acceptance test and its returned g
+    matches the box structure of lbg/ubg; (3) repeated solves are bitwise reproducible."""
+    from boundplanner_amd import scenes
+    N, B = 20, 8192
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 8192, be.fk, randomize_sets=True)
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    r2 = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    for k in ("x", "f", "iters", "status", "viol"):
+        assert np.array_equal(r[k], r2[k]), k
+    sub = be.solve_batch(batch["x0"][:512], batch["lbx"][:512], batch["ubx"][:512], batch["p"][:512], want_g=True)
+    for k in ("x", "f", "iters", "status", "viol"):
+        assert np.array_equal(sub[k], r[k][:512]), k
+    ok = (r["status"] == 0) | (r["viol"] < 1e-4)
+    assert ok.mean() > 0.99 and (r["status"] == 0).mean() > 0.99
+    assert r["iters"][r["status"] == 0].max() <= 100 and r["iters"].mean() < 30
+    conv = sub["status"] == 0
+    g = sub["g"][conv]
+    assert (g <= be.ubg + 1e-4).all() and (g >= be.lbg - 1e-4).all()
+    # stage-0 pins are returned exactly
+    x = r["x"]
+    for blk in range(4):
+        assert np.array_equal(x[:, blk * 7 * N:(blk + 1) * 7 * N:N], batch["lbx"][:, blk * 7 * N:(blk + 1) * 7 * N:N])
