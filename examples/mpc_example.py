@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Track phase of the reference's example (/root/reference/boundplanner_with_mpc_example.py:19-166) on the
+MI355X solver: default iiwa14 start configuration, MPCNode start-up + warm-up solve (:21-29), a via path
+handed to `update_reference` (:134) and the hot loop `while phi < phi_max - 0.001: mpc_node.step()` (:140-157).
+
+The plan phase (BoundPlanner.plan_convex_set_path, :102-115) is outside this build's scope;
+the via path below is hand-authored inside two large box sets, like the golden closed-loop fixture.
+BASELINE.json configs[0] ("single instance plumbing"): one instance, N = 15 (the reference default).
+
+    python examples/mpc_example.py            # needs an MI355X (no CPU fallback)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from boundplanner_amd.mpc_node import MPCNode            # noqa: E402
+from boundplanner_amd.robot_model import RobotModel       # noqa: E402
+from boundplanner_amd.solver import HipBoundMPC, HipNlpSolver   # noqa: E402
+
+
+def box_set(lo, hi):
+    a = np.vstack((np.eye(3), -np.eye(3), np.zeros((9, 3))))
+    return a, np.concatenate((np.asarray(hi, float), -np.asarray(lo, float), 10.0 * np.ones(9)))
+
+
+def main():
+    q0 = np.array([0.0, 0.0, 0.0, -np.pi / 2, 0.0, np.pi / 2, 0.0])        # example :20
+    be = HipBoundMPC(15)
+    node = MPCNode(q0, RobotModel(be.fk), lambda n, dt: HipNlpSolver(n, dt, backend=be))
+    node.step()                                                              # warm-up solve, example :29
+    p0 = node.p_lie
+    R0 = R.from_rotvec(p0[3:]).as_matrix()
+    p_via = [p0[:3].copy(), p0[:3] + np.array([0.05, -0.25, 0.10]), np.array([0.45, -0.5, 0.2])]   # goal of the example
+    r_via = [R0, R0 @ R.from_euler("xyz", [20, 0, 10], degrees=True).as_matrix(),
+             R0 @ R.from_euler("xyz", [20, 25, 10], degrees=True).as_matrix()]
+    sets = [box_set([-0.14, -1.0, 0.0], [1.0, 0.38, 1.0])] * 2               # workspace of the example (:97-100)
+    node.update_reference(p_via, r_via, [np.array([0.0, 0, 1])] * 2, [np.array([0.0, 0, 1])] * 2,
+                          [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(2)],
+                          [s[0] for s in sets], [s[1] for s in sets], [])
+    t0, steps = time.perf_counter(), 0
+    while node.mpc.phi_current[0] < node.mpc.phi_max[0] - 0.001 and steps < 300:
+        node.step()
+        steps += 1
+        if steps % 10 == 0:
+            print(f"step {steps:3d}  phi {node.mpc.phi_current[0]:.3f}/{node.mpc.phi_max[0]:.3f}  "
+                  f"sector {node.mpc.ref_path.sector}/{node.mpc.ref_path.num_sectors}  iters {node.iters[-1]}  "
+                  f"t_solve {1e3 * node.t_mpc:.1f} ms")
+    print(f"reached phi_max in {steps} steps, {np.mean(node.iters):.1f} iterations/step, "
+          f"{1e3 * (time.perf_counter() - t0) / max(steps, 1):.1f} ms/step wall, fails {int(np.sum(node.fails))}, "
+          f"final EE position {np.round(node.p_lie[:3], 4)}")
+
+
+if __name__ == "__main__":
+    main()
