@@ -199,9 +199,9 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
 };
 
 struct PointAsm {
-    RowAcc* R; const KinT* K; Emitter* E;
+    RowAcc* R; const KinT* K;
     double M3[6], mc[3], sc, b30[3], b31[3], b3z[3], bc0, bc1, bcz;
-    double Hqq[28], gq0[7], gq1[7], gqz[7], dD[6], gD0[6], gD1[6], gDz[6], cd5[7], Fc[6][3];
+    double Hqq[28], gq0[7], gq1[7], gqz[7], dD[6], gD0[6], gD1[6], gDz[6], cd[6][7], Fc[6][3];
     BMPC_INL void init() {
         BMPC_UNROLL
         for (int i = 0; i < 28; i++) Hqq[i] = 0;
@@ -249,12 +249,23 @@ struct PointAsm {
         BMPC_UNROLL
         for (int i = 0; i < 7; i++) {
             double v = (i < nj) ? (Jp[i < nj ? i : 0][0] * mc[0] + Jp[i < nj ? i : 0][1] * mc[1] + Jp[i < nj ? i : 0][2] * mc[2]) : 0.0;
-            if (C < 5) E->put(v); else cd5[i] = v;
+            cd[C][i] = v;
         }
         dD[C] = sc; gD0[C] = bc0; gD1[C] = bc1; gDz[C] = bcz;
         BMPC_UNROLL
         for (int a = 0; a < 3; a++) Fc[C][a] = b3z[a];
     }
+};
+
+// results of k_points for one pair, loaded from the side array where they are needed
+struct PointRes {
+    GCD base; size_t NP;      // base = A.part + PT_SIDE * NP + pair
+    BMPC_INL double at(int slot) const { return base[(size_t)slot * NP]; }
+    BMPC_INL double cd5(int i) const { return at(SD_CD5 + i); }
+    BMPC_INL double hqq(int e) const { return at(SD_HQQ + e); }
+    BMPC_INL double gq(int v, int i) const { return at(SD_GQ + 7 * v + i); }
+    BMPC_INL double dD(int c) const { return at(SD_DD + c); }
+    BMPC_INL double gD(int v, int c) const { return at(SD_GD + 6 * v + c); }
 };
 
 struct PoseAsm {
@@ -390,21 +401,21 @@ struct ChainOut { double g17[3][17]; };
 
 template <int J, int I>
 BMPC_INL void chain_rows(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* t1,
-                         const double* t2, const double* Hqq, Emitter& E) {
+                         const double* t2, const PointRes& PR, Emitter& E) {
     if constexpr (I <= J) {
         double cO[6], cV[6];
         chain_cols<I>(K, Jl, G, hdt, cO, cV);
         double s = 0;
         BMPC_UNROLL
         for (int a = 0; a < 6; a++) s += cO[a] * t1[a] + cV[a] * t2[a];
-        if constexpr (J < 7) s += Hqq[sym7(I, J)];
+        if constexpr (J < 7) s += PR.hqq(sym7(I, J));
         E.put(s);
-        chain_rows<J, I + 1>(K, Jl, G, hdt, t1, t2, Hqq, E);
+        chain_rows<J, I + 1>(K, Jl, G, hdt, t1, t2, PR, E);
     }
 }
 template <int J>
 BMPC_INL void chain_column(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* M6,
-                           const double* Hv, const double* Hqq, Emitter& E) {
+                           const double* Hv, const PointRes& PR, Emitter& E) {
     double cO[6], cV[6], t1[6], t2[6];
     chain_cols<J>(K, Jl, G, hdt, cO, cV);
     BMPC_UNROLL
@@ -414,21 +425,21 @@ BMPC_INL void chain_column(const KinT& K, const double Jl[3][7], const double G[
         for (int b = 0; b < 6; b++) { s1 += M6[sym6(a, b)] * cO[b]; s2 += Hv[sym6(a, b)] * cV[b]; }
         t1[a] = s1; t2[a] = s2;
     }
-    chain_rows<J, 0>(K, Jl, G, hdt, t1, t2, Hqq, E);
+    chain_rows<J, 0>(K, Jl, G, hdt, t1, t2, PR, E);
 }
 template <int J>
 BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* M6,
-                        const double* Hv, const double* Hqq, Emitter& E) {
+                        const double* Hv, const PointRes& PR, Emitter& E) {
     if constexpr (J < 17) {
-        chain_column<J>(K, Jl, G, hdt, M6, Hv, Hqq, E);
-        chain_all<J + 1>(K, Jl, G, hdt, M6, Hv, Hqq, E);
+        chain_column<J>(K, Jl, G, hdt, M6, Hv, PR, E);
+        chain_all<J + 1>(K, Jl, G, hdt, M6, Hv, PR, E);
     }
 }
 // P17 blocks: for position I of the (q, dq, pi) block emit the three slack-column couplings, then
 // D, g0, g1, gz of that position (its diagonal rows are walked here), 7 fields
 template <int I>
 BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, const double* y, const KinT& K,
-                           const double Jl[3][7], const double G[6][7], double hdt, RowAcc& R, const PointAsm& PA,
+                           const double Jl[3][7], const double G[6][7], double hdt, RowAcc& R, const PointRes& PA,
                            const PoseAsm& P, const double* bv, Emitter& E) {
     if constexpr (I < 17) {
         PGP wts = pg + P_W;
@@ -439,7 +450,7 @@ BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, c
             double s = 0;
             BMPC_UNROLL
             for (int a = 0; a < 6; a++) s += cO[a] * P.mS[sl][a];
-            if (sl == 2 && I < 7) s += PA.cd5[I < 7 ? I : 0];
+            if (sl == 2 && I < 7) s += PA.cd5(I < 7 ? I : 0);
             E.put(s);
         }
         double g0 = 0, g1 = 0, gz = 0;
@@ -456,7 +467,7 @@ BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, c
         walk_diag_pos<DI>(lbx, ubx, A.N, k, y, dgv);
         double D = dgv.D;
         g0 += dgv.g0; g1 += dgv.g1; gz += dgv.gz;
-        if constexpr (I < 7) { g0 += PA.gq0[I]; g1 += PA.gq1[I]; gz += PA.gqz[I]; }
+        if constexpr (I < 7) { g0 += PA.gq(0, I); g1 += PA.gq(1, I); gz += PA.gq(2, I); }
         if constexpr (I >= 7 + 2 && I <= 7 + 4) {            // joint-velocity cost (Q9)
             const double w2 = 2 * wts[6], val = w2 * y[Z_DQ + I - 7];
             D += w2; g0 += val; gz += val;
@@ -526,7 +537,7 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
 // DG entries: position I of the dg order
 template <int I>
 BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, bool term,
-                          const double* y, RowAcc& R, const PointAsm& PA, const PoseAsm& PO, Emitter& E) {
+                          const double* y, RowAcc& R, const PointRes& PA, const PoseAsm& PO, Emitter& E) {
     if constexpr (I < 38) {
         PGP wts = pg + P_W;
         DiagAsm dgv;
@@ -539,7 +550,7 @@ BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, bo
         if constexpr (I == 28) { D += PO.sS[1]; g0 += PO.bS0[1]; g1 += PO.bS1[1]; gz += PO.bSz[1]; }
         if constexpr (I >= 32 && I < 38) {
             constexpr int c = I - 32;
-            D += PA.dD[c]; g0 += PA.gD0[c]; g1 += PA.gD1[c]; gz += PA.gDz[c];
+            D += PA.dD(c); g0 += PA.gD(0, c); g1 += PA.gD(1, c); gz += PA.gD(2, c);
             if constexpr (c == 5) { D += PO.sS[2]; g0 += PO.bS0[2]; g1 += PO.bS1[2]; gz += PO.bSz[2]; }
         }
         // direct quadratic cost terms (natural coordinates)
@@ -596,11 +607,12 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     }
     RowAcc R;
     R.init(&A, m.pi, m.valid, ad);
-    // ---- collision points -> q x q block, q x d columns ----
-    PointAsm PA;
-    PA.R = &R; PA.K = &S.K; PA.E = &E;
-    PA.init();
-    walk_points<PointAsm, 0>(pg, S.K, S.C, PA);
+    // ---- collision-point results of k_points: q x d columns first, the rest where it is needed ----
+    PointRes PA{A.part + (size_t)PT_SIDE * A.NP + m.pi, A.NP};
+    R.cmax = PA.at(SD_KKT); R.csum = PA.at(SD_KKT + 1); R.cmin = PA.at(SD_KKT + 2); R.zsum = PA.at(SD_KKT + 3);
+    R.prim = PA.at(SD_KKT + 4); R.nrows = PA.at(SD_KKT + 5);
+    BMPC_UNROLL
+    for (int i = 0; i < 35; i++) E.put(PA.at(SD_CD + i));
     // ---- pose rows -> chained (q, dq, pi) block ----
     PoseAsm PO;
     PO.R = &R;
@@ -614,10 +626,6 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         for (int a = 0; a < 3; a++) F[(size_t)a * A.NP] = PO.bpz[a];
         BMPC_UNROLL
         for (int a = 0; a < 6; a++) F[(size_t)(3 + a) * A.NP] = g12[6 + a] + (a >= 3 ? hdt * PO.bpz[a] : 0.0);
-        BMPC_UNROLL
-        for (int c = 0; c < 6; c++)
-            BMPC_UNROLL
-            for (int a = 0; a < 3; a++) F[(size_t)(9 + 3 * c + a) * A.NP] = PA.Fc[c][a];
     }
     // ---- slack-column couplings + gradients + diagonal rows of the 17 chained positions ----
     p17_emit_all<0>(A, pg, lbx, ubx, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, g12 + 6, E);
@@ -625,7 +633,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     {
         double HpX[21], Hv[21];
         cost_hess(pg, S.C, term, HpX, Hv);
-        chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA.Hqq, E);
+        chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA, E);
     }
     // ---- remaining diagonal rows + gradients: ddq, u, rs, drs, ps, dps, d ----
     dg_emit_all<14>(A, pg, lbx, ubx, k, term, S.y, R, PA, PO, E);
@@ -693,6 +701,61 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         GD P = A.part + m.pi;
         P[PT_CMAX * A.NP] = R.cmax; P[PT_CSUM * A.NP] = R.csum; P[PT_CMIN * A.NP] = R.cmin; P[PT_ZSUM * A.NP] = R.zsum;
         P[PT_PRIM * A.NP] = prim; P[PT_NROWS * A.NP] = R.nrows;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_points: the 90 collision-point rows of a pair (ocp :323-330): barrier terms chained through the point
+// Jacobians into the q x q block, the q x d columns and the gradients; results go to the side array.
+// A kernel of its own because together with the pose / chain work of k_eval it does not fit the
+// register file (the spills were what bound k_eval).
+// ------------------------------------------------------------------------------------------
+BMPC_DEV void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
+    const int count = A.L.cnt[0], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    const DynC dc = make_dync(A.o.dt);
+    PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds_par);
+    double zeta[NZ], y[NZ];
+    load_zeta(A.zeta, A.NP, m.pi, zeta);
+    nat_all(zeta, dc, y);
+    KinT K;
+    kin_chain(A.rc, y + Z_Q, K);
+    SegCtx C;
+    BMPC_UNROLL
+    for (int i = 0; i < 6; i++) C.sl[i] = pg[P_SLACKS0 + i] + y[Z_D + i];
+    RowAcc R;
+    R.init(&A, m.pi, m.valid, 0.0);
+    PointAsm PA;
+    PA.R = &R; PA.K = &K;
+    PA.init();
+    walk_points<PointAsm, 0>(pg, K, C, PA);
+    if (!m.valid) return;
+    GD Sd = A.part + (size_t)PT_SIDE * A.NP + m.pi;
+    BMPC_UNROLL
+    for (int c = 0; c < 5; c++)
+        BMPC_UNROLL
+        for (int i = 0; i < 7; i++) Sd[(size_t)(SD_CD + 7 * c + i) * A.NP] = PA.cd[c][i];
+    BMPC_UNROLL
+    for (int i = 0; i < 7; i++) {
+        Sd[(size_t)(SD_CD5 + i) * A.NP] = PA.cd[5][i];
+        Sd[(size_t)(SD_GQ + i) * A.NP] = PA.gq0[i]; Sd[(size_t)(SD_GQ + 7 + i) * A.NP] = PA.gq1[i]; Sd[(size_t)(SD_GQ + 14 + i) * A.NP] = PA.gqz[i];
+    }
+    BMPC_UNROLL
+    for (int i = 0; i < 28; i++) Sd[(size_t)(SD_HQQ + i) * A.NP] = PA.Hqq[i];
+    BMPC_UNROLL
+    for (int c = 0; c < 6; c++) {
+        Sd[(size_t)(SD_DD + c) * A.NP] = PA.dD[c];
+        Sd[(size_t)(SD_GD + c) * A.NP] = PA.gD0[c]; Sd[(size_t)(SD_GD + 6 + c) * A.NP] = PA.gD1[c]; Sd[(size_t)(SD_GD + 12 + c) * A.NP] = PA.gDz[c];
+    }
+    Sd[(size_t)(SD_KKT + 0) * A.NP] = R.cmax; Sd[(size_t)(SD_KKT + 1) * A.NP] = R.csum; Sd[(size_t)(SD_KKT + 2) * A.NP] = R.cmin;
+    Sd[(size_t)(SD_KKT + 3) * A.NP] = R.zsum; Sd[(size_t)(SD_KKT + 4) * A.NP] = R.prim; Sd[(size_t)(SD_KKT + 5) * A.NP] = R.nrows;
+    if (A.o.hess == 2) {
+        GD F = A.part + (size_t)PT_FORCE * A.NP + m.pi;
+        BMPC_UNROLL
+        for (int c = 0; c < 6; c++)
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) F[(size_t)(9 + 3 * c + a) * A.NP] = PA.Fc[c][a];
     }
 }
 

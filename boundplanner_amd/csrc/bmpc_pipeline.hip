@@ -29,6 +29,7 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { 
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_eval(PipeArgsH H) {
     k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_points(PipeArgsH H) { k_points_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
     __shared__ double lds[EM_DOUBLES + 8];
     k_curv_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
@@ -79,6 +80,7 @@ extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st) 
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st) {
     const int nw = waves_for(A->N, n_act), ni = (n_act + 63) / 64;
     LAUNCH(bmpc_k_accept, nw, 256);
+    LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
     LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);

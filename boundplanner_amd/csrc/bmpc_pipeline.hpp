@@ -56,8 +56,12 @@ constexpr int dg_pos_c(int i) {
 BMPC_HD int pos17(int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); }
 
 constexpr int KREC = 320;               // gains per pair: K (9x32) + kf (2x16)
-constexpr int NPART = 48;               // per-pair partial sums (16) + generalised forces for k_curv (27)
+constexpr int NPART = 176;              // per-pair partial sums (16) + forces for k_curv (27) + point-group results (121)
 constexpr int PT_FORCE = 16;            // Fp[3], Fv[6], Fc[6][3]
+// results of the collision-point rows (k_points), read by k_eval where it needs them
+constexpr int PT_SIDE = 48, SD_CD = 0 /*[5][7]*/, SD_CD5 = 35 /*7*/, SD_HQQ = 42 /*28*/, SD_GQ = 70 /*[3][7]*/,
+              SD_DD = 91 /*6*/, SD_GD = 97 /*[3][6]*/, SD_KKT = 115 /*cmax csum cmin zsum prim nrows*/, SD_END = 121;
+static_assert(PT_SIDE + SD_END <= NPART, "partials layout");
 enum { PT_CMAX = 0, PT_CSUM, PT_CMIN, PT_ZSUM, PT_PRIM, PT_THETA, PT_LOGS, PT_NROWS, PT_FVAL,
        PT_AP, PT_AD, PT_DBAR, PT_DPHIF, PT_F1, PT_TH1, PT_LS1 };
 
