@@ -177,7 +177,7 @@ static int pipe_ensure(bmpc_handle* h, int B) {
     if (h->d_pipe_lists) { (void)hipFree(h->d_pipe_lists); h->d_pipe_lists = nullptr; }
     h->pipe_cap = 0;
     const size_t NP = ((size_t)cap * (h->o.N - 1) + 63) / 64 * 64 + 64;
-    const size_t n = (3 * (size_t)NZ + 5 * (size_t)NSLOT + NPART + HREC + KREC) * NP;
+    const size_t n = (3 * (size_t)NZ + 5 * (size_t)NSLOT + NPART + HREC + KREC) * NP + (size_t)cap * NX;
     HIPCHK(h, hipMalloc((void**)&h->d_pipe, n * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_pipe_st, (size_t)cap * bmpc_pipe_state_bytes()));
     HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (5 * (size_t)cap + 8) * sizeof(int)));
@@ -205,7 +205,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.t = w; w += NSLOT * NP; A.t_t = w; w += NSLOT * NP; A.z = w; w += NSLOT * NP; A.dt = w; w += NSLOT * NP;
     A.dzr = w; w += NSLOT * NP;
     A.part = w; w += NPART * NP;
-    A.hrec = w; w += HREC * NP; A.krec = w;
+    A.hrec = w; w += HREC * NP; A.krec = w; w += KREC * NP; A.dx1 = w;
     A.st = (InstState*)h->d_pipe_st;
     int* L = h->d_pipe_lists;
     A.L.eval = L; A.L.step = L + cap; A.L.trial = L + 2 * (size_t)cap; A.L.eval_next = L + 3 * (size_t)cap;

@@ -41,6 +41,10 @@ __global__ __launch_bounds__(BMPC_RIC_NT, BMPC_RIC_WPS) void bmpc_k_ric(PipeArgs
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
     k_ric_body<BMPC_RIC_NT>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
+__global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
+    __shared__ __attribute__((aligned(16))) double lds[FW_LDS_DOUBLES];
+    k_fwd_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 // streaming row kernels: 64 pairs x 4 slot groups per workgroup
 __global__ __launch_bounds__(256) void bmpc_k_accept(PipeArgsH H) { k_accept_body(DV(H), blockIdx.x, threadIdx.x); }
@@ -84,6 +88,7 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
     LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
+    LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH(bmpc_k_rowstep, nw, 256);
     LAUNCH(bmpc_k_ls0, ni, 64);

@@ -105,6 +105,7 @@ template <int DEV> struct PipeArgsT {
     typename PT::D t, t_t, z, dt, dzr;   // [NSLOT][NP]
     typename PT::D hrec;                 // [pairs][HREC]
     typename PT::D krec;                 // [pairs][KREC]
+    typename PT::D dx1;                  // [B][32] step of x_1 (k_ric -> k_fwd)
     typename PT::D part;                 // [NPART][NP]
     typename PT::S st;                   // [B]
     ListsT<DEV> L;

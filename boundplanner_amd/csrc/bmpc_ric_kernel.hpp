@@ -613,8 +613,8 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
     return ok;
 }
 
-// forward recursion: Newton direction dz for barrier parameter mu; false if the free part of the
-// stage-1 value function is not positive definite
+// start of the forward recursion: step of x_1 for barrier parameter mu (pinned part = initial defect, free
+// part minimises the cost-to-go); false if the free part of the stage-1 value function is not positive definite
 template <int NT>
 BMPC_NOINL bool ric_forward(const PipeArgsH& A, LDSD* lds, int b, int lane) {
     const double mu = lds[R_park + 11];
@@ -671,65 +671,86 @@ BMPC_NOINL bool ric_forward(const PipeArgsH& A, LDSD* lds, int b, int lane) {
         BMPC_SYNC();
     }
     if (!ok) return false;
-    constexpr int NK = (NU * NX + NT - 1) / NT;
+    // the recursion over the stages runs in k_fwd (tiny LDS footprint: every instance resident at once)
+    if (lane < NX) A.dx1[(size_t)b * NX + lane] = RL(R_dx)[lane];
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fwd: forward Riccati recursion dz_k = (dx_k, kf_k + K_k dx_k), dx_{k+1} = A dx + B dw + E dy + defect.
+// One wavefront per instance of the step list, 4.5 KB of LDS: all instances are resident together and
+// hide each other's latency (inside k_ric this part ran at 4 instances per CU).
+// ------------------------------------------------------------------------------------------
+constexpr int FW_Kl = 0, FW_kf = FW_Kl + NU * NX, FW_ew = FW_kf + 32, FW_rdef = FW_ew + 42, FW_dx = FW_rdef + NX + 6,
+              FW_dzeta = FW_dx + NX, FW_LDS_DOUBLES = FW_dzeta + ZPAD;
+
+BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
+    const int count = A.L.cnt[1];
+    if (blk >= count) return;
+    const int b = A.L.step[blk], N = A.N;
+    const DynC dc = make_dync(A.o.dt);
+    const double mu = A.st[b].mu;
+    constexpr int NK = (NU * NX + 63) / 64;
     double fK[NK], fkf = 0, few = 0, frd = 0;      // stage data in flight (prefetched one stage ahead)
     auto fetch = [&](int k) {
         const size_t pi = pair_of(A, b, k);
-        const double* krec = A.krec + pi * KREC;
-        const double* rec = A.hrec + pi * HREC;
+        GCD krec = A.krec + pi * KREC;
+        GCD rec = A.hrec + pi * HREC;
         BMPC_UNROLL
-        for (int m = 0; m < NK; m++) { int e = lane + NT * m; fK[m] = (e < NU * NX) ? krec[e] : 0.0; }
+        for (int m = 0; m < NK; m++) { int e = lane + 64 * m; fK[m] = (e < NU * NX) ? krec[e] : 0.0; }
         if (lane < 32) fkf = krec[NU * NX + lane];
         if (lane < 42) few = rec[F_EW + lane];
         if (lane < NX) frd = rec[F_RDEF + lane];
     };
     fetch(1);
+    if (lane < NX) lds[FW_dx + lane] = A.dx1[(size_t)b * NX + lane];
     for (int k = 1; k < N; k++) {
         const size_t pi = pair_of(A, b, k);
         BMPC_UNROLL
-        for (int m = 0; m < NK; m++) { int e = lane + NT * m; if (e < NU * NX) RL(R_Kl)[e] = fK[m]; }
-        if (lane < 32) RL(R_kf)[lane] = fkf;
-        if (lane < 42) RL(R_ew)[lane] = few;
-        if (lane < NX) RL(R_rdef)[lane] = frd;
+        for (int m = 0; m < NK; m++) { int e = lane + 64 * m; if (e < NU * NX) lds[FW_Kl + e] = fK[m]; }
+        if (lane < 32) lds[FW_kf + lane] = fkf;
+        if (lane < 42) lds[FW_ew + lane] = few;
+        if (lane < NX) lds[FW_rdef + lane] = frd;
         if (k < N - 1) fetch(k + 1);
         BMPC_SYNC();
-        if (lane < NX) RL(R_dzeta)[lane] = RL(R_dx)[lane];
+        // dzeta = (dx, kf0 + mu kf1 + K dx)
+        double dzv = 0;
+        if (lane < NX) dzv = lds[FW_dx + lane];
         else if (lane < NZ) {
-            int l = lane - NX;
-            double s = RL(R_kf)[l] + mu * RL(R_kf)[16 + l];
-            for (int j = 0; j < NX; j++) s += RL(R_Kl)[l * NX + j] * RL(R_dx)[j];
-            RL(R_dzeta)[lane] = s;
+            const int l = lane - NX;
+            double s = lds[FW_kf + l] + mu * lds[FW_kf + 16 + l];
+            BMPC_UNROLL
+            for (int j = 0; j < NX; j++) s += lds[FW_Kl + l * NX + j] * lds[FW_dx + j];
+            dzv = s;
         }
-        BMPC_SYNC();
-        if (lane < NZ) {
-            A.dz[(size_t)lane * A.NP + pi] = RL(R_dzeta)[lane];
-            RL(R_dy)[lane] = nat_from_zeta(RL(R_dzeta), lane, dc);
-        }
+        if (lane < NZ) { lds[FW_dzeta + lane] = dzv; A.dz[(size_t)lane * A.NP + pi] = dzv; }
         BMPC_SYNC();
         if (k < N - 1) {
+            double v = 0;
             if (lane < NX) {
-                const LDSD* d = RL(R_dzeta);
-                int i = lane;
-                double v;
+                const LDSD* d = lds + FW_dzeta;
+                const int i = lane;
                 if (i < Z_DQ) v = d[i] + dc.dt * d[i + 7] + 0.5 * dc.dt * dc.dt * d[i + 14] + dc.b3 * d[Z_U + i];
                 else if (i < Z_DDQ) v = d[i] + dc.dt * d[i + 7] + dc.b2 * d[Z_U + i - 7];
                 else if (i < Z_PI) v = d[i] + dc.b1 * d[Z_U + i - 14];
                 else if (i < Z_RS) {
-                    int a = i - Z_PI;
+                    const int a = i - Z_PI;
                     v = d[i];
-                    for (int j = 0; j < 7; j++)
-                        v += dc.dt * (RL(R_ew)[7 * a + j] * RL(R_dy)[Z_Q + j] + RL(R_ew)[21 + 7 * a + j] * RL(R_dy)[Z_DQ + j]);
+                    BMPC_UNROLL
+                    for (int j = 0; j < 7; j++) {      // natural steps dq = dq~ + c3 du, d(dq) = d(dq~) + c2 du
+                        const double dyq = d[Z_Q + j] + dc.c3 * d[Z_U + j], dydq = d[Z_DQ + j] + dc.c2 * d[Z_U + j];
+                        v += dc.dt * (lds[FW_ew + 7 * a + j] * dyq + lds[FW_ew + 21 + 7 * a + j] * dydq);
+                    }
                 } else if (i == Z_RS) v = d[i] + dc.dt * d[Z_DRS];
                 else if (i == Z_PS) v = d[i] + dc.dt * d[Z_DPS];
                 else v = d[i];
-                RL(R_dxn)[i] = v + RL(R_rdef)[i];
+                v += lds[FW_rdef + i];
             }
-            BMPC_SYNC();
-            if (lane < NX) RL(R_dx)[lane] = RL(R_dxn)[lane];
+            BMPC_SYNC();      // every lane has read dzeta / dx of this stage
+            if (lane < NX) lds[FW_dx + lane] = v;
         }
         BMPC_SYNC();
     }
-    return true;
 }
 
 // lds: RIC_LDS_DOUBLES.  One workgroup (one wavefront) per entry of the eval list.

@@ -77,13 +77,13 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     const size_t NP = ((size_t)B * (N - 1) + 63) / 64 * 64 + 64;
     A.NP = NP;
     std::vector<double> zeta(NZ * NP), zeta_t(NZ * NP), dz(NZ * NP), t(NSLOT * NP, 1.0), t_t(NSLOT * NP, 1.0),
-        z(NSLOT * NP), dtv(NSLOT * NP), dzr(NSLOT * NP), hrec(NP * HREC), krec(NP * KREC), part(NPART * NP);
+        z(NSLOT * NP), dtv(NSLOT * NP), dzr(NSLOT * NP), hrec(NP * HREC), krec(NP * KREC), part(NPART * NP), dx1v((size_t)B * NX);
     std::vector<InstState> st(B);
     std::vector<int> l_eval(B), l_step(B), l_trial(B), l_evn(B), l_trn(B), cnt(8, 0), tbl(3 * HREC);
     build_scatter_table(tbl.data());
     A.zeta = zeta.data(); A.zeta_t = zeta_t.data(); A.dz = dz.data();
     A.t = t.data(); A.t_t = t_t.data(); A.z = z.data(); A.dt = dtv.data(); A.dzr = dzr.data();
-    A.hrec = hrec.data(); A.krec = krec.data(); A.part = part.data(); A.st = st.data();
+    A.hrec = hrec.data(); A.krec = krec.data(); A.dx1 = dx1v.data(); A.part = part.data(); A.st = st.data();
     A.L.eval = l_eval.data(); A.L.step = l_step.data(); A.L.trial = l_trial.data();
     A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
     A.tbl = tbl.data();
@@ -103,6 +103,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
         launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
+        launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_rowstep_body(A, blk, l, lds.data()); }, 256);
         launch((cnt[1] + 63) / 64, [&](int blk, int l) { k_ls0_body(A, blk * 64 + l); });
