@@ -214,3 +214,18 @@ def test_full_size_batch_properties(backends):
     x = r["x"]
     for blk in range(4):
         assert np.array_equal(x[:, blk * 7 * N:(blk + 1) * 7 * N:N], batch["lbx"][:, blk * 7 * N:(blk + 1) * 7 * N:N])
+
+
+def test_hip_matches_committed_slsqp_solutions(backends, golden_dir):
+    """SURVEY 8(c) bridge (ii) on the product path: the HIP solve (through the C ABI) of the committed
+    N=10 instances lands on the solutions an independent SLSQP run found (tests/golden/gen/gen_slsqp.py)."""
+    import os
+    d = np.load(os.path.join(golden_dir, "slsqp_N10.npz"))
+    N = int(d["N"])
+    for tol, q_tol, pv_tol in ((1e-8, 1e-4, 2e-5), (1e-5, 2e-3, 5e-4)):
+        r = backends(N, tol=tol).solve_batch(d["x0"], d["lbx"], d["ubx"], d["p"])
+        assert (r["status"] == 0).all()
+        dx = np.abs(r["x"] - d["x"])
+        assert dx[:, : 7 * N].max() < q_tol
+        assert dx[:, 28 * N: 40 * N].max() < pv_tol
+        assert (np.abs(r["f"] - d["f"]) <= 1e-5 * np.abs(d["f"])).all()
