@@ -154,6 +154,16 @@ def main():
     mean_it = float(it_np.mean())
     ach_tf = alg_flops_per_solve(N, mean_it) * B / (k_ms * 1e-3) / 1e12
 
+    # HBM bytes of one batch from the PMC passes of tools/profile_round.sh (separate rocprofv3 --pmc runs of
+    # one synchronous batch of this same workload; FETCH_SIZE raw, see the note) -- null for other sizes
+    traffic, traffic_note = None, None
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tj) and (B, N) == (BATCH_PER_GPU, HORIZON):
+        t = json.load(open(tj))
+        traffic = t["fetch_bytes_raw"] + t["write_bytes"]
+        traffic_note = ("profiles/pmc_traffic.json: FETCH_SIZE (raw, 8-byte-per-lane loads are uncalibrated on gfx950, at most 2x low) "
+                        f"{t['fetch_bytes_raw'] / 1e9:.1f} GB + WRITE_SIZE {t['write_bytes'] / 1e9:.1f} GB per batch, all kernels")
+
     out = {
         "metric": "MPC solves/sec (whole node), iiwa14 7-DOF, N=20",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,7 +177,7 @@ def main():
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
                    "accepted_frac": float(ok.mean()), "gen_s": t_gen},
         "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "bmpc_k_ric (+ bmpc_k_eval, k_step, k_trial): one batch",
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": "bmpc_k_ric (+ bmpc_k_eval, k_step, k_trial): one batch",
                      "kernel_ms": k_ms, "event_ms_per_batch": float(np.mean(kernel_ms)), "alg_bytes_per_solve": alg_bytes_per_solve(N),
                      "note": "not HBM- or MFMA-bound: latency/VALU/LDS-bound small-matrix IP loop (DESIGN.md); "
                              "the meaningful limiter is FP64 VALU, reported in valu_fp64"},
@@ -179,7 +189,7 @@ def main():
         import oracle_lib as O               # cpu_baseline leg only
         cores = len(os.sched_getaffinity(0))
         nthr = min(cores, 64)
-        ns = min(B, 4 * nthr)
+        ns = min(B, 64 * nthr)          # ~15 s of host work at ~290 solves/s on 64 threads
         hess = int(be.opts.hess)
         t0 = time.perf_counter()
         ro = O.solve_batch(N, batch["x0"][:ns], batch["lbx"][:ns], batch["ubx"][:ns], batch["p"][:ns],
