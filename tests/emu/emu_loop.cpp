@@ -1,0 +1,51 @@
+// CPU build of the device-resident closed-loop step logic (boundplanner_amd/csrc/bmpc_loop.hpp) --
+// TEST INFRASTRUCTURE ONLY: lets tests/test_device_loop.py replay the reference's closed-loop trace
+// through the identical source the HIP kernels compile, without a GPU.  Never shipped, never used by
+// the product path.
+#include <cmath>
+#include <cstring>
+#define BMPC_DEV inline
+#define BMPC_INL inline
+#define BMPC_HD inline
+#define BMPC_NOINL
+typedef double LDSD;
+#define BMPC_SYNC() do {} while (0)
+#define BMPC_LANE() 0
+#define BMPC_NT 64
+#define BMPC_BLOCK() 0
+#define BMPC_NBLOCKS() 1
+#define BMPC_AS1
+using std::fmax;
+using std::fmin;
+#include "../../boundplanner_amd/csrc/bmpc_loop.hpp"
+#include "../../boundplanner_amd/csrc/bmpc_robot.hpp"
+
+using namespace bmpc;
+
+extern "C" int emu_loop_state_doubles(void) { return LS_SIZE; }
+extern "C" int emu_loop_logw(void) { return LP_LOGW; }
+extern "C" int emu_loop_field(const char* name, int* off, int* cnt) { return loop_field_lookup(name, off, cnt); }
+
+// one rollout: state S, previous solution row prev (n_w), outputs x0/lbx/ubx (n_w) and p (875)
+extern "C" void emu_loop_prepare(int N, double* S, const double* prev, double* x0, double* lbx, double* ubx, double* p) {
+    RobotConst rc;
+    fill_robot_const(rc);
+    const int n_w = 44 * N + 6;
+    for (int i = 0; i < n_w; i++) loop_bound_const(N, i, lbx + i, ubx + i);
+    loop_prepare(&rc, N, S, prev, p, lbx, ubx);
+    for (int i = 0; i < n_w; i++) x0[i] = loop_x0_elem(N, S, prev, i);
+}
+
+extern "C" void emu_loop_finish(int N, double dt, double* S, const double* x, double* prev, int status, double viol,
+                                int iters, double* log) {
+    RobotConst rc;
+    fill_robot_const(rc);
+    loop_finish(&rc, N, dt, S, x, prev, status, viol, iters, log);
+    if (S[LS_accept] != 0.0) std::memcpy(prev, x, sizeof(double) * (44 * N + 6));
+}
+
+extern "C" void emu_so3(const double* v, const double* M, double* R_of_v, double* v_of_M, double* eul_of_M) {
+    lp_rotvec_to_mat(v, R_of_v);
+    lp_mat_to_rotvec(M, v_of_M);
+    lp_euler_zyx(M, eul_of_M);
+}
