@@ -152,6 +152,12 @@ extern "C" int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p) {
     return 0;
 }
 
+extern "C" int bmpc_get_opts(const bmpc_handle* h, bmpc_opts* o) {
+    if (!h || !o) return 1;
+    *o = h->o;
+    return 0;
+}
+
 extern "C" int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg) {
     if (!h || !lbg || !ubg) return 1;
     const double INF = 1e20;

@@ -1,0 +1,267 @@
+// Device-resident closed loop (include/boundmpc.h, bmpc_loop_*): kernels around the batched solve for
+// gfx950.  Per-rollout logic: bmpc_loop.hpp (one thread per rollout -- it is sequential, data-dependent
+// bookkeeping on 3-vectors, a few microseconds per step); bulk row traffic (start vector, bound rows,
+// warm-start copy) goes through element-wise kernels so that every HBM access is coalesced.
+#include "bmpc_platform_hip.hpp"
+
+#define BMPC_NT 64
+#include "bmpc_loop.hpp"
+#include "bmpc_robot.hpp"
+
+#include <chrono>
+#include <string>
+
+#include "../../include/boundmpc.h"
+
+using namespace bmpc;
+
+__global__ __launch_bounds__(256) void bmpc_loop_k_bounds(int R, int N, double* lbx, double* ubx) {
+    const int n_w = 44 * N + 6;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)R * n_w) return;
+    loop_bound_const(N, (int)(e % n_w), lbx + e, ubx + e);
+}
+
+__global__ __launch_bounds__(64) void bmpc_loop_k_prepare(int R, int N, const RobotConst* rc, double* S, const double* prev,
+                                                          double* p, double* lbx, double* ubx) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    const size_t n_w = 44 * N + 6;
+    double* s = S + (size_t)r * LS_SIZE;
+    if (s[LS_dead] != 0.0) return;
+    loop_prepare(rc, N, s, prev + r * n_w, p + (size_t)r * NPAR, lbx + r * n_w, ubx + r * n_w);
+}
+
+__global__ __launch_bounds__(256) void bmpc_loop_k_x0(int R, int N, const double* S, const double* prev, double* x0) {
+    const int n_w = 44 * N + 6;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)R * n_w) return;
+    const size_t r = e / n_w;
+    x0[e] = loop_x0_elem(N, S + r * LS_SIZE, prev + r * n_w, (int)(e - r * n_w));
+}
+
+__global__ __launch_bounds__(64) void bmpc_loop_k_finish(int R, int N, double dt, const RobotConst* rc, double* S, const double* x,
+                                                         const double* prev, const int* status, const double* viol,
+                                                         const int* iters, double* log) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    const size_t n_w = 44 * N + 6;
+    double* s = S + (size_t)r * LS_SIZE;
+    double* lg = log ? log + (size_t)r * LP_LOGW : nullptr;
+    if (s[LS_dead] != 0.0) {
+        s[LS_accept] = 0.0;
+        if (lg) { for (int i = 0; i < LP_LOGW; i++) lg[i] = 0.0; lg[4] = 1.0; }
+        return;
+    }
+    loop_finish(rc, N, dt, s, x + r * n_w, prev + r * n_w, status[r], viol[r], iters[r], lg);
+}
+
+// prev_solution <- accepted solution (BoundMPC.py:643)
+__global__ __launch_bounds__(256) void bmpc_loop_k_keep(int R, int N, const double* S, const double* x, double* prev) {
+    const int n_w = 44 * N + 6;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)R * n_w) return;
+    if (S[(e / n_w) * LS_SIZE + LS_accept] != 0.0) prev[e] = x[e];
+}
+
+struct bmpc_loop {
+    bmpc_handle* h = nullptr;
+    int R = 0, N = 0, n_w = 0;
+    double dt = 0.1;
+    RobotConst* d_rc = nullptr;
+    double *d_S = nullptr, *d_prev = nullptr, *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr,
+           *d_x = nullptr, *d_f = nullptr, *d_viol = nullptr, *d_log = nullptr;
+    int *d_iters = nullptr, *d_status = nullptr;
+    size_t log_cap = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::string err;
+};
+
+#define LCHK(L, call)                                                            \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            (L)->err = std::string(#call) + ": " + hipGetErrorString(e_);        \
+            return 2;                                                            \
+        }                                                                        \
+    } while (0)
+
+extern "C" int bmpc_loop_state_doubles(void) { return LS_SIZE; }
+extern "C" int bmpc_loop_log_doubles(void) { return LP_LOGW; }
+extern "C" int bmpc_loop_field(const char* name, int* offset, int* count) { return loop_field_lookup(name, offset, count); }
+extern "C" const char* bmpc_loop_last_error(const bmpc_loop* L) { return L ? L->err.c_str() : "null loop"; }
+
+extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
+    if (!L) return;
+    double* bufs[] = {L->d_S, L->d_prev, L->d_x0, L->d_lbx, L->d_ubx, L->d_p, L->d_x, L->d_f, L->d_viol, L->d_log};
+    for (double* b : bufs) if (b) (void)hipFree(b);
+    if (L->d_iters) (void)hipFree(L->d_iters);
+    if (L->d_status) (void)hipFree(L->d_status);
+    if (L->d_rc) (void)hipFree(L->d_rc);
+    if (L->e0) (void)hipEventDestroy(L->e0);
+    if (L->e1) (void)hipEventDestroy(L->e1);
+    if (L->st) (void)hipStreamDestroy(L->st);
+    delete L;
+}
+
+extern "C" int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out) {
+    if (!h || !out || R <= 0) return 1;
+    bmpc_loop* L = new bmpc_loop();
+    *out = L;
+    L->h = h; L->R = R;
+    bmpc_opts o;
+    if (bmpc_get_opts(h, &o) != 0) { L->err = "bmpc_get_opts failed"; return 1; }
+    if (o.N > LP_NMAX) { L->err = "horizon too long for the device loop"; return 1; }
+    L->N = o.N; L->dt = o.dt; L->n_w = 44 * o.N + 6;
+    LCHK(L, hipSetDevice(o.device));
+    RobotConst rc;
+    fill_robot_const(rc);
+    LCHK(L, hipMalloc((void**)&L->d_rc, sizeof(RobotConst)));
+    LCHK(L, hipMemcpy(L->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
+    const size_t nw = (size_t)R * L->n_w * sizeof(double);
+    LCHK(L, hipMalloc((void**)&L->d_S, (size_t)R * LS_SIZE * sizeof(double)));
+    LCHK(L, hipMemset(L->d_S, 0, (size_t)R * LS_SIZE * sizeof(double)));
+    double** rows[] = {&L->d_prev, &L->d_x0, &L->d_lbx, &L->d_ubx, &L->d_x};
+    for (double** b : rows) { LCHK(L, hipMalloc((void**)b, nw)); LCHK(L, hipMemset(*b, 0, nw)); }
+    LCHK(L, hipMalloc((void**)&L->d_p, (size_t)R * NPAR * sizeof(double)));
+    LCHK(L, hipMalloc((void**)&L->d_f, (size_t)R * sizeof(double)));
+    LCHK(L, hipMalloc((void**)&L->d_viol, (size_t)R * sizeof(double)));
+    LCHK(L, hipMalloc((void**)&L->d_iters, (size_t)R * sizeof(int)));
+    LCHK(L, hipMalloc((void**)&L->d_status, (size_t)R * sizeof(int)));
+    LCHK(L, hipMemset(L->d_viol, 0, (size_t)R * sizeof(double)));
+    LCHK(L, hipMemset(L->d_iters, 0, (size_t)R * sizeof(int)));
+    LCHK(L, hipMemset(L->d_status, 0, (size_t)R * sizeof(int)));
+    LCHK(L, hipStreamCreate(&L->st));
+    LCHK(L, hipEventCreate(&L->e0));
+    LCHK(L, hipEventCreate(&L->e1));
+    const size_t ne = (size_t)R * L->n_w;
+    hipLaunchKernelGGL(bmpc_loop_k_bounds, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, R, L->N, L->d_lbx, L->d_ubx);
+    LCHK(L, hipGetLastError());
+    LCHK(L, hipStreamSynchronize(L->st));
+    return 0;
+}
+
+static bool range_ok(bmpc_loop* L, int first, int count) {
+    if (!L || first < 0 || count <= 0 || first + count > L->R) { if (L) L->err = "rollout range out of bounds"; return false; }
+    return true;
+}
+
+extern "C" int bmpc_loop_upload(bmpc_loop* L, int first, int count, const double* state, const double* prev) {
+    if (!range_ok(L, first, count) || !state) return 1;
+    LCHK(L, hipMemcpy(L->d_S + (size_t)first * LS_SIZE, state, (size_t)count * LS_SIZE * sizeof(double), hipMemcpyHostToDevice));
+    if (prev) LCHK(L, hipMemcpy(L->d_prev + (size_t)first * L->n_w, prev, (size_t)count * L->n_w * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int bmpc_loop_download(bmpc_loop* L, int first, int count, double* state, double* prev) {
+    if (!range_ok(L, first, count)) return 1;
+    LCHK(L, hipStreamSynchronize(L->st));
+    if (state) LCHK(L, hipMemcpy(state, L->d_S + (size_t)first * LS_SIZE, (size_t)count * LS_SIZE * sizeof(double), hipMemcpyDeviceToHost));
+    if (prev) LCHK(L, hipMemcpy(prev, L->d_prev + (size_t)first * L->n_w, (size_t)count * L->n_w * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int launch_prepare(bmpc_loop* L) {
+    const size_t ne = (size_t)L->R * L->n_w;
+    hipLaunchKernelGGL(bmpc_loop_k_prepare, dim3((L->R + 63) / 64), dim3(64), 0, L->st, L->R, L->N, L->d_rc, L->d_S, L->d_prev,
+                       L->d_p, L->d_lbx, L->d_ubx);
+    hipLaunchKernelGGL(bmpc_loop_k_x0, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, L->R, L->N, L->d_S, L->d_prev, L->d_x0);
+    LCHK(L, hipGetLastError());
+    return 0;
+}
+
+static int launch_finish(bmpc_loop* L, double* d_log_rows) {
+    const size_t ne = (size_t)L->R * L->n_w;
+    hipLaunchKernelGGL(bmpc_loop_k_finish, dim3((L->R + 63) / 64), dim3(64), 0, L->st, L->R, L->N, L->dt, L->d_rc, L->d_S, L->d_x,
+                       L->d_prev, L->d_status, L->d_viol, L->d_iters, d_log_rows);
+    hipLaunchKernelGGL(bmpc_loop_k_keep, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, L->R, L->N, L->d_S, L->d_x, L->d_prev);
+    LCHK(L, hipGetLastError());
+    return 0;
+}
+
+static int ensure_log(bmpc_loop* L, size_t rows) {
+    if (rows <= L->log_cap) return 0;
+    if (L->d_log) (void)hipFree(L->d_log);
+    L->d_log = nullptr; L->log_cap = 0;
+    LCHK(L, hipMalloc((void**)&L->d_log, rows * LP_LOGW * sizeof(double)));
+    L->log_cap = rows;
+    return 0;
+}
+
+static int do_solve(bmpc_loop* L) {
+    int rc = bmpc_solve_dev(L->h, L->R, L->d_x0, L->d_lbx, L->d_ubx, L->d_p, L->d_x, nullptr, L->d_f, L->d_iters, L->d_status,
+                            L->d_viol, (void*)L->st);
+    if (rc != 0) { L->err = std::string("bmpc_solve_dev: ") + bmpc_last_error(L->h); return rc; }
+    return 0;
+}
+
+extern "C" int bmpc_loop_prepare(bmpc_loop* L) {
+    if (!L) return 1;
+    if (int rc = launch_prepare(L)) return rc;
+    LCHK(L, hipStreamSynchronize(L->st));
+    return 0;
+}
+
+extern "C" int bmpc_loop_solve(bmpc_loop* L) { return L ? do_solve(L) : 1; }
+
+extern "C" int bmpc_loop_finish(bmpc_loop* L, double* log) {
+    if (!L) return 1;
+    if (log) { if (int rc = ensure_log(L, (size_t)L->R)) return rc; }
+    if (int rc = launch_finish(L, log ? L->d_log : nullptr)) return rc;
+    LCHK(L, hipStreamSynchronize(L->st));
+    if (log) LCHK(L, hipMemcpy(log, L->d_log, (size_t)L->R * LP_LOGW * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_total, float* ms_solve) {
+    if (!L || nsteps <= 0) return 1;
+    if (log) { if (int rc = ensure_log(L, (size_t)nsteps * L->R)) return rc; }
+    double solve_s = 0.0;
+    LCHK(L, hipEventRecord(L->e0, L->st));
+    for (int s = 0; s < nsteps; s++) {
+        if (int rc = launch_prepare(L)) return rc;
+        auto t0 = std::chrono::steady_clock::now();
+        if (int rc = do_solve(L)) return rc;
+        solve_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (int rc = launch_finish(L, log ? L->d_log + (size_t)s * L->R * LP_LOGW : nullptr)) return rc;
+    }
+    LCHK(L, hipEventRecord(L->e1, L->st));
+    LCHK(L, hipStreamSynchronize(L->st));
+    float ms = 0.f;
+    LCHK(L, hipEventElapsedTime(&ms, L->e0, L->e1));
+    if (ms_total) *ms_total = ms;
+    if (ms_solve) *ms_solve = (float)(1e3 * solve_s);
+    if (log) LCHK(L, hipMemcpy(log, L->d_log, (size_t)nsteps * L->R * LP_LOGW * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int bmpc_loop_problem(bmpc_loop* L, double* x0, double* lbx, double* ubx, double* p) {
+    if (!L) return 1;
+    LCHK(L, hipStreamSynchronize(L->st));
+    const size_t nw = (size_t)L->R * L->n_w * sizeof(double);
+    if (x0) LCHK(L, hipMemcpy(x0, L->d_x0, nw, hipMemcpyDeviceToHost));
+    if (lbx) LCHK(L, hipMemcpy(lbx, L->d_lbx, nw, hipMemcpyDeviceToHost));
+    if (ubx) LCHK(L, hipMemcpy(ubx, L->d_ubx, nw, hipMemcpyDeviceToHost));
+    if (p) LCHK(L, hipMemcpy(p, L->d_p, (size_t)L->R * NPAR * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int bmpc_loop_solution(bmpc_loop* L, double* x, int* iters, int* status, double* viol) {
+    if (!L) return 1;
+    LCHK(L, hipStreamSynchronize(L->st));
+    if (x) LCHK(L, hipMemcpy(x, L->d_x, (size_t)L->R * L->n_w * sizeof(double), hipMemcpyDeviceToHost));
+    if (iters) LCHK(L, hipMemcpy(iters, L->d_iters, (size_t)L->R * sizeof(int), hipMemcpyDeviceToHost));
+    if (status) LCHK(L, hipMemcpy(status, L->d_status, (size_t)L->R * sizeof(int), hipMemcpyDeviceToHost));
+    if (viol) LCHK(L, hipMemcpy(viol, L->d_viol, (size_t)L->R * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int bmpc_loop_set_solution(bmpc_loop* L, const double* x, const int* iters, const int* status, const double* viol) {
+    if (!L || !x || !status || !viol) return 1;
+    LCHK(L, hipMemcpy(L->d_x, x, (size_t)L->R * L->n_w * sizeof(double), hipMemcpyHostToDevice));
+    if (iters) LCHK(L, hipMemcpy(L->d_iters, iters, (size_t)L->R * sizeof(int), hipMemcpyHostToDevice));
+    LCHK(L, hipMemcpy(L->d_status, status, (size_t)L->R * sizeof(int), hipMemcpyHostToDevice));
+    LCHK(L, hipMemcpy(L->d_viol, viol, (size_t)L->R * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}

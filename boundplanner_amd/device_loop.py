@@ -86,3 +86,115 @@ def state_view(lay, S):
     """dict of named views into one state vector (or a [R, size] array of them)."""
     S = np.asarray(S)
     return {k: S[..., oc[0]:oc[0] + oc[1]] for k, oc in lay.items() if k != "_size"}
+
+
+class DeviceLoop:
+    """R closed-loop rollouts on one GPU.  `backend` is a HipBoundMPC (its handle's solver is borrowed).
+
+    Typical use (tools/closed_loop_device.py):
+        loop = DeviceLoop(backend, R)
+        loop.set_rollout(r, mpc, q, ...)      # host objects after BoundMPC.__init__ / update
+        loop.upload()
+        log = loop.run(nsteps)                # [nsteps, R, log_doubles]
+    """
+
+    LOG = {"iters": 0, "status": 1, "viol": 2, "error_count": 3, "dead": 4, "phi": 5, "phi_max": 6, "split1": 7,
+           "sector": 8, "switch": 9, "p_lie": slice(10, 16), "q": slice(16, 23)}
+
+    def __init__(self, backend, R):
+        from .solver import load_library
+        self.lib = load_library()
+        self.be, self.R, self.N = backend, int(R), backend.N
+        self.lay = read_layout(self.lib.bmpc_loop_field, self.lib.bmpc_loop_state_doubles)
+        self.logw = self.lib.bmpc_loop_log_doubles()
+        self._l = ctypes.c_void_p()
+        rc = self.lib.bmpc_loop_create(backend._h, self.R, ctypes.byref(self._l))
+        if rc != 0:
+            msg = self.lib.bmpc_loop_last_error(self._l).decode() if self._l else "invalid arguments"
+            raise RuntimeError(f"bmpc_loop_create failed ({rc}): {msg} -- the device loop has no CPU fallback")
+        self.state = np.zeros((self.R, self.lay["_size"]))
+        self.prev = np.zeros((self.R, backend.n_w))
+        self.ms_total = self.ms_solve = 0.0
+
+    def close(self):
+        if getattr(self, "_l", None):
+            self.lib.bmpc_loop_destroy(self._l)
+            self._l = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.bmpc_loop_last_error(self._l).decode()}")
+
+    def _P(self, a):
+        return a.ctypes.data_as(_dp) if a is not None else None
+
+    # ---- host <-> device state
+    def set_rollout(self, r, mpc, q, dq, ddq, jerk, qf, v, p_lie):
+        self.state[r] = pack_state(self.lay, mpc, q, dq, ddq, jerk, qf, v, p_lie)
+        if mpc.prev_solution is not None:
+            self.prev[r] = mpc.prev_solution
+
+    def upload(self, first=0, count=None):
+        count = self.R - first if count is None else count
+        self._chk(self.lib.bmpc_loop_upload(self._l, first, count, self._P(self.state[first:first + count]),
+                                            self._P(self.prev[first:first + count])), "bmpc_loop_upload")
+
+    def download(self):
+        self._chk(self.lib.bmpc_loop_download(self._l, 0, self.R, self._P(self.state), self._P(self.prev)), "bmpc_loop_download")
+        return state_view(self.lay, self.state)
+
+    def replan(self, r, mpc, p_via, r_via, bp1, br1, e_r_bound, a_sets, b_sets):
+        """MPCNode.update_reference for rollout r (MPCNode.py:82-104): the host BoundMPC object `mpc` of this
+        rollout is updated with the new via path from the rollout's CURRENT device state and re-serialised; warm
+        start, slacks0 and error count carry over (a15).  Call download() first, upload() afterwards."""
+        V = state_view(self.lay, self.state[r])
+        mpc.slacks0 = V["slacks0"].copy(); mpc.error_count = int(V["error_count"][0])
+        mpc.prev_solution = self.prev[r].copy() if V["has_prev"][0] != 0 else None
+        q = V["q"].copy()
+        mpc.update(p_via, r_via, bp1, br1, e_r_bound, a_sets, b_sets, [], V["v"].copy(), p0=V["p_lie"].copy(),
+                   params=type("P", (), {"weights": V["weights"].copy()})())
+        self.state[r] = pack_state(self.lay, mpc, q, V["dq"].copy(), V["ddq"].copy(), V["jerk"].copy(), q, V["v"].copy(),
+                                   V["p_lie"].copy())
+
+    # ---- stepping
+    def run(self, nsteps, log=True):
+        out = np.zeros((nsteps, self.R, self.logw)) if log else None
+        mt, ms = ctypes.c_float(), ctypes.c_float()
+        self._chk(self.lib.bmpc_loop_run(self._l, int(nsteps), self._P(out), ctypes.byref(mt), ctypes.byref(ms)), "bmpc_loop_run")
+        self.ms_total, self.ms_solve = mt.value, ms.value
+        return out
+
+    def prepare(self):
+        self._chk(self.lib.bmpc_loop_prepare(self._l), "bmpc_loop_prepare")
+
+    def solve(self):
+        self._chk(self.lib.bmpc_loop_solve(self._l), "bmpc_loop_solve")
+
+    def finish(self):
+        out = np.zeros((self.R, self.logw))
+        self._chk(self.lib.bmpc_loop_finish(self._l, self._P(out)), "bmpc_loop_finish")
+        return out
+
+    def problem(self):
+        nw = self.be.n_w
+        x0, lbx, ubx, p = np.zeros((self.R, nw)), np.zeros((self.R, nw)), np.zeros((self.R, nw)), np.zeros((self.R, 875))
+        self._chk(self.lib.bmpc_loop_problem(self._l, self._P(x0), self._P(lbx), self._P(ubx), self._P(p)), "bmpc_loop_problem")
+        return x0, lbx, ubx, p
+
+    def solution(self):
+        x = np.zeros((self.R, self.be.n_w)); it = np.zeros(self.R, np.int32); st = np.zeros(self.R, np.int32); viol = np.zeros(self.R)
+        self._chk(self.lib.bmpc_loop_solution(self._l, self._P(x), it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), self._P(viol)),
+                  "bmpc_loop_solution")
+        return dict(x=x, iters=it, status=st, viol=viol)
+
+    def set_solution(self, x, iters, status, viol):
+        x = np.ascontiguousarray(x, float); viol = np.ascontiguousarray(viol, float)
+        it = np.ascontiguousarray(iters, np.int32); st = np.ascontiguousarray(status, np.int32)
+        self._chk(self.lib.bmpc_loop_set_solution(self._l, self._P(x), it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), self._P(viol)),
+                  "bmpc_loop_set_solution")

@@ -53,6 +53,9 @@ const char* bmpc_last_error(const bmpc_handle* h);
 /* n_w = 44N+6, n_g = 147(N-1)+21, n_p = 875 */
 int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p);
 
+/* the options the handle was created with */
+int bmpc_get_opts(const bmpc_handle* h, bmpc_opts* o);
+
 /* constant constraint bounds (self.lbg / self.ubg, casadi_ocp_formulation.py:145-380);
  * infinities are returned as +-1e20 */
 int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg);
@@ -98,6 +101,40 @@ int bmpc_last_kernel_ms(bmpc_handle* h, float* ms);
 
 /* Diagnostic builds (-DBMPC_PROFILE) only: per-phase shader-cycle sums of the last launches. */
 int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident closed loop: R rollouts advanced in lock step, one batched solve per MPC step,
+ * per-rollout state in HBM.  Replaces, for every rollout and step, the host code around the solver
+ * call: BoundMPC.step before the solve (BoundMPC.py:388-589), the acceptance test and
+ * compute_return_data (BoundMPC.py:604-1040), ReferencePath.update (ReferencePath.py:187-207),
+ * MPCNode.step's state advance with integrate_joint (MPCNode.py:106-160, util_functions.py:55-65).
+ * Plan-time construction (ReferencePath.__init__, BoundMPC.update) stays with the caller, who
+ * serialises it into the state vector: bmpc_loop_state_doubles() doubles per rollout, fields located by
+ * name with bmpc_loop_field() (names = LP_FIELDS of boundplanner_amd/csrc/bmpc_loop.hpp).
+ * Obstacle-free scenes only (collision sets = boxes around the collision points).
+ * All pointers below are HOST pointers.  The loop borrows the handle's solver: do not use the handle
+ * for other solves while a loop call is running. */
+typedef struct bmpc_loop bmpc_loop;
+int bmpc_loop_state_doubles(void);
+int bmpc_loop_log_doubles(void);
+int bmpc_loop_field(const char* name, int* offset, int* count);
+int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out);
+void bmpc_loop_destroy(bmpc_loop* l);
+const char* bmpc_loop_last_error(const bmpc_loop* l);
+/* state: [count][state_doubles]; prev: [count][n_w] previous solutions (warm start) or NULL */
+int bmpc_loop_upload(bmpc_loop* l, int first, int count, const double* state, const double* prev);
+int bmpc_loop_download(bmpc_loop* l, int first, int count, double* state, double* prev);
+/* nsteps MPC steps of all rollouts; log: [nsteps][R][log_doubles] or NULL -- per row: iters, status,
+ * viol, error_count, dead, phi, phi_max, split_idx[1], sector, switch, p_lie(6), q(7).
+ * ms_total: HIP-event time of the whole run on the loop's stream; ms_solve: host time inside the solves */
+int bmpc_loop_run(bmpc_loop* l, int nsteps, double* log, float* ms_total, float* ms_solve);
+/* the three phases of one step separately, and access to the solver arguments / solution (tests) */
+int bmpc_loop_prepare(bmpc_loop* l);
+int bmpc_loop_solve(bmpc_loop* l);
+int bmpc_loop_finish(bmpc_loop* l, double* log);
+int bmpc_loop_problem(bmpc_loop* l, double* x0, double* lbx, double* ubx, double* p);
+int bmpc_loop_solution(bmpc_loop* l, double* x, int* iters, int* status, double* viol);
+int bmpc_loop_set_solution(bmpc_loop* l, const double* x, const int* iters, const int* status, const double* viol);
 
 #ifdef __cplusplus
 }

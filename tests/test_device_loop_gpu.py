@@ -1,0 +1,137 @@
+"""The device-resident closed loop on the MI355X (C ABI bmpc_loop_*): the HIP kernels replay the reference's
+closed-loop trace, and the full device loop (prepare kernel -> batched HIP solve -> finish kernel) tracks the
+host loop (BatchMPCNode: the pinned per-instance host mirror around the same HIP solver)."""
+import os
+
+import numpy as np
+import pytest
+
+from boundplanner_amd.params import Params, get_default_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(N):
+    base = get_default_params()
+    return Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+
+
+def test_kernels_replay_the_reference_trace(golden_dir):
+    import oracle_lib as O
+    from boundplanner_amd.device_loop import DeviceLoop, state_view
+    from boundplanner_amd.mpc_node import MPCNode
+    from boundplanner_amd.robot_model import RobotModel
+    from boundplanner_amd.solver import HipBoundMPC
+    from test_closed_loop import ReplaySolver
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    N = int(g["N"])
+    params = _params(N)
+    be = HipBoundMPC(N)
+    R = 3                                     # identical rollouts: the result may not depend on the batch slot
+    loop = DeviceLoop(be, R)
+    shadow = MPCNode(g["in_q"][0], RobotModel(O.fk_batch), lambda n, dt: ReplaySolver(g, tol=1e-9), params=params)
+    for r in range(R):
+        loop.set_rollout(r, shadow.mpc, shadow.q, shadow.dq, shadow.ddq, shadow.jerk, shadow.qf, shadow.v, shadow.p_lie)
+    loop.upload()
+    n_steps, n_update = g["in_q"].shape[0], int(g["n_update"])
+    big = lambda a: np.nan_to_num(np.asarray(a, float), posinf=1e20, neginf=-1e20)
+    for k in range(n_steps):
+        if k == n_update:
+            # new plan: host-side BoundMPC.update / ReferencePath construction, re-serialised; warm start, slacks0 and
+            # error count are NOT reset (a15) and stay what the device holds
+            V = loop.download()
+            keep = {f: V[f].copy() for f in ("slacks0", "error_count", "has_prev", "q", "dq", "ddq", "jerk", "v", "p_lie")}
+            prev = loop.prev.copy()
+            shadow.update_reference([p.copy() for p in g["via_p_via"]], [q.copy() for q in g["via_r_via"]],
+                                    [b.copy() for b in g["via_bp1"]], [b.copy() for b in g["via_br1"]],
+                                    [e.copy() for e in g["via_e_r_bound"]], [a.copy() for a in g["via_a_sets"]],
+                                    [b.copy() for b in g["via_b_sets"]], [])
+            for r in range(R):
+                loop.set_rollout(r, shadow.mpc, keep["q"][r], keep["dq"][r], keep["ddq"][r], keep["jerk"][r], keep["q"][r],
+                                 keep["v"][r], keep["p_lie"][r])
+                W = state_view(loop.lay, loop.state[r])
+                for f in ("slacks0", "error_count", "has_prev"):
+                    W[f][:] = keep[f][r]
+            loop.prev[:] = prev
+            loop.upload()
+        loop.prepare()
+        x0, lbx, ubx, p = loop.problem()
+        for r in range(R):
+            for name, mine in (("x0", x0), ("lbx", lbx), ("ubx", ubx), ("p", p)):
+                d = np.abs(mine[r] - big(g["call_" + name][k])).max()
+                assert d < 1e-9, (k, r, name, d)
+        loop.set_solution(np.tile(g["call_x"][k], (R, 1)), np.full(R, int(g["iters"][k])), np.full(R, int(g["status"][k])),
+                          np.full(R, float(g["viol"][k])))
+        log = loop.finish()
+        shadow.step()
+        V = loop.download()
+        for r in range(R):
+            assert [int(s) for s in V["split"][r]] == list(g["split_idxs"][k]), (k, r)
+            assert int(V["rp_sector"][r][0]) == int(g["sector"][k])
+            for f, key in (("pr_ref", "pr_ref"), ("phi_current", "phi_current"), ("phi_max", "phi_max"), ("slacks0", "slacks0"),
+                           ("rp_pd", "rp_pd"), ("q", "out_q"), ("dq", "out_dq"), ("ddq", "out_ddq"), ("v", "out_v"),
+                           ("qf", "out_qf"), ("p_lie", "out_p_lie")):
+                assert np.abs(V[f][r] - np.asarray(g[key][k]).reshape(-1)).max() < 1e-9, (k, r, f)
+            assert abs(log[r, loop.LOG["phi"]] - g["phi_current"][k][0]) < 1e-9
+    assert (V["phi_current"][:, 0] >= V["phi_max"][:, 0] - 0.001).all()
+
+
+def _scenario(be, R, N, seed):
+    """configs[4] style: random start/goal, fixed EE workspace box, obstacle-free collision sets."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.params import normalize_set_size
+    rng = np.random.default_rng(seed)
+    q_start, q_goal = scenes.sample_start_goal(rng, be.fk, R)
+    fs, fg = be.fk(q_start), be.fk(q_goal)
+    a_ee, b_ee = scenes._box_set([-1.0, -1.0, 0.0], [1.0, 1.0, 1.2])
+    plans = []
+    for r in range(R):
+        sets = normalize_set_size([[a_ee, b_ee]], 15)
+        plans.append(dict(goal=fg["ee_pos"][r].copy(), r_via=[fs["ee_rot"][r].copy(), fg["ee_rot"][r].copy()],
+                          bp1=[np.array([0.0, 0, 1])], br1=[np.array([0.0, 0, 1])],
+                          erb=[np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180], a=[sets[0][0]], b=[sets[0][1]]))
+    return q_start, plans
+
+
+def test_device_loop_tracks_host_loop():
+    from boundplanner_amd.batch_node import BatchMPCNode
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.solver import HipBoundMPC
+    N, R, steps = 10, 12, 14
+    params = _params(N)
+    be = HipBoundMPC(N, max_batch=R)
+    q_start, plans = _scenario(be, R, N, 4096)
+    cp = lambda P: dict(goal=P["goal"].copy(), r_via=[m.copy() for m in P["r_via"]], bp1=[b.copy() for b in P["bp1"]],
+                        br1=[b.copy() for b in P["br1"]], erb=[e.copy() for e in P["erb"]], a=[a.copy() for a in P["a"]],
+                        b=[b.copy() for b in P["b"]])
+    # host loop
+    host = BatchMPCNode(be, q_start, params)
+    host.step()                                          # start-up solve on the trivial path
+    for r in range(R):
+        P = cp(plans[r])
+        host.update_reference(r, [host.p_lie[r][:3].copy(), P["goal"]], P["r_via"], P["bp1"], P["br1"], P["erb"], P["a"], P["b"])
+    # device loop: same start-up step, then the same plans
+    ref = BatchMPCNode(be, q_start, params)               # only its freshly constructed host objects are used
+    loop = DeviceLoop(be, R)
+    for r in range(R):
+        loop.set_rollout(r, ref.mpcs[r], ref.q[r], ref.dq[r], ref.ddq[r], ref.jerk[r], ref.qf[r], ref.v[r], ref.p_lie[r])
+    loop.upload()
+    loop.run(1)
+    V = loop.download()
+    assert np.abs(V["q"] - host.q).max() < 1e-9 and np.abs(V["p_lie"] - host.p_lie).max() < 1e-9
+    for r in range(R):
+        P = cp(plans[r])
+        loop.replan(r, ref.mpcs[r], [V["p_lie"][r][:3].copy(), P["goal"]], P["r_via"], P["bp1"], P["br1"], P["erb"], P["a"], P["b"])
+    loop.upload()
+    dmax = 0.0
+    for k in range(steps):
+        host.step()
+        log = loop.run(1)[0]
+        phi_host = np.array([m.phi_current[0] for m in host.mpcs])
+        dmax = max(dmax, np.abs(log[:, loop.LOG["q"]] - host.q).max(), np.abs(log[:, loop.LOG["p_lie"]] - host.p_lie).max(),
+                   np.abs(log[:, loop.LOG["phi"]] - phi_host).max())
+        assert (log[:, loop.LOG["iters"]] == host.iters[-1]).mean() > 0.9, k
+        assert (log[:, loop.LOG["split1"]] == np.array([m.split_idxs[1] for m in host.mpcs])).all(), k
+    # same solver, same arguments to rounding: the loops stay together far below the solver tolerance
+    assert dmax < 1e-6, dmax
+    assert (phi_host > 0.05).all()                       # the rollouts actually move along their paths

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] on the device-resident loop: R parallel rollouts x S MPC steps, horizon N, fixed sets,
+warm start exactly as the reference warm-starts (previous solution unshifted, Q11).  Per step: prepare kernel ->
+batched HIP solve -> finish kernel; the per-rollout state never leaves HBM, the host only polls the solver's
+active count.  Rollouts that reached the path end keep stepping (idle solves count).
+
+  python tools/closed_loop_device.py --rollouts 4096 --horizon 30 --steps 200
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rollouts", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--chunk", type=int, default=25, help="MPC steps per bmpc_loop_run call (progress lines)")
+    ap.add_argument("--seed", type=int, default=4096)
+    args = ap.parse_args()
+    from boundplanner_amd import scenes
+    from boundplanner_amd.batch_node import BatchMPCNode
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.params import Params, get_default_params, normalize_set_size
+    from boundplanner_amd.solver import HipBoundMPC
+
+    N, R = args.horizon, args.rollouts
+    base = get_default_params()
+    params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    be = HipBoundMPC(N, max_batch=R)
+    rng = np.random.default_rng(args.seed)
+    t0 = time.perf_counter()
+    q_start, q_goal = scenes.sample_start_goal(rng, be.fk, R)
+    fs, fg = be.fk(q_start), be.fk(q_goal)
+    seed_objs = BatchMPCNode(be, q_start, params)          # host construction of the R BoundMPC objects (trivial start-up path)
+    loop = DeviceLoop(be, R)
+    for r in range(R):
+        loop.set_rollout(r, seed_objs.mpcs[r], seed_objs.q[r], seed_objs.dq[r], seed_objs.ddq[r], seed_objs.jerk[r],
+                         seed_objs.qf[r], seed_objs.v[r], seed_objs.p_lie[r])
+    loop.upload()
+    loop.run(1, log=False)                                 # start-up solve on the trivial path (example :28-29)
+    V = loop.download()
+    a_ee, b_ee = scenes._box_set([-1.0, -1.0, 0.0], [1.0, 1.0, 1.2])
+    for r in range(R):
+        sets = normalize_set_size([[a_ee, b_ee]], 15)
+        loop.replan(r, seed_objs.mpcs[r], [V["p_lie"][r][:3].copy(), fg["ee_pos"][r].copy()],
+                    [fs["ee_rot"][r].copy(), fg["ee_rot"][r].copy()], [np.array([0.0, 0, 1])], [np.array([0.0, 0, 1])],
+                    [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180], [sets[0][0]], [sets[0][1]])
+    loop.upload()
+    t_plan = time.perf_counter() - t0
+    print(f"plan-time host setup of {R} rollouts: {t_plan:.1f} s", file=sys.stderr, flush=True)
+
+    L = loop.LOG
+    iters, fails, reached_at = [], [], np.full(R, -1)
+    ms_total = ms_solve = 0.0
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.steps:
+        n = min(args.chunk, args.steps - done)
+        log = loop.run(n)
+        ms_total += loop.ms_total; ms_solve += loop.ms_solve
+        iters.append(log[:, :, L["iters"]]); fails.append(log[:, :, L["error_count"]] > 0)
+        at_end = log[:, :, L["phi"]] >= log[:, :, L["phi_max"]] - 0.001
+        for s in range(n):
+            reached_at[(reached_at < 0) & at_end[s]] = done + s + 1
+        done += n
+        print(f"step {done}/{args.steps}: {1e3 * (time.perf_counter() - t0) / done:.1f} ms/step, mean iters {iters[-1].mean():.1f}, "
+              f"at path end {(reached_at > 0).mean():.3f}", file=sys.stderr, flush=True)
+    wall = time.perf_counter() - t0
+    it = np.concatenate(iters)
+    dead = float(log[-1, :, L["dead"]].mean())
+    out = {
+        "config": f"BASELINE configs[4]: closed loop, {R} rollouts x {args.steps} steps, N={N}, fixed sets, warm start (reference Q11), "
+                  "device-resident loop (prepare kernel -> batched solve -> finish kernel)",
+        "solves": int(R * args.steps), "wall_s": wall, "solves_per_s": R * args.steps / wall,
+        "gpu_stream_ms_total": ms_total, "host_ms_inside_solves": ms_solve, "ms_per_step": 1e3 * wall / args.steps,
+        "plan_time_host_setup_s": t_plan,
+        "iters_mean": float(it.mean()), "iters_p50": float(np.median(it)), "iters_p99": float(np.percentile(it, 99)),
+        "iters_first_step_mean": float(it[0].mean()), "fail_frac": float(np.concatenate(fails).mean()), "dead_frac": dead,
+        "reached_end_frac": float((reached_at > 0).mean()),
+        "steps_to_end_median": float(np.median(reached_at[reached_at > 0])) if (reached_at > 0).any() else None,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
