@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--chunk", type=int, default=25, help="MPC steps per bmpc_loop_run call (progress lines)")
     ap.add_argument("--seed", type=int, default=4096)
+    ap.add_argument("--groups", type=int, default=1, help="rollout groups stepped concurrently (own solver handle and stream "
+                    "each): the straggler tail of one group's solve overlaps the bulk of another's")
     args = ap.parse_args()
     from boundplanner_amd import scenes
     from boundplanner_amd.batch_node import BatchMPCNode
@@ -35,26 +37,31 @@ def main():
     N, R = args.horizon, args.rollouts
     base = get_default_params()
     params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
-    be = HipBoundMPC(N, max_batch=R)
+    G = max(1, args.groups)
+    bounds = [R * g // G for g in range(G + 1)]
+    bes = [HipBoundMPC(N, max_batch=bounds[g + 1] - bounds[g]) for g in range(G)]
+    be = bes[0]
     rng = np.random.default_rng(args.seed)
     t0 = time.perf_counter()
     q_start, q_goal = scenes.sample_start_goal(rng, be.fk, R)
     fs, fg = be.fk(q_start), be.fk(q_goal)
     seed_objs = BatchMPCNode(be, q_start, params)          # host construction of the R BoundMPC objects (trivial start-up path)
-    loop = DeviceLoop(be, R)
-    for r in range(R):
-        loop.set_rollout(r, seed_objs.mpcs[r], seed_objs.q[r], seed_objs.dq[r], seed_objs.ddq[r], seed_objs.jerk[r],
-                         seed_objs.qf[r], seed_objs.v[r], seed_objs.p_lie[r])
-    loop.upload()
-    loop.run(1, log=False)                                 # start-up solve on the trivial path (example :28-29)
-    V = loop.download()
+    loops = [DeviceLoop(bes[g], bounds[g + 1] - bounds[g]) for g in range(G)]
     a_ee, b_ee = scenes._box_set([-1.0, -1.0, 0.0], [1.0, 1.0, 1.2])
-    for r in range(R):
-        sets = normalize_set_size([[a_ee, b_ee]], 15)
-        loop.replan(r, seed_objs.mpcs[r], [V["p_lie"][r][:3].copy(), fg["ee_pos"][r].copy()],
-                    [fs["ee_rot"][r].copy(), fg["ee_rot"][r].copy()], [np.array([0.0, 0, 1])], [np.array([0.0, 0, 1])],
-                    [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180], [sets[0][0]], [sets[0][1]])
-    loop.upload()
+    for g, loop in enumerate(loops):
+        for i, r in enumerate(range(bounds[g], bounds[g + 1])):
+            loop.set_rollout(i, seed_objs.mpcs[r], seed_objs.q[r], seed_objs.dq[r], seed_objs.ddq[r], seed_objs.jerk[r],
+                             seed_objs.qf[r], seed_objs.v[r], seed_objs.p_lie[r])
+        loop.upload()
+        loop.run(1, log=False)                             # start-up solve on the trivial path (example :28-29)
+        V = loop.download()
+        for i, r in enumerate(range(bounds[g], bounds[g + 1])):
+            sets = normalize_set_size([[a_ee, b_ee]], 15)
+            loop.replan(i, seed_objs.mpcs[r], [V["p_lie"][i][:3].copy(), fg["ee_pos"][r].copy()],
+                        [fs["ee_rot"][r].copy(), fg["ee_rot"][r].copy()], [np.array([0.0, 0, 1])], [np.array([0.0, 0, 1])],
+                        [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180], [sets[0][0]], [sets[0][1]])
+        loop.upload()
+    loop = loops[0]
     t_plan = time.perf_counter() - t0
     print(f"plan-time host setup of {R} rollouts: {t_plan:.1f} s", file=sys.stderr, flush=True)
 
@@ -65,8 +72,18 @@ def main():
     done = 0
     while done < args.steps:
         n = min(args.chunk, args.steps - done)
-        log = loop.run(n)
-        ms_total += loop.ms_total; ms_solve += loop.ms_solve
+        if G == 1:
+            log = loop.run(n)
+        else:       # one host thread per group; bmpc_loop_run releases the GIL for its whole duration
+            import threading
+            parts = [None] * G
+            def work(g):
+                parts[g] = loops[g].run(n)
+            th = [threading.Thread(target=work, args=(g,)) for g in range(G)]
+            for t in th: t.start()
+            for t in th: t.join()
+            log = np.concatenate(parts, axis=1)
+        ms_total += max(l.ms_total for l in loops); ms_solve += max(l.ms_solve for l in loops)
         iters.append(log[:, :, L["iters"]]); fails.append(log[:, :, L["error_count"]] > 0)
         at_end = log[:, :, L["phi"]] >= log[:, :, L["phi_max"]] - 0.001
         for s in range(n):
@@ -79,7 +96,8 @@ def main():
     dead = float(log[-1, :, L["dead"]].mean())
     out = {
         "config": f"BASELINE configs[4]: closed loop, {R} rollouts x {args.steps} steps, N={N}, fixed sets, warm start (reference Q11), "
-                  "device-resident loop (prepare kernel -> batched solve -> finish kernel)",
+                  "device-resident loop (prepare kernel -> batched solve -> finish kernel)" + (f", {G} rollout groups in flight" if G > 1 else ""),
+        "groups": G,
         "solves": int(R * args.steps), "wall_s": wall, "solves_per_s": R * args.steps / wall,
         "gpu_stream_ms_total": ms_total, "host_ms_inside_solves": ms_solve, "ms_per_step": 1e3 * wall / args.steps,
         "plan_time_host_setup_s": t_plan,
