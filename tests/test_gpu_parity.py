@@ -49,7 +49,10 @@ def test_fk_matches_reference_tapes(backends, golden_dir):
 #   joint space q, dq, ddq           |d|_inf <= 2e-3        jerk u   |d|_inf <= 2e-2 (bound 35)
 # with identical iteration counts (+-1 on a few instances), and at tol = 1e-8 agreement to 1e-5 in
 # joint space / 1e-7 in task space.
-@pytest.mark.parametrize("N,seed,rnd,B", [(6, 6, True, 16), (10, 1024, False, 64), (20, 8192, True, 48)])
+@pytest.mark.parametrize("N,seed,rnd,B", [(6, 6, True, 16), (10, 1024, False, 64), (20, 8192, True, 48),
+                                          (15, 15, True, 24),      # the reference's default horizon (util_functions.py:49)
+                                          (30, 4096, False, 24),   # configs[4]
+                                          (3, 3, True, 8)])        # shortest horizon the handle accepts
 def test_solve_matches_oracle(backends, N, seed, rnd, B):
     from boundplanner_amd import scenes
     be = backends(N)
@@ -229,3 +232,24 @@ def test_hip_matches_committed_slsqp_solutions(backends, golden_dir):
         assert dx[:, : 7 * N].max() < q_tol
         assert dx[:, 28 * N: 40 * N].max() < pv_tol
         assert (np.abs(r["f"] - d["f"]) <= 1e-5 * np.abs(d["f"])).all()
+
+
+def test_ragged_batches_and_api_misuse(backends):
+    """Batch sizes that do not fill a wavefront (3 instances of N=20 share one) or a list slot, and the error
+    convention of the C ABI (nonzero return code + message, no exception from the device)."""
+    from boundplanner_amd import scenes
+    N = 20
+    be = backends(N)
+    batch = scenes.make_batch(67, N, 5, be.fk, randomize_sets=True)
+    full = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    for B in (1, 2, 3, 4, 63, 65):
+        r = be.solve_batch(batch["x0"][:B], batch["lbx"][:B], batch["ubx"][:B], batch["p"][:B])
+        assert np.array_equal(r["x"], full["x"][:B]) and np.array_equal(r["iters"], full["iters"][:B]), B
+    sel = [66, 3, 41]                                    # order / neighbours do not matter
+    r = be.solve_batch(batch["x0"][sel], batch["lbx"][sel], batch["ubx"][sel], batch["p"][sel])
+    assert np.array_equal(r["x"], full["x"][sel])
+    rc = be.lib.bmpc_solve(be._h, 0, None, None, None, None, None, None, None, None, None, None, None, None)
+    assert rc != 0                                       # empty batch / null pointers: refused, not a crash
+    with pytest.raises(RuntimeError):
+        from boundplanner_amd.solver import HipBoundMPC
+        HipBoundMPC(2)                                   # horizon below the formulation's minimum
