@@ -152,6 +152,8 @@ extern "C" int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p) {
     return 0;
 }
 
+extern "C" void* bmpc_stream(bmpc_handle* h) { return h ? (void*)h->stream : nullptr; }
+
 extern "C" int bmpc_get_opts(const bmpc_handle* h, bmpc_opts* o) {
     if (!h || !o) return 1;
     *o = h->o;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void bmpc_loop_k_keep(int R, int N, const doub
 
 struct bmpc_loop {
     bmpc_handle* h = nullptr;
-    int R = 0, N = 0, n_w = 0;
+    int R = 0, N = 0, n_w = 0, dev = 0;
     double dt = 0.1;
     RobotConst* d_rc = nullptr;
     double *d_S = nullptr, *d_prev = nullptr, *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr,
@@ -101,7 +101,6 @@ extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
     if (L->d_rc) (void)hipFree(L->d_rc);
     if (L->e0) (void)hipEventDestroy(L->e0);
     if (L->e1) (void)hipEventDestroy(L->e1);
-    if (L->st) (void)hipStreamDestroy(L->st);
     delete L;
 }
 
@@ -114,6 +113,7 @@ extern "C" int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out) {
     if (bmpc_get_opts(h, &o) != 0) { L->err = "bmpc_get_opts failed"; return 1; }
     if (o.N > LP_NMAX) { L->err = "horizon too long for the device loop"; return 1; }
     L->N = o.N; L->dt = o.dt; L->n_w = 44 * o.N + 6;
+    L->dev = o.device;
     LCHK(L, hipSetDevice(o.device));
     RobotConst rc;
     fill_robot_const(rc);
@@ -132,7 +132,7 @@ extern "C" int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out) {
     LCHK(L, hipMemset(L->d_viol, 0, (size_t)R * sizeof(double)));
     LCHK(L, hipMemset(L->d_iters, 0, (size_t)R * sizeof(int)));
     LCHK(L, hipMemset(L->d_status, 0, (size_t)R * sizeof(int)));
-    LCHK(L, hipStreamCreate(&L->st));
+    L->st = (hipStream_t)bmpc_stream(h);      // the handle's stream: one stream (one hardware queue) per solver handle
     LCHK(L, hipEventCreate(&L->e0));
     LCHK(L, hipEventCreate(&L->e1));
     const size_t ne = (size_t)R * L->n_w;
@@ -149,6 +149,7 @@ static bool range_ok(bmpc_loop* L, int first, int count) {
 
 extern "C" int bmpc_loop_upload(bmpc_loop* L, int first, int count, const double* state, const double* prev) {
     if (!range_ok(L, first, count) || !state) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     LCHK(L, hipMemcpy(L->d_S + (size_t)first * LS_SIZE, state, (size_t)count * LS_SIZE * sizeof(double), hipMemcpyHostToDevice));
     if (prev) LCHK(L, hipMemcpy(L->d_prev + (size_t)first * L->n_w, prev, (size_t)count * L->n_w * sizeof(double), hipMemcpyHostToDevice));
     return 0;
@@ -156,6 +157,7 @@ extern "C" int bmpc_loop_upload(bmpc_loop* L, int first, int count, const double
 
 extern "C" int bmpc_loop_download(bmpc_loop* L, int first, int count, double* state, double* prev) {
     if (!range_ok(L, first, count)) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     LCHK(L, hipStreamSynchronize(L->st));
     if (state) LCHK(L, hipMemcpy(state, L->d_S + (size_t)first * LS_SIZE, (size_t)count * LS_SIZE * sizeof(double), hipMemcpyDeviceToHost));
     if (prev) LCHK(L, hipMemcpy(prev, L->d_prev + (size_t)first * L->n_w, (size_t)count * L->n_w * sizeof(double), hipMemcpyDeviceToHost));
@@ -198,6 +200,7 @@ static int do_solve(bmpc_loop* L) {
 
 extern "C" int bmpc_loop_prepare(bmpc_loop* L) {
     if (!L) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     if (int rc = launch_prepare(L)) return rc;
     LCHK(L, hipStreamSynchronize(L->st));
     return 0;
@@ -207,6 +210,7 @@ extern "C" int bmpc_loop_solve(bmpc_loop* L) { return L ? do_solve(L) : 1; }
 
 extern "C" int bmpc_loop_finish(bmpc_loop* L, double* log) {
     if (!L) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     if (log) { if (int rc = ensure_log(L, (size_t)L->R)) return rc; }
     if (int rc = launch_finish(L, log ? L->d_log : nullptr)) return rc;
     LCHK(L, hipStreamSynchronize(L->st));
@@ -216,6 +220,7 @@ extern "C" int bmpc_loop_finish(bmpc_loop* L, double* log) {
 
 extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_total, float* ms_solve) {
     if (!L || nsteps <= 0) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     if (log) { if (int rc = ensure_log(L, (size_t)nsteps * L->R)) return rc; }
     double solve_s = 0.0;
     LCHK(L, hipEventRecord(L->e0, L->st));
@@ -238,6 +243,7 @@ extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_to
 
 extern "C" int bmpc_loop_problem(bmpc_loop* L, double* x0, double* lbx, double* ubx, double* p) {
     if (!L) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     LCHK(L, hipStreamSynchronize(L->st));
     const size_t nw = (size_t)L->R * L->n_w * sizeof(double);
     if (x0) LCHK(L, hipMemcpy(x0, L->d_x0, nw, hipMemcpyDeviceToHost));
@@ -249,6 +255,7 @@ extern "C" int bmpc_loop_problem(bmpc_loop* L, double* x0, double* lbx, double* 
 
 extern "C" int bmpc_loop_solution(bmpc_loop* L, double* x, int* iters, int* status, double* viol) {
     if (!L) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     LCHK(L, hipStreamSynchronize(L->st));
     if (x) LCHK(L, hipMemcpy(x, L->d_x, (size_t)L->R * L->n_w * sizeof(double), hipMemcpyDeviceToHost));
     if (iters) LCHK(L, hipMemcpy(iters, L->d_iters, (size_t)L->R * sizeof(int), hipMemcpyDeviceToHost));
@@ -259,6 +266,7 @@ extern "C" int bmpc_loop_solution(bmpc_loop* L, double* x, int* iters, int* stat
 
 extern "C" int bmpc_loop_set_solution(bmpc_loop* L, const double* x, const int* iters, const int* status, const double* viol) {
     if (!L || !x || !status || !viol) return 1;
+    LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     LCHK(L, hipMemcpy(L->d_x, x, (size_t)L->R * L->n_w * sizeof(double), hipMemcpyHostToDevice));
     if (iters) LCHK(L, hipMemcpy(L->d_iters, iters, (size_t)L->R * sizeof(int), hipMemcpyHostToDevice));
     LCHK(L, hipMemcpy(L->d_status, status, (size_t)L->R * sizeof(int), hipMemcpyHostToDevice));

@@ -13,6 +13,9 @@ using namespace bmpc;
 #ifndef BMPC_PAIR_WPS
 #define BMPC_PAIR_WPS 1
 #endif
+#ifndef BMPC_EVAL_WPS
+#define BMPC_EVAL_WPS BMPC_PAIR_WPS
+#endif
 #ifndef BMPC_RIC_WPS
 #define BMPC_RIC_WPS 1
 #endif
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(64) void bmpc_k_init_inst(PipeArgsH H) { k_init_ins
 // dynamic LDS of the thread-per-pair kernels: [emitter tile (k_eval, k_curv)] [staged parameter vectors]
 extern __shared__ __attribute__((aligned(16))) double bmpc_dyn_lds[];
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { k_init_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_eval(PipeArgsH H) {
+__global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval(PipeArgsH H) {
     k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_points(PipeArgsH H) { k_points_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }

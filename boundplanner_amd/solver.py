@@ -26,7 +26,7 @@ class BmpcOpts(ctypes.Structure):
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
            "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_solve_dev_async", "bmpc_wait", "bmpc_active", "bmpc_fk",
-           "bmpc_last_kernel_ms", "bmpc_get_opts",
+           "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream",
            "bmpc_debug_phase_cycles",
            "bmpc_loop_state_doubles", "bmpc_loop_log_doubles", "bmpc_loop_field", "bmpc_loop_create", "bmpc_loop_destroy",
            "bmpc_loop_last_error", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_prepare",

@@ -53,6 +53,9 @@ const char* bmpc_last_error(const bmpc_handle* h);
 /* n_w = 44N+6, n_g = 147(N-1)+21, n_p = 875 */
 int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p);
 
+/* the handle's own HIP stream (a hipStream_t): the one bmpc_solve, bmpc_solve_dev_async and the device loop run on */
+void* bmpc_stream(bmpc_handle* h);
+
 /* the options the handle was created with */
 int bmpc_get_opts(const bmpc_handle* h, bmpc_opts* o);
 
