@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--chunk", type=int, default=25, help="MPC steps per bmpc_loop_run call (progress lines)")
     ap.add_argument("--seed", type=int, default=4096)
-    ap.add_argument("--groups", type=int, default=1, help="rollout groups stepped concurrently (own solver handle and stream "
+    ap.add_argument("--groups", type=int, default=3, help="rollout groups stepped concurrently (own solver handle and stream "
                     "each): the straggler tail of one group's solve overlaps the bulk of another's")
     args = ap.parse_args()
     from boundplanner_amd import scenes
