@@ -1,6 +1,6 @@
 """Diagnostic (not a test): per-instance differences HIP vs oracle."""
 import sys, os, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O
 from boundplanner_amd import scenes

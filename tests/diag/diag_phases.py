@@ -1,7 +1,7 @@
 """Diagnostic (not a test): build a -DBMPC_PROFILE library and print per-phase cycle shares."""
 import ctypes, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CS = os.path.join(ROOT, "boundplanner_amd", "csrc")
 out = os.path.join(ROOT, "gpurun_out", "libboundmpc_prof.so")

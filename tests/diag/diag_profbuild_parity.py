@@ -1,6 +1,6 @@
 """Diagnostic: does the -DBMPC_PROFILE build give the same answers as the product build?"""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from boundplanner_amd import solver, scenes
 N, B = 20, 256

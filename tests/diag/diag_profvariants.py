@@ -1,6 +1,6 @@
 """Diagnostic: which instrumentation point perturbs the results?"""
 import os, subprocess, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CS = os.path.join(ROOT, "boundplanner_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out")

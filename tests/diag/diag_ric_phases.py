@@ -2,7 +2,7 @@
 (BMPC_LIB must point at it)."""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from boundplanner_amd import solver, scenes
 N, B = 20, int(sys.argv[1]) if len(sys.argv) > 1 else 2048

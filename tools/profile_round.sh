@@ -9,6 +9,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   n=$(echo $set | cut -d" " -f1)
   timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d $O/pmc_$n -- python3 bench.py --steps 1 --warmup 0 --depth 1 --no-cpu-baseline > $O/pmc_$n.json 2> $O/pmc_$n.err || echo "pmc pass $n failed"
 done
-python3 tests/summarize_pmc.py $O/pmc_*/ --traffic-json $O/pmc_traffic.json > $O/pmc_summary.csv
+python3 tools/summarize_pmc.py $O/pmc_*/ --traffic-json $O/pmc_traffic.json > $O/pmc_summary.csv
 rm -rf $O/stats $O/pmc_*/
 cat $O/kernel_stats.csv | cut -d, -f1-5 | head -14; cat $O/pmc_summary.csv | head -80; cat $O/bench_default.json
