@@ -80,3 +80,75 @@ def test_replay_of_the_reference_trace(golden_dir):
             assert d < 1e-9, (k, f, d)
     assert g["switch"].sum() >= 1 and g["sector"][-1] == 1      # the trace exercises a switch + via-point adaptation
     print("max deviation from the reference trace:", {k: float(f"{v:.2e}") for k, v in worst.items()})
+
+
+def test_failure_path_matches_host_mirror():
+    """Solver failures (BoundMPC.py:619-645, Q12): the step falls back to the previous solution and shifts its outputs
+    by error_count columns; a failure before any accepted solution keeps the current one.  The device logic and the host
+    mirror (boundplanner_amd.bound_mpc / post, the restatement pinned by the golden trace on the success path) must
+    carry identical state through a scripted sequence of failures."""
+    from boundplanner_amd.batch_node import BatchMPCNode
+    from boundplanner_amd import scenes
+    from boundplanner_amd.params import normalize_set_size
+    N = 8
+    base = get_default_params()
+    params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+
+    class FakeBackend:           # kinematics from the oracle, solves from the oracle: checker-side stand-ins
+        def __init__(self):
+            self.N, self.n_w = N, 44 * N + 6
+            self.script = []
+
+        def fk(self, q, dq=None):
+            return O.fk_batch(q, dq)
+
+        def solve_batch(self, x0, lbx, ubx, p, want_g=False):
+            # both sides get the SAME solution (the NLP solve amplifies rounding-level argument differences in the
+            # weakly determined jerk block); the host's own arguments must equal the device logic's
+            args, r, fail = self.script.pop(0)
+            for mine, dev in zip((x0, lbx, ubx, p), args):
+                assert np.abs(mine[0] - dev).max() < 1e-9
+            r = {k: np.array(v, copy=True) for k, v in r.items()}
+            if fail:
+                r["status"][:] = 1
+                r["viol"][:] = 1.0
+            return r
+
+    be = FakeBackend()
+    rng = np.random.default_rng(5)
+    q_start, q_goal = scenes.sample_start_goal(rng, be.fk, 1)
+    fg = be.fk(q_goal)
+    host = BatchMPCNode(be, q_start, params)
+    lay = E.layout()
+    S = pack_state(lay, host.mpcs[0], host.q[0], host.dq[0], host.ddq[0], host.jerk[0], host.qf[0], host.v[0], host.p_lie[0])
+    prev = np.zeros(44 * N + 6)
+    a_ee, b_ee = scenes._box_set([-1.0, -1.0, 0.0], [1.0, 1.0, 1.2])
+    # failure on the very first solve (no previous solution), successes, two failures in a row, recovery
+    script = [True, False, False, True, True, False, False, True, False]
+    for k, fail in enumerate(script):
+        if k == 1:
+            sets = normalize_set_size([[a_ee, b_ee]], 15)
+            host.update_reference(0, [host.p_lie[0][:3].copy(), fg["ee_pos"][0].copy()],
+                                  [R.from_rotvec(host.p_lie[0][3:]).as_matrix(), fg["ee_rot"][0].copy()], [np.array([0.0, 0, 1])],
+                                  [np.array([0.0, 0, 1])], [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180], [sets[0][0]], [sets[0][1]])
+            keep = {f: state_view(lay, S)[f].copy() for f in ("slacks0", "error_count", "has_prev")}
+            S = pack_state(lay, host.mpcs[0], host.q[0], host.dq[0], host.ddq[0], host.jerk[0], host.qf[0], host.v[0], host.p_lie[0])
+            for f, val in keep.items():
+                state_view(lay, S)[f][:] = val
+        x0, lbx, ubx, p = E.prepare(N, S, prev)
+        r = O.solve_batch(N, x0[None], lbx[None], ubx[None], p[None])
+        st, viol = (1, 1.0) if fail else (int(r["status"][0]), float(r["viol"][0]))
+        E.finish(N, params.dt, S, r["x"][0], prev, st, viol)
+        be.script = [((x0, lbx, ubx, p), r, fail)]
+        host.step()
+        m, V = host.mpcs[0], state_view(lay, S)
+        assert int(V["error_count"][0]) == m.error_count, k
+        assert (V["has_prev"][0] != 0) == (m.prev_solution is not None), k
+        assert [int(s) for s in V["split"]] == list(m.split_idxs), k
+        for f, ref in (("q", host.q[0]), ("dq", host.dq[0]), ("ddq", host.ddq[0]), ("jerk", host.jerk[0]), ("qf", host.qf[0]),
+                       ("v", host.v[0]), ("p_lie", host.p_lie[0]), ("slacks0", m.slacks0), ("pr_ref", m.pr_ref), ("iw_ref", m.iw_ref),
+                       ("phi_current", m.phi_current), ("dphi_current", m.dphi_current)):
+            assert np.abs(V[f] - np.asarray(ref).reshape(-1)).max() < 1e-9, (k, f)
+        if m.prev_solution is not None:
+            assert np.abs(prev - m.prev_solution).max() < 1e-9, k
+    assert host.mpcs[0].error_count == 0 and max(script) is True

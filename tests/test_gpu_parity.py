@@ -52,7 +52,8 @@ def test_fk_matches_reference_tapes(backends, golden_dir):
 @pytest.mark.parametrize("N,seed,rnd,B", [(6, 6, True, 16), (10, 1024, False, 64), (20, 8192, True, 48),
                                           (15, 15, True, 24),      # the reference's default horizon (util_functions.py:49)
                                           (30, 4096, False, 24),   # configs[4]
-                                          (3, 3, True, 8)])        # shortest horizon the handle accepts
+                                          (3, 3, True, 8),         # shortest horizon the handle accepts
+                                          (10, 1024, False, 1024)])  # configs[1] at its full size
 def test_solve_matches_oracle(backends, N, seed, rnd, B):
     from boundplanner_amd import scenes
     be = backends(N)
