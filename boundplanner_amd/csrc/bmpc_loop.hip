@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <string>
+#include <vector>
 
 #include "../../include/boundmpc.h"
 
@@ -22,14 +23,25 @@ __global__ __launch_bounds__(256) void bmpc_loop_k_bounds(int R, int N, double* 
     loop_bound_const(N, (int)(e % n_w), lbx + e, ubx + e);
 }
 
+// closest pairs collision-point segment <-> obstacle: one thread per (rollout, collision point, obstacle)
+__global__ __launch_bounds__(64) void bmpc_loop_k_colpairs(int R, const RobotConst* rc, LoopScene sc, const double* S, double* colres) {
+    const int e = blockIdx.x * 64 + threadIdx.x, per = 6 * sc.n_obs;
+    if (e >= R * per) return;
+    const int r = e / per, rem = e - r * per, pt = rem / sc.n_obs, ob = rem - pt * sc.n_obs;
+    const double* s = S + (size_t)r * LS_SIZE;
+    if (s[LS_dead] != 0.0) return;
+    loop_collision_pair(rc, sc, s, pt, ob, colres + (size_t)e * LP_CRES);
+}
+
 __global__ __launch_bounds__(64) void bmpc_loop_k_prepare(int R, int N, const RobotConst* rc, double* S, const double* prev,
-                                                          double* p, double* lbx, double* ubx) {
+                                                          double* p, double* lbx, double* ubx, LoopScene sc, const double* colres) {
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= R) return;
     const size_t n_w = 44 * N + 6;
     double* s = S + (size_t)r * LS_SIZE;
     if (s[LS_dead] != 0.0) return;
-    loop_prepare(rc, N, s, prev + r * n_w, p + (size_t)r * NPAR, lbx + r * n_w, ubx + r * n_w);
+    loop_prepare(rc, N, s, prev + r * n_w, p + (size_t)r * NPAR, lbx + r * n_w, ubx + r * n_w, &sc,
+                 colres ? colres + (size_t)r * 6 * sc.n_obs * LP_CRES : nullptr);
 }
 
 __global__ __launch_bounds__(256) void bmpc_loop_k_x0(int R, int N, const double* S, const double* prev, double* x0) {
@@ -72,6 +84,10 @@ struct bmpc_loop {
     double *d_S = nullptr, *d_prev = nullptr, *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr,
            *d_x = nullptr, *d_f = nullptr, *d_viol = nullptr, *d_log = nullptr;
     int *d_iters = nullptr, *d_status = nullptr;
+    LoopScene sc{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // device pointers
+    double* d_scene = nullptr;     // A | b | AAt | V
+    int* d_scene_i = nullptr;      // nrows | nv
+    double* d_colres = nullptr;
     size_t log_cap = 0;
     hipStream_t st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -99,6 +115,9 @@ extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
     if (L->d_iters) (void)hipFree(L->d_iters);
     if (L->d_status) (void)hipFree(L->d_status);
     if (L->d_rc) (void)hipFree(L->d_rc);
+    if (L->d_scene) (void)hipFree(L->d_scene);
+    if (L->d_scene_i) (void)hipFree(L->d_scene_i);
+    if (L->d_colres) (void)hipFree(L->d_colres);
     if (L->e0) (void)hipEventDestroy(L->e0);
     if (L->e1) (void)hipEventDestroy(L->e1);
     delete L;
@@ -164,10 +183,54 @@ extern "C" int bmpc_loop_download(bmpc_loop* L, int first, int count, double* st
     return 0;
 }
 
+extern "C" int bmpc_loop_set_obstacles(bmpc_loop* L, int n_obs, const double* A, const double* b, const int* nrows, const double* V,
+                                       const int* nv) {
+    if (!L || n_obs < 0 || n_obs > LP_MAXOBS || (n_obs > 0 && (!A || !b || !nrows || !V || !nv))) { if (L) L->err = "bmpc_loop_set_obstacles: bad arguments"; return 1; }
+    LCHK(L, hipSetDevice(L->dev));
+    LCHK(L, hipStreamSynchronize(L->st));
+    if (L->d_scene) { (void)hipFree(L->d_scene); L->d_scene = nullptr; }
+    if (L->d_scene_i) { (void)hipFree(L->d_scene_i); L->d_scene_i = nullptr; }
+    if (L->d_colres) { (void)hipFree(L->d_colres); L->d_colres = nullptr; }
+    L->sc = LoopScene{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (n_obs == 0) return 0;
+    for (int i = 0; i < n_obs; i++)
+        if (nrows[i] < 1 || nrows[i] > LP_ROWS || nv[i] < 1 || nv[i] > LP_NV) { L->err = "obstacle with too many rows or vertices"; return 1; }
+    const size_t nA = (size_t)n_obs * 45, nb = (size_t)n_obs * LP_ROWS, nAAt = (size_t)n_obs * LP_ROWS * LP_ROWS, nV = (size_t)n_obs * LP_NV * 3;
+    std::vector<double> h(nA + nb + nAAt + nV, 0.0);
+    std::vector<int> hi(2 * (size_t)n_obs);
+    for (int o = 0; o < n_obs; o++) {
+        for (int r = 0; r < nrows[o]; r++) {
+            for (int c = 0; c < 3; c++) h[45 * o + 3 * r + c] = A[45 * o + 3 * r + c];
+            h[nA + LP_ROWS * o + r] = b[LP_ROWS * o + r];
+        }
+        for (int r = 0; r < nrows[o]; r++)
+            for (int q = 0; q < nrows[o]; q++) {
+                double sum = 0;
+                for (int c = 0; c < 3; c++) sum += A[45 * o + 3 * r + c] * A[45 * o + 3 * q + c];
+                h[nA + nb + (size_t)LP_ROWS * LP_ROWS * o + LP_ROWS * r + q] = sum;
+            }
+        for (int v = 0; v < nv[o]; v++)
+            for (int c = 0; c < 3; c++) h[nA + nb + nAAt + 3 * ((size_t)LP_NV * o + v) + c] = V[3 * (LP_NV * o + v) + c];
+        hi[o] = nrows[o]; hi[n_obs + o] = nv[o];
+    }
+    LCHK(L, hipMalloc((void**)&L->d_scene, h.size() * sizeof(double)));
+    LCHK(L, hipMemcpy(L->d_scene, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    LCHK(L, hipMalloc((void**)&L->d_scene_i, hi.size() * sizeof(int)));
+    LCHK(L, hipMemcpy(L->d_scene_i, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice));
+    LCHK(L, hipMalloc((void**)&L->d_colres, (size_t)L->R * 6 * n_obs * LP_CRES * sizeof(double)));
+    LCHK(L, hipMemset(L->d_colres, 0, (size_t)L->R * 6 * n_obs * LP_CRES * sizeof(double)));
+    L->sc = LoopScene{n_obs, L->d_scene, L->d_scene + nA, L->d_scene + nA + nb, L->d_scene_i, L->d_scene + nA + nb + nAAt, L->d_scene_i + n_obs};
+    return 0;
+}
+
 static int launch_prepare(bmpc_loop* L) {
     const size_t ne = (size_t)L->R * L->n_w;
+    if (L->sc.n_obs > 0) {
+        const int np = L->R * 6 * L->sc.n_obs;
+        hipLaunchKernelGGL(bmpc_loop_k_colpairs, dim3((np + 63) / 64), dim3(64), 0, L->st, L->R, L->d_rc, L->sc, L->d_S, L->d_colres);
+    }
     hipLaunchKernelGGL(bmpc_loop_k_prepare, dim3((L->R + 63) / 64), dim3(64), 0, L->st, L->R, L->N, L->d_rc, L->d_S, L->d_prev,
-                       L->d_p, L->d_lbx, L->d_ubx);
+                       L->d_p, L->d_lbx, L->d_ubx, L->sc, L->d_colres);
     hipLaunchKernelGGL(bmpc_loop_k_x0, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, L->R, L->N, L->d_S, L->d_prev, L->d_x0);
     LCHK(L, hipGetLastError());
     return 0;

@@ -233,10 +233,151 @@ BMPC_INL void lp_path_update(double* S, bool sw) {
     lp_set_point(S, LP_S - 1);
 }
 
+// ---- per-step collision sets with obstacles (ConvexSetFinder.find_set_collision_avoidance, ---------
+// ConvexSetFinder.py:309-375, with compute_set_projs_line :491-510): the scene's obstacle polytopes are shared
+// by all rollouts.  The closest pair between the segment [p(q0), p(qf)] of a collision point and a polytope is the
+// algorithm of the host restatement (boundplanner_amd/collision_sets.py: golden section over the segment
+// parameter, each distance an exact projection by Hildreth's dual coordinate ascent), so that both sides agree
+// to rounding; one thread per (rollout, collision point, obstacle), then the greedy nearest-first selection of
+// separating halfspaces per (rollout, collision point) inside loop_prepare.
+constexpr int LP_MAXOBS = 16;    // obstacle polytopes per scene
+constexpr int LP_NV = 32;        // vertices per obstacle
+constexpr int LP_CRES = 8;       // doubles per closest-pair result: x(3), y(3), distance, pad
+
+struct LoopScene {
+    int n_obs;
+    const double* A;      // [n_obs][15][3], rows beyond nrows are zero
+    const double* b;      // [n_obs][15]
+    const double* AAt;    // [n_obs][15][15]
+    const int* nrows;     // [n_obs]
+    const double* V;      // [n_obs][LP_NV][3]
+    const int* nv;        // [n_obs]
+};
+
+// Euclidean projection of y onto {x: A x <= b - 0.001} (collision_sets._project_polytope)
+BMPC_INL void lp_project_polytope(const double* A, const double* b, const double* AAt, int nr, const double* y, double* x) {
+    double Ay[LP_ROWS], lam[LP_ROWS];
+    bool inside = true;
+    for (int i = 0; i < nr; i++) {
+        Ay[i] = A[3 * i] * y[0] + A[3 * i + 1] * y[1] + A[3 * i + 2] * y[2];
+        if (Ay[i] - (b[i] - 0.001) > 1e-12) inside = false;
+        lam[i] = 0.0;
+    }
+    x[0] = y[0]; x[1] = y[1]; x[2] = y[2];
+    if (inside) return;
+    for (int sweep = 0; sweep < 1200; sweep++) {
+        double max_change = 0.0;
+        for (int i = 0; i < nr; i++) {
+            double r = Ay[i];
+            for (int j = 0; j < nr; j++) r -= AAt[LP_ROWS * i + j] * lam[j];
+            r -= (b[i] - 0.001);
+            const double dg = fmax(AAt[LP_ROWS * i + i], 1e-16);
+            const double nw = fmax(0.0, lam[i] + r / dg);
+            max_change = fmax(max_change, fabs(nw - lam[i]));
+            lam[i] = nw;
+        }
+        if (max_change < 1e-13) break;
+    }
+    for (int i = 0; i < nr; i++)
+        for (int c = 0; c < 3; c++) x[c] -= A[3 * i + c] * lam[i];
+}
+
+BMPC_INL double lp_seg_dist(const double* A, const double* b, const double* AAt, int nr, const double* p0, const double* d,
+                            double phi, double* x) {
+    const double y[3] = {p0[0] + phi * d[0], p0[1] + phi * d[1], p0[2] + phi * d[2]};
+    lp_project_polytope(A, b, AAt, nr, y, x);
+    return sqrt((y[0] - x[0]) * (y[0] - x[0]) + (y[1] - x[1]) * (y[1] - x[1]) + (y[2] - x[2]) * (y[2] - x[2]));
+}
+
+// closest pair segment <-> polytope (collision_sets.closest_pair_segment_polytope); out: x, y = p0 + phi d, distance
+BMPC_DEV void loop_closest_pair(const double* A, const double* b, const double* AAt, int nr, const double* p0, const double* p1,
+                                double* out) {
+    const double d[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    double x[3], phi = 0.0;
+    if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) >= 1e-12) {
+        double lo = 0.0, hi = 1.0;
+        const double gr = (sqrt(5.0) - 1.0) / 2.0;
+        double c = hi - gr * (hi - lo), e = lo + gr * (hi - lo);
+        double fc = lp_seg_dist(A, b, AAt, nr, p0, d, c, x), fe = lp_seg_dist(A, b, AAt, nr, p0, d, e, x);
+        for (int it = 0; it < 80; it++) {
+            if (fc < fe) {
+                hi = e; e = c; fe = fc;
+                c = hi - gr * (hi - lo);
+                fc = lp_seg_dist(A, b, AAt, nr, p0, d, c, x);
+            } else {
+                lo = c; c = e; fc = fe;
+                e = lo + gr * (hi - lo);
+                fe = lp_seg_dist(A, b, AAt, nr, p0, d, e, x);
+            }
+        }
+        const double pm = 0.5 * (lo + hi);
+        const double f0 = lp_seg_dist(A, b, AAt, nr, p0, d, 0.0, x), f1 = lp_seg_dist(A, b, AAt, nr, p0, d, 1.0, x),
+                     fm = lp_seg_dist(A, b, AAt, nr, p0, d, pm, x);
+        // min over (distance, phi) pairs in the order (0, 1, pm): ties go to the smaller phi
+        double best = f0; phi = 0.0;
+        if (f1 < best) { best = f1; phi = 1.0; }
+        if (fm < best || (fm == best && pm < phi)) { best = fm; phi = pm; }
+    }
+    const double dist = lp_seg_dist(A, b, AAt, nr, p0, d, phi, x);
+    for (int c = 0; c < 3; c++) { out[c] = x[c]; out[3 + c] = p0[c] + phi * d[c]; }
+    out[6] = dist; out[7] = phi;
+}
+
+// one (rollout, collision point, obstacle) of the closest-pair pass
+BMPC_DEV void loop_collision_pair(const RobotConst* rc, const LoopScene& sc, const double* S, int pt, int ob, double* out) {
+    Kin k0, kf;
+    kin_eval(rc, S + LS_q, k0);
+    kin_eval(rc, S + LS_qf, kf);
+    loop_closest_pair(sc.A + 45 * ob, sc.b + LP_ROWS * ob, sc.AAt + LP_ROWS * LP_ROWS * ob, sc.nrows[ob], k0.pc[pt], kf.pc[pt], out);
+}
+
+// greedy nearest-first separating halfspaces of one collision point (ConvexSetFinder.py:330-375); res: the
+// closest-pair results of this (rollout, point) for all obstacles; rows 6.. of a[15][3], b[15] are appended.
+// Returns the number of rows, or -1 when they do not fit max_set_size (the host raises there).
+BMPC_INL int lp_collision_rows(const LoopScene& sc, const double* res, const double* p0, const double* p1, double a[][3], double* b) {
+    int n = 6;
+    bool remain[LP_MAXOBS];
+    for (int i = 0; i < sc.n_obs; i++) remain[i] = true;
+    for (;;) {
+        int idx = -1;
+        for (int i = 0; i < sc.n_obs; i++)
+            if (remain[i] && (idx < 0 || res[LP_CRES * i + 6] < res[LP_CRES * idx + 6])) idx = i;
+        if (idx < 0) break;
+        const double* cp = res + LP_CRES * idx;
+        double av[3] = {cp[0] - cp[3], cp[1] - cp[4], cp[2] - cp[5]};
+        double na = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+        if (na < 1e-6) {          // the segment touches the obstacle
+            for (int c = 0; c < 3; c++) av[c] = cp[c] - p0[c];
+            na = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+            if (na < 1e-6) {
+                for (int c = 0; c < 3; c++) av[c] = p1[c] - p0[c];
+                na = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+            }
+        }
+        for (int c = 0; c < 3; c++) av[c] /= na;
+        const double bh = av[0] * cp[0] + av[1] * cp[1] + av[2] * cp[2] - 0.001;
+        remain[idx] = false;
+        for (int i = 0; i < sc.n_obs; i++) {
+            if (!remain[i]) continue;
+            double mn = 1e300;
+            for (int v = 0; v < sc.nv[i]; v++) {
+                const double* vv = sc.V + 3 * (LP_NV * i + v);
+                mn = fmin(mn, vv[0] * av[0] + vv[1] * av[1] + vv[2] * av[2] - bh);
+            }
+            if (mn >= -1e-4) remain[i] = false;     // entirely behind the new halfspace
+        }
+        if (n >= LP_ROWS) return -1;
+        a[n][0] = av[0]; a[n][1] = av[1]; a[n][2] = av[2]; b[n] = bh;
+        n++;
+    }
+    return n;
+}
+
 // ---- before the solve: BoundMPC.step up to the solver call ---------------------------------------
 // S: state; prev: previous solution row (read when has_prev); p/lbx/ubx: rows of the solver arguments
 // (lbx/ubx hold the constant limits already, only the stage-0 pins are written here).
-BMPC_DEV void loop_prepare(const RobotConst* rc, int N, double* S, const double* prev, double* p, double* lbx, double* ubx) {
+BMPC_DEV void loop_prepare(const RobotConst* rc, int N, double* S, const double* prev, double* p, double* lbx, double* ubx,
+                           const LoopScene* sc = nullptr, const double* colres = nullptr) {
     // MPCNode.step: p_lie = fk(q) (MPCNode.py:118)
     Kin k;
     kin_eval(rc, S + LS_q, k);
@@ -338,20 +479,26 @@ BMPC_DEV void loop_prepare(const RobotConst* rc, int N, double* S, const double*
             for (int r = 0; r < LP_ROWS; r++) p[P_ASET + 45 * i + LP_ROWS * c + r] = S[LS_rp_a + 45 * (sec + i) + 3 * r + c];
     for (int r = 0; r < LP_ROWS; r++)
         for (int i = 0; i < LP_S; i++) p[P_BSET + LP_S * r + i] = S[LS_rp_b + LP_ROWS * (sec + i) + r];
-    // collision sets without obstacles: 0.7 m box around each collision point at q0, shrunk by the
-    // joint size, padded with (A = 0, b = 10) (ConvexSetFinder.py:400-421, BoundMPC.py:480-497)
+    // collision sets: 0.7 m box around each collision point at q0 (ConvexSetFinder.py:400-421), separating halfspaces
+    // of the scene's obstacles along the segment to the point's position at qf, everything shrunk by the joint size,
+    // padded with (A = 0, b = 10) (BoundMPC.py:480-497, util_functions.py:121-135)
+    const bool obst = sc && sc->n_obs > 0;
+    Kin kf;
+    if (obst) kin_eval(rc, S + LS_qf, kf);
     for (int j = 0; j < 6; j++) {
-        for (int c = 0; c < 3; c++)
-            for (int r = 0; r < LP_ROWS; r++) {
-                double a = 0.0;
-                if (r < 6 && (r >> 1) == c) a = (r & 1) ? -1.0 : 1.0;
-                p[P_ASETJ + 45 * j + LP_ROWS * c + r] = a;
-            }
-        for (int r = 0; r < LP_ROWS; r++) {
-            double b = 10.0;
-            if (r < 6) b = ((r & 1) ? -k.pc[j][r >> 1] : k.pc[j][r >> 1]) + 0.7 - LP_COLSIZE[j];
-            p[P_BSETJ + 6 * r + j] = b;
+        double a[LP_ROWS][3], b[LP_ROWS];
+        for (int r = 0; r < 6; r++) {
+            for (int c = 0; c < 3; c++) a[r][c] = ((r >> 1) == c) ? ((r & 1) ? -1.0 : 1.0) : 0.0;
+            b[r] = ((r & 1) ? -k.pc[j][r >> 1] : k.pc[j][r >> 1]) + 0.7;
         }
+        int n = 6;
+        if (obst) {
+            n = lp_collision_rows(*sc, colres + LP_CRES * sc->n_obs * j, k.pc[j], kf.pc[j], a, b);
+            if (n < 0) { S[LS_dead] = 2.0; n = LP_ROWS; }       // more rows than max_set_size: the host raises
+        }
+        for (int c = 0; c < 3; c++)
+            for (int r = 0; r < LP_ROWS; r++) p[P_ASETJ + 45 * j + LP_ROWS * c + r] = (r < n) ? a[r][c] : 0.0;
+        for (int r = 0; r < LP_ROWS; r++) p[P_BSETJ + 6 * r + j] = (r < n) ? b[r] - LP_COLSIZE[j] : 10.0;
     }
 
     // stage-0 pins (BoundMPC.py:544-580, Q7): x[0:-1:N] = value on the joint-major arrays

@@ -7,8 +7,9 @@ the Python objects, `pack_state` serialises them into the state vector of
 boundplanner_amd/csrc/bmpc_loop.hpp, and the HIP kernels carry on from there
 (BoundMPC.step / compute_return_data / MPCNode.step, BoundMPC.py:388-1040, MPCNode.py:106-160).
 
-No CPU fallback: `DeviceLoop` needs libboundmpc_hip.so and a GPU.  Scenes with obstacles (per-step
-collision sets from the host finder, collision_sets.py) are refused.
+No CPU fallback: `DeviceLoop` needs libboundmpc_hip.so and a GPU.  Scene obstacles (polytopes with their vertices, the
+inputs of ConvexSetFinder.find_set_collision_avoidance, ConvexSetFinder.py:309-375) are shared by all rollouts of a loop:
+`set_obstacles`; the per-step collision sets are then computed on the device as well.
 """
 import ctypes
 
@@ -50,8 +51,6 @@ def _rows(lst, width, n=NL):
 
 def pack_state(lay, mpc, q, dq, ddq, jerk, qf, v, p_lie):
     """Serialise one rollout: a host BoundMPC object (after __init__ / update) + the node state."""
-    if getattr(mpc, "obs_sets", None):
-        raise ValueError("the device loop handles obstacle-free scenes only (per-step collision sets are host code)")
     S = np.zeros(lay["_size"])
 
     def put(name, val):
@@ -80,6 +79,22 @@ def pack_state(lay, mpc, q, dq, ddq, jerk, qf, v, p_lie):
     put("rp_pd", rp.pd); put("rp_r_taud", rp.r_taud); put("rp_dpd", rp.dpd); put("rp_dpdn", rp.dpd_normed)
     put("rp_phi_switch", rp.phi_switch)
     return S
+
+
+def pack_obstacles(obs_sets, obs_points_sets):
+    """[A, b] polytopes + vertex arrays -> the flat arrays of bmpc_loop_set_obstacles (15 rows / 32 vertices each)."""
+    n = len(obs_sets)
+    if n > 16:
+        raise ValueError("at most 16 scene obstacles")
+    A = np.zeros((n, 15, 3)); b = np.zeros((n, 15)); V = np.zeros((n, 32, 3))
+    nrows = np.zeros(n, np.int32); nv = np.zeros(n, np.int32)
+    for i, ((a_i, b_i), v_i) in enumerate(zip(obs_sets, obs_points_sets)):
+        a_i, b_i, v_i = np.asarray(a_i, float), np.asarray(b_i, float), np.asarray(v_i, float)
+        if a_i.shape[0] > 15 or v_i.shape[0] > 32:
+            raise ValueError("obstacle with more than 15 faces or 32 vertices")
+        A[i, :a_i.shape[0]] = a_i; b[i, :a_i.shape[0]] = b_i; V[i, :v_i.shape[0]] = v_i
+        nrows[i], nv[i] = a_i.shape[0], v_i.shape[0]
+    return A, b, nrows, V, nv
 
 
 def state_view(lay, S):
@@ -139,6 +154,12 @@ class DeviceLoop:
         self.state[r] = pack_state(self.lay, mpc, q, dq, ddq, jerk, qf, v, p_lie)
         if mpc.prev_solution is not None:
             self.prev[r] = mpc.prev_solution
+
+    def set_obstacles(self, obs_sets, obs_points_sets):
+        """Scene obstacles of ALL rollouts (what BoundMPC.set_obstacle_sets takes per instance on the host)."""
+        A, b, nrows, V, nv = pack_obstacles(obs_sets, obs_points_sets)
+        self._chk(self.lib.bmpc_loop_set_obstacles(self._l, len(obs_sets), self._P(A), self._P(b), nrows.ctypes.data_as(_ip),
+                                                   self._P(V), nv.ctypes.data_as(_ip)), "bmpc_loop_set_obstacles")
 
     def upload(self, first=0, count=None):
         count = self.R - first if count is None else count

@@ -114,7 +114,9 @@ int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16);
  * Plan-time construction (ReferencePath.__init__, BoundMPC.update) stays with the caller, who
  * serialises it into the state vector: bmpc_loop_state_doubles() doubles per rollout, fields located by
  * name with bmpc_loop_field() (names = LP_FIELDS of boundplanner_amd/csrc/bmpc_loop.hpp).
- * Obstacle-free scenes only (collision sets = boxes around the collision points).
+ * Per-step collision sets (ConvexSetFinder.find_set_collision_avoidance, ConvexSetFinder.py:309-375) are computed on the
+ * device too: boxes around the collision points, plus separating halfspaces of the scene obstacles set with
+ * bmpc_loop_set_obstacles (shared by all rollouts of the loop).
  * All pointers below are HOST pointers.  The loop borrows the handle's solver: do not use the handle
  * for other solves while a loop call is running. */
 typedef struct bmpc_loop bmpc_loop;
@@ -124,6 +126,11 @@ int bmpc_loop_field(const char* name, int* offset, int* count);
 int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out);
 void bmpc_loop_destroy(bmpc_loop* l);
 const char* bmpc_loop_last_error(const bmpc_loop* l);
+/* scene obstacles (BoundMPC.obstacles as polytopes A x <= b with their vertices; ConvexSetFinder.py:309-375):
+ * A [n_obs][15][3] and b [n_obs][15] (first nrows[o] rows used), V [n_obs][32][3] (first nv[o] vertices used);
+ * n_obs <= 16; n_obs = 0 clears the scene */
+int bmpc_loop_set_obstacles(bmpc_loop* l, int n_obs, const double* A, const double* b, const int* nrows, const double* V,
+                            const int* nv);
 /* state: [count][state_doubles]; prev: [count][n_w] previous solutions (warm start) or NULL */
 int bmpc_loop_upload(bmpc_loop* l, int first, int count, const double* state, const double* prev);
 int bmpc_loop_download(bmpc_loop* l, int first, int count, double* state, double* prev);

@@ -4,6 +4,7 @@
 // the product path.
 #include <cmath>
 #include <cstring>
+#include <vector>
 #define BMPC_DEV inline
 #define BMPC_INL inline
 #define BMPC_HD inline
@@ -33,6 +34,28 @@ extern "C" void emu_loop_prepare(int N, double* S, const double* prev, double* x
     const int n_w = 44 * N + 6;
     for (int i = 0; i < n_w; i++) loop_bound_const(N, i, lbx + i, ubx + i);
     loop_prepare(&rc, N, S, prev, p, lbx, ubx);
+    for (int i = 0; i < n_w; i++) x0[i] = loop_x0_elem(N, S, prev, i);
+}
+
+// the same with scene obstacles: A [n_obs][15][3], b [n_obs][15], nrows, V [n_obs][32][3], nv (layout of bmpc_loop_set_obstacles)
+extern "C" void emu_loop_prepare_obs(int N, double* S, const double* prev, double* x0, double* lbx, double* ubx, double* p, int n_obs,
+                                     const double* A, const double* b, const int* nrows, const double* V, const int* nv) {
+    RobotConst rc;
+    fill_robot_const(rc);
+    const int n_w = 44 * N + 6;
+    std::vector<double> AAt((size_t)n_obs * LP_ROWS * LP_ROWS, 0.0), colres((size_t)6 * n_obs * LP_CRES, 0.0);
+    for (int o = 0; o < n_obs; o++)
+        for (int r = 0; r < nrows[o]; r++)
+            for (int q = 0; q < nrows[o]; q++) {
+                double s = 0;
+                for (int c = 0; c < 3; c++) s += A[45 * o + 3 * r + c] * A[45 * o + 3 * q + c];
+                AAt[(size_t)LP_ROWS * LP_ROWS * o + LP_ROWS * r + q] = s;
+            }
+    LoopScene sc{n_obs, A, b, AAt.data(), nrows, V, nv};
+    for (int pt = 0; pt < 6; pt++)
+        for (int ob = 0; ob < n_obs; ob++) loop_collision_pair(&rc, sc, S, pt, ob, colres.data() + (size_t)(pt * n_obs + ob) * LP_CRES);
+    for (int i = 0; i < n_w; i++) loop_bound_const(N, i, lbx + i, ubx + i);
+    loop_prepare(&rc, N, S, prev, p, lbx, ubx, &sc, colres.data());
     for (int i = 0; i < n_w; i++) x0[i] = loop_x0_elem(N, S, prev, i);
 }
 

@@ -37,6 +37,17 @@ def prepare(N, S, prev):
     return x0, lbx, ubx, p
 
 
+def prepare_obs(N, S, prev, obs_sets, obs_points_sets):
+    from boundplanner_amd.device_loop import pack_obstacles
+    A, b, nrows, V, nv = pack_obstacles(obs_sets, obs_points_sets)
+    ip = ctypes.POINTER(ctypes.c_int)
+    n_w = 44 * N + 6
+    x0, lbx, ubx, p = np.zeros(n_w), np.zeros(n_w), np.zeros(n_w), np.zeros(875)
+    lib().emu_loop_prepare_obs(N, P(S), P(prev), P(x0), P(lbx), P(ubx), P(p), len(obs_sets), P(A), P(b), nrows.ctypes.data_as(ip),
+                               P(V), nv.ctypes.data_as(ip))
+    return x0, lbx, ubx, p
+
+
 def finish(N, dt, S, x, prev, status, viol, iters=0):
     log = np.zeros(lib().emu_loop_logw())
     lib().emu_loop_finish(N, ctypes.c_double(dt), P(S), P(np.ascontiguousarray(x, float)), P(prev), int(status),

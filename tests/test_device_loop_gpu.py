@@ -135,3 +135,45 @@ def test_device_loop_tracks_host_loop():
     # same solver, same arguments to rounding: the loops stay together far below the solver tolerance
     assert dmax < 1e-6, dmax
     assert (phi_host > 0.05).all()                       # the rollouts actually move along their paths
+
+
+def test_device_loop_with_obstacles_tracks_host_loop():
+    """Scene obstacles: the per-step collision sets come from the colpairs kernel + the greedy selection in the prepare
+    kernel on the device, from collision_sets.find_set_collision_avoidance on the host."""
+    from boundplanner_amd.batch_node import BatchMPCNode
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.solver import HipBoundMPC
+    from test_device_loop import _box_scene
+    N, R, steps = 10, 4, 8
+    params = _params(N)
+    be = HipBoundMPC(N, max_batch=R)
+    q_start, plans = _scenario(be, R, N, 77)
+    sets, pts = _box_scene(np.random.default_rng(3), 6)
+    cp = lambda P: dict(goal=P["goal"].copy(), r_via=[m.copy() for m in P["r_via"]], bp1=[b.copy() for b in P["bp1"]],
+                        br1=[b.copy() for b in P["br1"]], erb=[e.copy() for e in P["erb"]], a=[a.copy() for a in P["a"]],
+                        b=[b.copy() for b in P["b"]])
+    host = BatchMPCNode(be, q_start, params)
+    ref = BatchMPCNode(be, q_start, params)
+    for m in host.mpcs + ref.mpcs:
+        m.set_obstacle_sets(sets, pts)
+    loop = DeviceLoop(be, R)
+    loop.set_obstacles(sets, pts)
+    for r in range(R):
+        P = cp(plans[r])
+        host.update_reference(r, [host.p_lie[r][:3].copy(), P["goal"]], P["r_via"], P["bp1"], P["br1"], P["erb"], P["a"], P["b"])
+        P = cp(plans[r])
+        ref.update_reference(r, [ref.p_lie[r][:3].copy(), P["goal"]], P["r_via"], P["bp1"], P["br1"], P["erb"], P["a"], P["b"])
+        loop.set_rollout(r, ref.mpcs[r], ref.q[r], ref.dq[r], ref.ddq[r], ref.jerk[r], ref.qf[r], ref.v[r], ref.p_lie[r])
+    loop.upload()
+    dmax, rows = 0.0, 0
+    for k in range(steps):
+        loop.prepare()
+        p_dev = loop.problem()[3]
+        host.step()
+        loop.solve()
+        log = loop.finish()
+        rows = max(rows, int((np.abs(p_dev[:, 515:785].reshape(R, 6, 3, 15)).sum(axis=2) > 0).sum(axis=2).max()))
+        dmax = max(dmax, np.abs(log[:, loop.LOG["q"]] - host.q).max(), np.abs(log[:, loop.LOG["p_lie"]] - host.p_lie).max())
+    assert rows > 6                    # obstacle halfspaces were active in the collision sets
+    assert dmax < 1e-5, dmax           # the halfspaces agree to ~1e-7 (golden section), the closed loops stay together
+    assert (log[:, loop.LOG["dead"]] == 0).all()
