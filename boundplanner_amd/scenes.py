@@ -103,3 +103,40 @@ def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1):
         out["x0"][b], out["lbx"][b], out["ubx"][b], out["p"][b] = w0, lbx, ubx, p
         out["mpcs"].append(mpc)
     return out
+
+
+def example_scene():
+    """The 12 box obstacles of the reference's example scene as [xmin, ymin, zmin, xmax, ymax, zmax]
+    (boundplanner_with_mpc_example.py:38-98: an open box of four 2 cm walls around (0.45, -0.48), the table, a shelf, two
+    walls, two blocks and two 8 cm cubes), its start configuration (:19-25) and goal pose (:33-34)."""
+    size, s_box, w, pb, h_box = 0.04, 0.12, 0.02, (0.45, -0.48, 0.05), 0.18
+    top = pb[2] + h_box
+    boxes = [
+        [pb[0] + s_box - w, pb[1] - s_box, 0.0, pb[0] + s_box, pb[1] + s_box, top],
+        [pb[0] - s_box, pb[1] - s_box, 0.0, pb[0] - s_box + w, pb[1] + s_box, top],
+        [pb[0] - s_box, pb[1] - s_box - w, 0.0, pb[0] + s_box, pb[1] - s_box, top],
+        [pb[0] - s_box, pb[1] + s_box, 0.0, pb[0] + s_box, pb[1] + s_box + w, top],
+        [0.2, -1.0, -0.1, 1.0, 1.0, 0.0],
+        [-0.3, -1.0, 0.53, 0.2, -0.35, 1.0],
+        [-0.2, -1.0, 0.0, -0.14, 1.0, 1.0],
+        [-1.0, 0.38, 0.0, 1.0, 0.5, 1.0],
+        [0.4, -0.05, 0.0, 0.5, 0.05, 0.15],
+        [0.1, -0.55, 0.0, 0.3, -0.35, 0.07],
+        [0.5 - size, -0.2 - size, 0.03 - size, 0.5 + size, -0.2 + size, 0.03 + size],
+        [0.4 - size, 0.3 - size, 0.03 - size, 0.4 + size, 0.3 + size, 0.03 + size],
+    ]
+    q0 = np.array([0.0, 0.0, 0.0, -np.pi / 2, 0.0, np.pi / 2, 0.0])
+    goal_p = np.array([0.45, -0.5, 0.2])
+    goal_r = R.from_euler("XYZ", [0, 90, 0], degrees=True).as_matrix()
+    return np.array(boxes), q0, goal_p, goal_r
+
+
+def boxes_to_sets(boxes):
+    """Axis-aligned boxes -> ([A, b] polytopes, vertex arrays): the obstacle form the per-step collision-set finder
+    takes (ConvexSetFinder.py:309-375; the reference builds the same from its box list with cdd)."""
+    sets, pts = [], []
+    for bx in np.asarray(boxes, float):
+        lo, hi = bx[:3], bx[3:]
+        sets.append([np.vstack((np.eye(3), -np.eye(3))), np.concatenate((hi, -lo))])
+        pts.append(np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]))
+    return sets, pts

@@ -148,7 +148,16 @@ def test_device_loop_with_obstacles_tracks_host_loop():
     params = _params(N)
     be = HipBoundMPC(N, max_batch=R)
     q_start, plans = _scenario(be, R, N, 77)
-    sets, pts = _box_scene(np.random.default_rng(3), 6)
+    # boxes near, but not touching, the arms: a collision point inside an obstacle has no separating halfspace (0/0 in
+    # the reference's finder as well)
+    col0 = be.fk(q_start)["col_pts"].reshape(-1, 3)
+    rng, sets, pts = np.random.default_rng(3), [], []
+    while len(sets) < 6:
+        s1, p1 = _box_scene(rng, 1)
+        lo, hi = p1[0].min(axis=0), p1[0].max(axis=0)
+        gap = np.linalg.norm(np.maximum(np.maximum(lo - col0, col0 - hi), 0.0), axis=1).min()
+        if 0.15 < gap < 0.45:
+            sets += s1; pts += p1
     cp = lambda P: dict(goal=P["goal"].copy(), r_via=[m.copy() for m in P["r_via"]], bp1=[b.copy() for b in P["bp1"]],
                         br1=[b.copy() for b in P["br1"]], erb=[e.copy() for e in P["erb"]], a=[a.copy() for a in P["a"]],
                         b=[b.copy() for b in P["b"]])
@@ -169,11 +178,13 @@ def test_device_loop_with_obstacles_tracks_host_loop():
     for k in range(steps):
         loop.prepare()
         p_dev = loop.problem()[3]
+        assert np.isfinite(p_dev).all(), k
         host.step()
         loop.solve()
         log = loop.finish()
         rows = max(rows, int((np.abs(p_dev[:, 515:785].reshape(R, 6, 3, 15)).sum(axis=2) > 0).sum(axis=2).max()))
+        assert np.isfinite(log).all() and np.isfinite(host.q).all(), k
         dmax = max(dmax, np.abs(log[:, loop.LOG["q"]] - host.q).max(), np.abs(log[:, loop.LOG["p_lie"]] - host.p_lie).max())
     assert rows > 6                    # obstacle halfspaces were active in the collision sets
-    assert dmax < 1e-5, dmax           # the halfspaces agree to ~1e-7 (golden section), the closed loops stay together
+    assert np.isfinite(dmax) and dmax < 1e-5, dmax           # the halfspaces agree to ~1e-7 (golden section), the closed loops stay together
     assert (log[:, loop.LOG["dead"]] == 0).all()

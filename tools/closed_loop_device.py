@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--chunk", type=int, default=25, help="MPC steps per bmpc_loop_run call (progress lines)")
     ap.add_argument("--seed", type=int, default=4096)
+    ap.add_argument("--scene", choices=["free", "example"], default="free", help="free: configs[4] (no obstacles); example: the 12 "
+                    "boxes of the reference's example scene, starts scattered around its start configuration, its goal pose")
     ap.add_argument("--groups", type=int, default=3, help="rollout groups stepped concurrently (own solver handle and stream "
                     "each): the straggler tail of one group's solve overlaps the bulk of another's")
     args = ap.parse_args()
@@ -43,12 +45,22 @@ def main():
     be = bes[0]
     rng = np.random.default_rng(args.seed)
     t0 = time.perf_counter()
-    q_start, q_goal = scenes.sample_start_goal(rng, be.fk, R)
-    fs, fg = be.fk(q_start), be.fk(q_goal)
+    obs = None
+    if args.scene == "example":
+        boxes, q0, goal_p, goal_r = scenes.example_scene()
+        obs = scenes.boxes_to_sets(boxes)
+        q_start = q0 + rng.uniform(-0.15, 0.15, size=(R, 7))
+        fs = be.fk(q_start)
+        fg = {"ee_pos": np.tile(goal_p, (R, 1)), "ee_rot": np.tile(goal_r, (R, 1, 1))}
+    else:
+        q_start, q_goal = scenes.sample_start_goal(rng, be.fk, R)
+        fs, fg = be.fk(q_start), be.fk(q_goal)
     seed_objs = BatchMPCNode(be, q_start, params)          # host construction of the R BoundMPC objects (trivial start-up path)
     loops = [DeviceLoop(bes[g], bounds[g + 1] - bounds[g]) for g in range(G)]
     a_ee, b_ee = scenes._box_set([-1.0, -1.0, 0.0], [1.0, 1.0, 1.2])
     for g, loop in enumerate(loops):
+        if obs is not None:
+            loop.set_obstacles(*obs)
         for i, r in enumerate(range(bounds[g], bounds[g + 1])):
             loop.set_rollout(i, seed_objs.mpcs[r], seed_objs.q[r], seed_objs.dq[r], seed_objs.ddq[r], seed_objs.jerk[r],
                              seed_objs.qf[r], seed_objs.v[r], seed_objs.p_lie[r])
@@ -95,6 +107,7 @@ def main():
     it = np.concatenate(iters)
     dead = float(log[-1, :, L["dead"]].mean())
     out = {
+        "scene": args.scene,
         "config": f"BASELINE configs[4]: closed loop, {R} rollouts x {args.steps} steps, N={N}, fixed sets, warm start (reference Q11), "
                   "device-resident loop (prepare kernel -> batched solve -> finish kernel)" + (f", {G} rollout groups in flight" if G > 1 else ""),
         "groups": G,
