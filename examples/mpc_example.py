@@ -8,6 +8,8 @@ the via path below is hand-authored inside two large box sets, like the golden c
 BASELINE.json configs[0] ("single instance plumbing"): one instance, N = 15 (the reference default).
 
     python examples/mpc_example.py            # needs an MI355X (no CPU fallback)
+    python examples/mpc_example.py --device   # the same on the device-resident loop, with the example's 12 box
+                                              # obstacles and per-step collision sets computed on the GPU
 """
 import os
 import sys
@@ -28,7 +30,51 @@ def box_set(lo, hi):
     return a, np.concatenate((np.asarray(hi, float), -np.asarray(lo, float), 10.0 * np.ones(9)))
 
 
+def main_device():
+    """One rollout on the device-resident loop (boundplanner_amd.device_loop), example scene obstacles included."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.batch_node import BatchMPCNode
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.params import Params, get_default_params
+    boxes, q0, goal_p, _ = scenes.example_scene()
+    base = get_default_params()
+    params = Params(n=15, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    be = HipBoundMPC(15)
+    seed = BatchMPCNode(be, q0[None], params)                  # host construction of the start-up BoundMPC object
+    loop = DeviceLoop(be, 1)
+    loop.set_obstacles(*scenes.boxes_to_sets(boxes))
+    loop.set_rollout(0, seed.mpcs[0], seed.q[0], seed.dq[0], seed.ddq[0], seed.jerk[0], seed.qf[0], seed.v[0], seed.p_lie[0])
+    loop.upload()
+    loop.run(1, log=False)                                     # warm-up solve, example :29
+    V = loop.download()
+    p0 = V["p_lie"][0].copy()
+    R0 = R.from_rotvec(p0[3:]).as_matrix()
+    p_via = [p0[:3].copy(), p0[:3] + np.array([0.05, -0.25, 0.10]), goal_p.copy()]
+    r_via = [R0, R0 @ R.from_euler("xyz", [20, 0, 10], degrees=True).as_matrix(),
+             R0 @ R.from_euler("xyz", [20, 25, 10], degrees=True).as_matrix()]
+    sets = [box_set([-0.14, -1.0, 0.0], [1.0, 0.38, 1.0])] * 2
+    loop.replan(0, seed.mpcs[0], p_via, r_via, [np.array([0.0, 0, 1])] * 2, [np.array([0.0, 0, 1])] * 2,
+                [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(2)], [s[0] for s in sets], [s[1] for s in sets])
+    loop.upload()
+    L, t0, steps, iters = loop.LOG, time.perf_counter(), 0, []
+    while steps < 300:
+        log = loop.run(10)
+        for row in log[:, 0]:
+            steps += 1
+            iters.append(row[L["iters"]])
+            if row[L["phi"]] >= row[L["phi_max"]] - 0.001:
+                break
+        print(f"step {steps:3d}  phi {row[L['phi']]:.3f}/{row[L['phi_max']]:.3f}  sector {int(row[L['sector']])}  iters {int(row[L['iters']])}")
+        if row[L["phi"]] >= row[L["phi_max"]] - 0.001:
+            break
+    print(f"reached phi_max in {steps} steps, {np.mean(iters):.1f} iterations/step, "
+          f"{1e3 * (time.perf_counter() - t0) / max(steps, 1):.1f} ms/step wall (device loop, 12 obstacles), "
+          f"final EE position {np.round(row[L['p_lie']][:3], 4)}")
+
+
 def main():
+    if "--device" in sys.argv:
+        return main_device()
     q0 = np.array([0.0, 0.0, 0.0, -np.pi / 2, 0.0, np.pi / 2, 0.0])        # example :20
     be = HipBoundMPC(15)
     node = MPCNode(q0, RobotModel(be.fk), lambda n, dt: HipNlpSolver(n, dt, backend=be))
