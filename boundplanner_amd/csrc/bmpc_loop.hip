@@ -23,14 +23,15 @@ __global__ __launch_bounds__(256) void bmpc_loop_k_bounds(int R, int N, double* 
     loop_bound_const(N, (int)(e % n_w), lbx + e, ubx + e);
 }
 
-// closest pairs collision-point segment <-> obstacle: one thread per (rollout, collision point, obstacle)
+// closest pairs collision-point segment <-> obstacle: one thread per (rollout, collision point), blockIdx.y = obstacle, so
+// that the obstacle's rows are wave-uniform (scalar loads)
 __global__ __launch_bounds__(64) void bmpc_loop_k_colpairs(int R, const RobotConst* rc, LoopScene sc, const double* S, double* colres) {
-    const int e = blockIdx.x * 64 + threadIdx.x, per = 6 * sc.n_obs;
-    if (e >= R * per) return;
-    const int r = e / per, rem = e - r * per, pt = rem / sc.n_obs, ob = rem - pt * sc.n_obs;
+    const int e = blockIdx.x * 64 + threadIdx.x, ob = blockIdx.y;
+    if (e >= R * 6) return;
+    const int r = e / 6, pt = e - 6 * r;
     const double* s = S + (size_t)r * LS_SIZE;
     if (s[LS_dead] != 0.0) return;
-    loop_collision_pair(rc, sc, s, pt, ob, colres + (size_t)e * LP_CRES);
+    loop_collision_pair(rc, sc, s, pt, ob, colres + ((size_t)e * sc.n_obs + ob) * LP_CRES);
 }
 
 __global__ __launch_bounds__(64) void bmpc_loop_k_prepare(int R, int N, const RobotConst* rc, double* S, const double* prev,
@@ -226,8 +227,8 @@ extern "C" int bmpc_loop_set_obstacles(bmpc_loop* L, int n_obs, const double* A,
 static int launch_prepare(bmpc_loop* L) {
     const size_t ne = (size_t)L->R * L->n_w;
     if (L->sc.n_obs > 0) {
-        const int np = L->R * 6 * L->sc.n_obs;
-        hipLaunchKernelGGL(bmpc_loop_k_colpairs, dim3((np + 63) / 64), dim3(64), 0, L->st, L->R, L->d_rc, L->sc, L->d_S, L->d_colres);
+        hipLaunchKernelGGL(bmpc_loop_k_colpairs, dim3((L->R * 6 + 63) / 64, L->sc.n_obs), dim3(64), 0, L->st, L->R, L->d_rc, L->sc, L->d_S,
+                           L->d_colres);
     }
     hipLaunchKernelGGL(bmpc_loop_k_prepare, dim3((L->R + 63) / 64), dim3(64), 0, L->st, L->R, L->N, L->d_rc, L->d_S, L->d_prev,
                        L->d_p, L->d_lbx, L->d_ubx, L->sc, L->d_colres);

@@ -23,6 +23,10 @@
 #pragma once
 #include "bmpc_device.hpp"
 
+#ifndef BMPC_UNROLL
+#define BMPC_UNROLL _Pragma("unroll")
+#endif
+
 namespace bmpc {
 
 constexpr int LP_NL = 11;        // via points + nr_segs-1 padded copies, at most (8 via points)
@@ -254,32 +258,43 @@ struct LoopScene {
     const int* nv;        // [n_obs]
 };
 
-// Euclidean projection of y onto {x: A x <= b - 0.001} (collision_sets._project_polytope)
+// Euclidean projection of y onto {x: A x <= b - 0.001} (collision_sets._project_polytope).  Loops run over the fixed
+// LP_ROWS with an early exit at nr so that, unrolled, Ay / lam stay in registers (static indices)
 BMPC_INL void lp_project_polytope(const double* A, const double* b, const double* AAt, int nr, const double* y, double* x) {
     double Ay[LP_ROWS], lam[LP_ROWS];
     bool inside = true;
-    for (int i = 0; i < nr; i++) {
-        Ay[i] = A[3 * i] * y[0] + A[3 * i + 1] * y[1] + A[3 * i + 2] * y[2];
-        if (Ay[i] - (b[i] - 0.001) > 1e-12) inside = false;
-        lam[i] = 0.0;
+    BMPC_UNROLL
+    for (int i = 0; i < LP_ROWS; i++) {
+        Ay[i] = 0.0; lam[i] = 0.0;
+        if (i < nr) {
+            Ay[i] = A[3 * i] * y[0] + A[3 * i + 1] * y[1] + A[3 * i + 2] * y[2];
+            if (Ay[i] - (b[i] - 0.001) > 1e-12) inside = false;
+        }
     }
     x[0] = y[0]; x[1] = y[1]; x[2] = y[2];
     if (inside) return;
     for (int sweep = 0; sweep < 1200; sweep++) {
         double max_change = 0.0;
-        for (int i = 0; i < nr; i++) {
-            double r = Ay[i];
-            for (int j = 0; j < nr; j++) r -= AAt[LP_ROWS * i + j] * lam[j];
-            r -= (b[i] - 0.001);
-            const double dg = fmax(AAt[LP_ROWS * i + i], 1e-16);
-            const double nw = fmax(0.0, lam[i] + r / dg);
-            max_change = fmax(max_change, fabs(nw - lam[i]));
-            lam[i] = nw;
+        BMPC_UNROLL
+        for (int i = 0; i < LP_ROWS; i++) {
+            if (i < nr) {
+                double r = Ay[i];
+                BMPC_UNROLL
+                for (int j = 0; j < LP_ROWS; j++)
+                    if (j < nr) r -= AAt[LP_ROWS * i + j] * lam[j];
+                r -= (b[i] - 0.001);
+                const double dg = fmax(AAt[LP_ROWS * i + i], 1e-16);
+                const double nw = fmax(0.0, lam[i] + r / dg);
+                max_change = fmax(max_change, fabs(nw - lam[i]));
+                lam[i] = nw;
+            }
         }
         if (max_change < 1e-13) break;
     }
-    for (int i = 0; i < nr; i++)
-        for (int c = 0; c < 3; c++) x[c] -= A[3 * i + c] * lam[i];
+    BMPC_UNROLL
+    for (int i = 0; i < LP_ROWS; i++)
+        if (i < nr)
+            for (int c = 0; c < 3; c++) x[c] -= A[3 * i + c] * lam[i];
 }
 
 BMPC_INL double lp_seg_dist(const double* A, const double* b, const double* AAt, int nr, const double* p0, const double* d,
