@@ -106,6 +106,9 @@ def main():
         kernel_ms.append(bes[j].last_kernel_ms())
         if world > 1:
             dist.all_gather_into_tensor(gathered, outs[j]["x"])
+            # the next solve on this handle overwrites outs[j]["x"]: the gather must have read it (only torch's current
+            # stream is waited for, the other handles' solver streams keep running)
+            torch.cuda.current_stream(dev).synchronize()
 
     def run(nsteps):
         for i in range(nsteps):
