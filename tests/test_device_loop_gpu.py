@@ -188,3 +188,40 @@ def test_device_loop_with_obstacles_tracks_host_loop():
     assert rows > 6                    # obstacle halfspaces were active in the collision sets
     assert np.isfinite(dmax) and dmax < 1e-5, dmax           # the halfspaces agree to ~1e-7 (golden section), the closed loops stay together
     assert (log[:, loop.LOG["dead"]] == 0).all()
+
+
+def test_device_loop_tracks_reference_trace_with_hip_solver(golden_dir):
+    """The reference's closed-loop scenario end to end on the device (prepare kernel -> HIP solve -> finish kernel):
+    same switching step, same number of steps to the path end, states within the stated solver tolerance of the
+    golden trace (which was produced by the reference's host code with the CPU oracle in the solver slot)."""
+    import oracle_lib as O
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.mpc_node import MPCNode
+    from boundplanner_amd.robot_model import RobotModel
+    from boundplanner_amd.solver import HipBoundMPC
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    N = int(g["N"])
+    params = _params(N)
+    be = HipBoundMPC(N)
+    loop = DeviceLoop(be, 1)
+    seed = MPCNode(g["in_q"][0], RobotModel(be.fk), lambda n, dt: None, params=params)   # host construction only
+    loop.set_rollout(0, seed.mpc, seed.q, seed.dq, seed.ddq, seed.jerk, seed.qf, seed.v, seed.p_lie)
+    loop.upload()
+    n_steps, n_update = g["in_q"].shape[0], int(g["n_update"])
+    L, dq_max, dp_max, iters = loop.LOG, 0.0, 0.0, []
+    for k in range(n_steps):
+        if k == n_update:
+            V = loop.download()
+            loop.replan(0, seed.mpc, [p.copy() for p in g["via_p_via"]], [r.copy() for r in g["via_r_via"]],
+                        [b.copy() for b in g["via_bp1"]], [b.copy() for b in g["via_br1"]], [e.copy() for e in g["via_e_r_bound"]],
+                        [a.copy() for a in g["via_a_sets"]], [b.copy() for b in g["via_b_sets"]])
+            loop.upload()
+        row = loop.run(1)[0, 0]
+        iters.append(row[L["iters"]])
+        assert int(row[L["split1"]]) == int(g["split_idxs"][k][1]) and int(row[L["sector"]]) == int(g["sector"][k]), k
+        assert row[L["error_count"]] == 0
+        dq_max = max(dq_max, np.abs(row[L["q"]] - g["out_q"][k]).max())
+        dp_max = max(dp_max, np.abs(row[L["p_lie"]] - g["out_p_lie"][k]).max())
+    assert dp_max < 1e-3 and dq_max < 5e-3, (dp_max, dq_max)
+    assert row[L["phi"]] >= row[L["phi_max"]] - 0.001
+    assert abs(np.mean(iters) - g["iters"].mean()) < 1.0
