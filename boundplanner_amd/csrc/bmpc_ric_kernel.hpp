@@ -378,6 +378,7 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
                 RL(R_vt0)[r] = v;
             }
             BMPC_SYNC();
+            RPROF(7);
             // C2: structured part Phi0^T P Phi0.  Every lane first gathers the operands of ALL its
             // entries (joint x joint block, two joint x single entries, two single x single entries),
             // then computes and scatters: one LDS latency instead of five
@@ -479,6 +480,7 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
                 }
             }
             BMPC_SYNC();
+            RPROF(8);
             // C3: rank-3 part  D[i][j] = Y~[i] . E[:, j] + Y~[j] . E[:, i]  on the 21 columns j where E is
             // nonzero: lane = column (three lane groups split the rows), two rows per batch
             {

@@ -12,7 +12,7 @@ r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
 buf = (ctypes.c_double * 16)()
 be.lib.bmpc_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 be.lib.bmpc_debug_phase_cycles(be._h, buf)
-names = ['load+scatter', 'lam-curv', 'T', 'couple', 'adj+chol+gains', 'schur', 'forward(all stages)']
+names = ['load+scatter', 'lam-curv', 'T', 'couple C3 + gradients', 'adj+chol+gains', 'schur', 'forward(all stages)', 'couple C1 (Et, Y, vt0)', 'couple C2 (structured)']
 v = np.array(list(buf)); its = (r["iters"].sum() + B) * (N - 1)
 print("kernel ms", be.last_kernel_ms(), "iters mean", r["iters"].mean())
 for n, x in zip(names, v):
