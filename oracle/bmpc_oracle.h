@@ -13,8 +13,9 @@
  * requirements.txt:1, call site BoundMPC.py:594-603) cannot be executed in this project
  * (no wheel, no network): PARITY AT THE IPOPT BOUNDARY IS UNPINNED.  The solver below follows
  * the published algorithm (Waechter & Biegler 2006: slack-based primal-dual IP,
- * fraction-to-boundary, LOQO-style adaptive mu, IPOPT's scaled termination error) on a
- * stage-condensed form of the same NLP, and is validated by KKT residuals of the pinned NLP.
+ * fraction-to-boundary, filter line search, monotone barrier update, IPOPT's scaled termination error) on a
+ * stage-condensed form of the same NLP, and is validated by KKT residuals of the pinned NLP and by an independent
+ * SLSQP solve of the same NLP that reaches the same solutions (tests/test_independent_solver.py).
  */
 #ifndef BMPC_ORACLE_H
 #define BMPC_ORACLE_H

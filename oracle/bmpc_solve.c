@@ -5,7 +5,8 @@
  * IPOPT (+MUMPS) applied to the NLP of casadi_ocp_formulation.py.  IPOPT is a third-party
  * dependency that is absent from /root/reference and from this image, so this file restates
  * the PUBLISHED algorithm family (Waechter & Biegler, Math. Prog. 106, 2006: slack-based
- * primal-dual barrier method, fraction-to-boundary rule, LOQO adaptive barrier update,
+ * primal-dual barrier method, fraction-to-boundary rule, filter line search, monotone Fiacco-McCormick
+ * barrier update (default; the LOQO rule of IPOPT's mu_oracle=loqo is available as mu_strategy=0),
  * scaled optimality error of eq. (5)-(6) with tol/dual_inf_tol/constr_viol_tol/compl_inf_tol)
  * on an equivalent stage-condensed form of the same NLP:
  *
