@@ -178,8 +178,9 @@ class DeviceLoop:
         mpc.slacks0 = V["slacks0"].copy(); mpc.error_count = int(V["error_count"][0])
         mpc.prev_solution = self.prev[r].copy() if V["has_prev"][0] != 0 else None
         q = V["q"].copy()
+        from .params import Params
         mpc.update(p_via, r_via, bp1, br1, e_r_bound, a_sets, b_sets, [], V["v"].copy(), p0=V["p_lie"].copy(),
-                   params=type("P", (), {"weights": V["weights"].copy()})())
+                   params=Params(n=self.N, dt=self.be.opts.dt, build=False, weights=V["weights"].copy(), nr_segs=mpc.nr_segs))
         self.state[r] = pack_state(self.lay, mpc, q, V["dq"].copy(), V["ddq"].copy(), V["jerk"].copy(), q, V["v"].copy(),
                                    V["p_lie"].copy())
 
