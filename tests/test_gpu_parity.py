@@ -278,3 +278,22 @@ def test_config1_full_batch_against_oracle(backends):
     assert d_task[conv].max() < 1e-3
     assert (np.abs(r["f"][conv] - ro["f"][conv]) <= 1e-5 * np.maximum(1.0, np.abs(ro["f"][conv]))).all()
     assert abs(r["iters"].mean() - ro["iters"].mean()) < 0.05
+
+
+def test_longest_horizon(backends):
+    """N = 64, the longest horizon the handle accepts (one instance per wavefront in the thread-per-pair kernels, 63
+    Riccati stages): instances that converge on both sides agree with the oracle; one of the six wanders to max_iter on
+    the oracle and may or may not do so on the GPU."""
+    from boundplanner_amd import scenes
+    N, B = 64, 6
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 64, be.fk, randomize_sets=False)
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], nthreads=0)
+    conv = (r["status"] == 0) & (ro["status"] == 0)
+    assert conv.sum() >= B - 1
+    eq = conv & (np.abs(r["iters"] - ro["iters"]) <= 1)
+    assert eq.sum() >= conv.sum() - 1
+    assert np.abs(r["x"][eq][:, 28 * N:40 * N] - ro["x"][eq][:, 28 * N:40 * N]).max() < 1e-4
+    assert np.abs(r["f"][conv] - ro["f"][conv]).max() < 1e-5 * np.abs(ro["f"][conv]).max()
+    assert (r["viol"][conv] < 1e-4).all()
