@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--bpc", type=int, default=None, help="resident workgroups per CU")
     ap.add_argument("--depth", type=int, default=3, help="solves in flight (2: the straggler tail of one batch overlaps "
                     "the bulk of the next, two handles used alternately; 1: one at a time)")
+    ap.add_argument("--merge", type=int, default=2, help="8192-instance batches handed to the solver per call (they are independent: "
+                    "a larger launch amortises the straggler tail over more bulk work)")
     ap.add_argument("--gate", type=float, default=0.2, help="start the next batch when the others have < gate*B active")
     ap.add_argument("--engine", type=int, default=None, help="0 pipeline (default), 1 persistent kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,21 +82,23 @@ def main():
     if args.engine is not None:
         kw["engine"] = args.engine
     depth = max(1, min(args.depth, 4))
-    bes = [HipBoundMPC(N, device=local_rank, max_batch=B, **kw) for _ in range(depth)]
+    M = max(1, min(args.merge, 4))
+    bes = [HipBoundMPC(N, device=local_rank, max_batch=M * B, **kw) for _ in range(depth)]
     be = bes[0]
     t0 = time.time()
     batch = scenes.make_batch(B, N, 8192 + rank, be.fk, randomize_sets=True)
     t_gen = time.time() - t0
     big = lambda a: np.nan_to_num(a, posinf=1e20, neginf=-1e20)
-    d = {k: torch.from_numpy(big(batch[k])).to(dev) for k in ("x0", "lbx", "ubx", "p")}
+    # M batches per solver call: the synthetic batch repeated M times (every batch of the run is this same batch anyway)
+    d = {k: torch.from_numpy(big(batch[k])).to(dev).repeat(M, 1).contiguous() for k in ("x0", "lbx", "ubx", "p")}
     n_w = be.n_w
     # one set of output buffers per handle in flight
-    outs = [dict(x=torch.empty((B, n_w), dtype=torch.float64, device=dev), f=torch.empty(B, dtype=torch.float64, device=dev),
-                 viol=torch.empty(B, dtype=torch.float64, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev),
-                 status=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(depth)]
-    gathered = torch.empty((world * B, n_w), dtype=torch.float64, device=dev) if world > 1 else None
+    outs = [dict(x=torch.empty((M * B, n_w), dtype=torch.float64, device=dev), f=torch.empty(M * B, dtype=torch.float64, device=dev),
+                 viol=torch.empty(M * B, dtype=torch.float64, device=dev), iters=torch.empty(M * B, dtype=torch.int32, device=dev),
+                 status=torch.empty(M * B, dtype=torch.int32, device=dev)) for _ in range(depth)]
+    gathered = torch.empty((world * M * B, n_w), dtype=torch.float64, device=dev) if world > 1 else None
     torch.cuda.synchronize(dev)      # inputs complete before any handle's own stream reads them
-    busy = [False] * depth
+    busy = [0] * depth               # batches in the solve in flight on each handle
     kernel_ms = []
 
     def retire(j):
@@ -102,30 +106,35 @@ def main():
         if not busy[j]:
             return
         bes[j].wait()
-        busy[j] = False
-        kernel_ms.append(bes[j].last_kernel_ms())
+        m, busy[j] = busy[j], 0
+        kernel_ms.append(bes[j].last_kernel_ms() / m)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, outs[j]["x"])
+            dist.all_gather_into_tensor(gathered[:world * m * B], outs[j]["x"][:m * B])
             # the next solve on this handle overwrites outs[j]["x"]: the gather must have read it (only torch's current
             # stream is waited for, the other handles' solver streams keep running)
             torch.cuda.current_stream(dev).synchronize()
 
     def run(nsteps):
-        for i in range(nsteps):
-            j = i % depth
+        """nsteps batches, M per solver call (the last call takes what is left)."""
+        calls, left = 0, nsteps
+        while left > 0:
+            m = min(M, left)
+            j = calls % depth
             retire(j)
-            # start the next batch when the batches in flight have left their bulk phase (most of their
-            # instances finished): the launch-latency-bound straggler tail of one batch then runs beside
+            # start the next call when the solves in flight have left their bulk phase (most of their
+            # instances finished): the launch-latency-bound straggler tail of one solve then runs beside
             # the throughput-bound bulk of the next
-            while any(busy[q] and bes[q].active() > args.gate * B for q in range(depth)):
+            while any(busy[q] and bes[q].active() > args.gate * busy[q] * B for q in range(depth)):
                 time.sleep(0.0005)
             o = outs[j]
-            bes[j].solve_dev_async(B, d["x0"].data_ptr(), d["lbx"].data_ptr(), d["ubx"].data_ptr(), d["p"].data_ptr(),
+            bes[j].solve_dev_async(m * B, d["x0"].data_ptr(), d["lbx"].data_ptr(), d["ubx"].data_ptr(), d["p"].data_ptr(),
                                    o["x"].data_ptr(), o["f"].data_ptr(), o["iters"].data_ptr(), o["status"].data_ptr(),
                                    o["viol"].data_ptr())
-            busy[j] = True
+            busy[j] = m
+            calls += 1
+            left -= m
         for j in range(depth):
-            retire((nsteps + j) % depth)
+            retire((calls + j) % depth)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -144,7 +153,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    x, iters, status, viol = outs[0]["x"], outs[0]["iters"], outs[0]["status"], outs[0]["viol"]
+    x, iters, status, viol = outs[0]["x"][:B], outs[0]["iters"][:B], outs[0]["status"][:B], outs[0]["viol"][:B]
 
     it_np, st_np, viol_np = iters.cpu().numpy(), status.cpu().numpy(), viol.cpu().numpy()
     ok = (st_np == 0) | (viol_np < 1e-4)            # the reference's acceptance test (BoundMPC.py:617)
@@ -175,7 +184,8 @@ def main():
         "config": {"workload": f"BASELINE configs[2]: {B}-batch per GPU, randomized convex-set obstacles, N={N}, "
                                "cold start, tol 1e-5, max_iter 100", "batch_per_gpu": B, "horizon": N,
                    "sharding": "independent instances per rank + RCCL all-gather of x" if world > 1 else "single GPU",
-                   "hess": int(be.opts.hess), "engine": int(be.opts.engine), "batches_in_flight": depth},
+                   "hess": int(be.opts.hess), "engine": int(be.opts.engine), "solver_handles_in_flight": depth,
+                   "batches_per_solver_call": M, "batches_in_flight": depth * M},
         "solver": {"iters_mean": mean_it, "iters_p50": float(np.median(it_np)), "iters_p99": float(np.percentile(it_np, 99)),
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
                    "accepted_frac": float(ok.mean()), "gen_s": t_gen},
