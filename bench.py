@@ -51,7 +51,8 @@ def main():
                     "the bulk of the next, two handles used alternately; 1: one at a time)")
     ap.add_argument("--merge", type=int, default=2, help="8192-instance batches handed to the solver per call (they are independent: "
                     "a larger launch amortises the straggler tail over more bulk work)")
-    ap.add_argument("--gate", type=float, default=0.2, help="start the next batch when the others have < gate*B active")
+    ap.add_argument("--gate", type=float, default=1.0, help="start the next solver call when the others have < gate * their instances "
+                    "active (1.0: at once -- with two batches per call holding calls back no longer pays)")
     ap.add_argument("--engine", type=int, default=None, help="0 pipeline (default), 1 persistent kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
