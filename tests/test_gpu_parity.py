@@ -297,3 +297,22 @@ def test_longest_horizon(backends):
     assert np.abs(r["x"][eq][:, 28 * N:40 * N] - ro["x"][eq][:, 28 * N:40 * N]).max() < 1e-4
     assert np.abs(r["f"][conv] - ro["f"][conv]).max() < 1e-5 * np.abs(ro["f"][conv]).max()
     assert (r["viol"][conv] < 1e-4).all()
+
+
+def test_poisoned_instance_is_contained(backends):
+    """A NaN / infinite parameter in one instance must not hang the batch or leak into its neighbours: the other
+    instances return bitwise what they return without it, the poisoned one comes back with a nonzero status."""
+    from boundplanner_amd import scenes
+    N, B = 10, 9
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 1024, be.fk)
+    clean = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    p = batch["p"].copy()
+    p[4, 100] = np.nan          # a reference-path entry of instance 4
+    x0 = batch["x0"].copy()
+    x0[7, 3] = np.inf           # a start-vector entry of instance 7
+    r = be.solve_batch(x0, batch["lbx"], batch["ubx"], p)
+    ok = [i for i in range(B) if i not in (4, 7)]
+    assert np.array_equal(r["x"][ok], clean["x"][ok]) and np.array_equal(r["iters"][ok], clean["iters"][ok])
+    assert r["status"][4] != 0 and r["status"][7] != 0
+    assert (r["iters"][[4, 7]] <= be.opts.max_iter).all()
