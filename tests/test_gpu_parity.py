@@ -316,3 +316,26 @@ def test_poisoned_instance_is_contained(backends):
     assert np.array_equal(r["x"][ok], clean["x"][ok]) and np.array_equal(r["iters"][ok], clean["iters"][ok])
     assert r["status"][4] != 0 and r["status"][7] != 0
     assert (r["iters"][[4, 7]] <= be.opts.max_iter).all()
+
+
+def test_two_handles_from_two_host_threads():
+    """One handle per host thread (the C ABI's threading contract): concurrent solves on the same GPU return what the
+    same solves return one after the other."""
+    import threading
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N = 10
+    hs = [HipBoundMPC(N), HipBoundMPC(N)]
+    batches = [scenes.make_batch(96, N, 11 + i, hs[0].fk, randomize_sets=True) for i in range(2)]
+    seq = [hs[i].solve_batch(b["x0"], b["lbx"], b["ubx"], b["p"]) for i, b in enumerate(batches)]
+    par = [None, None]
+
+    def work(i):
+        b = batches[i]
+        for _ in range(3):
+            par[i] = hs[i].solve_batch(b["x0"], b["lbx"], b["ubx"], b["p"])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(2):
+        assert np.array_equal(par[i]["x"], seq[i]["x"]) and np.array_equal(par[i]["status"], seq[i]["status"])
