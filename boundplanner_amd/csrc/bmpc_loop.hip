@@ -85,7 +85,7 @@ struct bmpc_loop {
     double *d_S = nullptr, *d_prev = nullptr, *d_x0 = nullptr, *d_lbx = nullptr, *d_ubx = nullptr, *d_p = nullptr,
            *d_x = nullptr, *d_f = nullptr, *d_viol = nullptr, *d_log = nullptr;
     int *d_iters = nullptr, *d_status = nullptr;
-    LoopScene sc{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // device pointers
+    LoopScene sc{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // device pointers
     double* d_scene = nullptr;     // A | b | AAt | V
     int* d_scene_i = nullptr;      // nrows | nv
     double* d_colres = nullptr;
@@ -192,13 +192,14 @@ extern "C" int bmpc_loop_set_obstacles(bmpc_loop* L, int n_obs, const double* A,
     if (L->d_scene) { (void)hipFree(L->d_scene); L->d_scene = nullptr; }
     if (L->d_scene_i) { (void)hipFree(L->d_scene_i); L->d_scene_i = nullptr; }
     if (L->d_colres) { (void)hipFree(L->d_colres); L->d_colres = nullptr; }
-    L->sc = LoopScene{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    L->sc = LoopScene{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n_obs == 0) return 0;
     for (int i = 0; i < n_obs; i++)
         if (nrows[i] < 1 || nrows[i] > LP_ROWS || nv[i] < 1 || nv[i] > LP_NV) { L->err = "obstacle with too many rows or vertices"; return 1; }
     const size_t nA = (size_t)n_obs * 45, nb = (size_t)n_obs * LP_ROWS, nAAt = (size_t)n_obs * LP_ROWS * LP_ROWS, nV = (size_t)n_obs * LP_NV * 3;
-    std::vector<double> h(nA + nb + nAAt + nV, 0.0);
-    std::vector<int> hi(2 * (size_t)n_obs);
+    const size_t nBox = (size_t)n_obs * 6;
+    std::vector<double> h(nA + nb + nAAt + nV + nBox, 0.0);
+    std::vector<int> hi(3 * (size_t)n_obs);
     for (int o = 0; o < n_obs; o++) {
         for (int r = 0; r < nrows[o]; r++) {
             for (int c = 0; c < 3; c++) h[45 * o + 3 * r + c] = A[45 * o + 3 * r + c];
@@ -213,6 +214,8 @@ extern "C" int bmpc_loop_set_obstacles(bmpc_loop* L, int n_obs, const double* A,
         for (int v = 0; v < nv[o]; v++)
             for (int c = 0; c < 3; c++) h[nA + nb + nAAt + 3 * ((size_t)LP_NV * o + v) + c] = V[3 * (LP_NV * o + v) + c];
         hi[o] = nrows[o]; hi[n_obs + o] = nv[o];
+        double* bx = h.data() + nA + nb + nAAt + nV + 6 * (size_t)o;
+        hi[2 * n_obs + o] = loop_detect_box(A + 45 * o, b + LP_ROWS * o, nrows[o], bx, bx + 3) ? 1 : 0;
     }
     LCHK(L, hipMalloc((void**)&L->d_scene, h.size() * sizeof(double)));
     LCHK(L, hipMemcpy(L->d_scene, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -220,7 +223,8 @@ extern "C" int bmpc_loop_set_obstacles(bmpc_loop* L, int n_obs, const double* A,
     LCHK(L, hipMemcpy(L->d_scene_i, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice));
     LCHK(L, hipMalloc((void**)&L->d_colres, (size_t)L->R * 6 * n_obs * LP_CRES * sizeof(double)));
     LCHK(L, hipMemset(L->d_colres, 0, (size_t)L->R * 6 * n_obs * LP_CRES * sizeof(double)));
-    L->sc = LoopScene{n_obs, L->d_scene, L->d_scene + nA, L->d_scene + nA + nb, L->d_scene_i, L->d_scene + nA + nb + nAAt, L->d_scene_i + n_obs};
+    L->sc = LoopScene{n_obs, L->d_scene, L->d_scene + nA, L->d_scene + nA + nb, L->d_scene_i, L->d_scene + nA + nb + nAAt, L->d_scene_i + n_obs,
+                      L->d_scene + nA + nb + nAAt + nV, L->d_scene_i + 2 * n_obs};
     return 0;
 }
 

@@ -256,7 +256,29 @@ struct LoopScene {
     const int* nrows;     // [n_obs]
     const double* V;      // [n_obs][LP_NV][3]
     const int* nv;        // [n_obs]
+    const double* box;    // [n_obs][6]: lo(3), hi(3) of obstacles that are axis-aligned boxes (is_box[o] != 0)
+    const int* is_box;    // [n_obs]
 };
+
+// host side (upload / CPU harness): is {A x <= b} (nr rows) an axis-aligned box?  If so lo/hi are its bounds.
+inline bool loop_detect_box(const double* A, const double* b, int nr, double* lo, double* hi) {
+    if (nr != 6) return false;
+    bool have[6] = {false, false, false, false, false, false};
+    for (int r = 0; r < 6; r++) {
+        int ax = -1;
+        for (int c = 0; c < 3; c++) {
+            const double a = A[3 * r + c];
+            if (a == 0.0) continue;
+            if ((a != 1.0 && a != -1.0) || ax >= 0) return false;
+            ax = c;
+        }
+        if (ax < 0) return false;
+        if (A[3 * r + ax] > 0) { if (have[ax]) return false; have[ax] = true; hi[ax] = b[r]; }
+        else { if (have[3 + ax]) return false; have[3 + ax] = true; lo[ax] = -b[r]; }
+    }
+    for (int i = 0; i < 6; i++) if (!have[i]) return false;
+    return true;
+}
 
 // Euclidean projection of y onto {x: A x <= b - 0.001} (collision_sets._project_polytope).  Loops run over the fixed
 // LP_ROWS with an early exit at nr so that, unrolled, Ay / lam stay in registers (static indices)
@@ -297,43 +319,49 @@ BMPC_INL void lp_project_polytope(const double* A, const double* b, const double
             for (int c = 0; c < 3; c++) x[c] -= A[3 * i + c] * lam[i];
 }
 
-BMPC_INL double lp_seg_dist(const double* A, const double* b, const double* AAt, int nr, const double* p0, const double* d,
-                            double phi, double* x) {
+// distance from the segment point p0 + phi d to the polytope {A x <= b - 0.001}; box != null: the polytope is the
+// axis-aligned box [lo, hi] and its exact projection is a clamp (what Hildreth's iteration converges to)
+BMPC_INL double lp_seg_dist(const double* A, const double* b, const double* AAt, int nr, const double* box, const double* p0,
+                            const double* d, double phi, double* x) {
     const double y[3] = {p0[0] + phi * d[0], p0[1] + phi * d[1], p0[2] + phi * d[2]};
-    lp_project_polytope(A, b, AAt, nr, y, x);
+    if (box) {
+        for (int c = 0; c < 3; c++) x[c] = fmin(fmax(y[c], box[c] + 0.001), box[3 + c] - 0.001);
+    } else {
+        lp_project_polytope(A, b, AAt, nr, y, x);
+    }
     return sqrt((y[0] - x[0]) * (y[0] - x[0]) + (y[1] - x[1]) * (y[1] - x[1]) + (y[2] - x[2]) * (y[2] - x[2]));
 }
 
 // closest pair segment <-> polytope (collision_sets.closest_pair_segment_polytope); out: x, y = p0 + phi d, distance
-BMPC_DEV void loop_closest_pair(const double* A, const double* b, const double* AAt, int nr, const double* p0, const double* p1,
-                                double* out) {
+BMPC_DEV void loop_closest_pair(const double* A, const double* b, const double* AAt, int nr, const double* box, const double* p0,
+                                const double* p1, double* out) {
     const double d[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
     double x[3], phi = 0.0;
     if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) >= 1e-12) {
         double lo = 0.0, hi = 1.0;
         const double gr = (sqrt(5.0) - 1.0) / 2.0;
         double c = hi - gr * (hi - lo), e = lo + gr * (hi - lo);
-        double fc = lp_seg_dist(A, b, AAt, nr, p0, d, c, x), fe = lp_seg_dist(A, b, AAt, nr, p0, d, e, x);
+        double fc = lp_seg_dist(A, b, AAt, nr, box, p0, d, c, x), fe = lp_seg_dist(A, b, AAt, nr, box, p0, d, e, x);
         for (int it = 0; it < 80; it++) {
             if (fc < fe) {
                 hi = e; e = c; fe = fc;
                 c = hi - gr * (hi - lo);
-                fc = lp_seg_dist(A, b, AAt, nr, p0, d, c, x);
+                fc = lp_seg_dist(A, b, AAt, nr, box, p0, d, c, x);
             } else {
                 lo = c; c = e; fc = fe;
                 e = lo + gr * (hi - lo);
-                fe = lp_seg_dist(A, b, AAt, nr, p0, d, e, x);
+                fe = lp_seg_dist(A, b, AAt, nr, box, p0, d, e, x);
             }
         }
         const double pm = 0.5 * (lo + hi);
-        const double f0 = lp_seg_dist(A, b, AAt, nr, p0, d, 0.0, x), f1 = lp_seg_dist(A, b, AAt, nr, p0, d, 1.0, x),
-                     fm = lp_seg_dist(A, b, AAt, nr, p0, d, pm, x);
+        const double f0 = lp_seg_dist(A, b, AAt, nr, box, p0, d, 0.0, x), f1 = lp_seg_dist(A, b, AAt, nr, box, p0, d, 1.0, x),
+                     fm = lp_seg_dist(A, b, AAt, nr, box, p0, d, pm, x);
         // min over (distance, phi) pairs in the order (0, 1, pm): ties go to the smaller phi
         double best = f0; phi = 0.0;
         if (f1 < best) { best = f1; phi = 1.0; }
         if (fm < best || (fm == best && pm < phi)) { best = fm; phi = pm; }
     }
-    const double dist = lp_seg_dist(A, b, AAt, nr, p0, d, phi, x);
+    const double dist = lp_seg_dist(A, b, AAt, nr, box, p0, d, phi, x);
     for (int c = 0; c < 3; c++) { out[c] = x[c]; out[3 + c] = p0[c] + phi * d[c]; }
     out[6] = dist; out[7] = phi;
 }
@@ -343,7 +371,8 @@ BMPC_DEV void loop_collision_pair(const RobotConst* rc, const LoopScene& sc, con
     Kin k0, kf;
     kin_eval(rc, S + LS_q, k0);
     kin_eval(rc, S + LS_qf, kf);
-    loop_closest_pair(sc.A + 45 * ob, sc.b + LP_ROWS * ob, sc.AAt + LP_ROWS * LP_ROWS * ob, sc.nrows[ob], k0.pc[pt], kf.pc[pt], out);
+    loop_closest_pair(sc.A + 45 * ob, sc.b + LP_ROWS * ob, sc.AAt + LP_ROWS * LP_ROWS * ob, sc.nrows[ob],
+                      sc.is_box[ob] ? sc.box + 6 * ob : nullptr, k0.pc[pt], kf.pc[pt], out);
 }
 
 // greedy nearest-first separating halfspaces of one collision point (ConvexSetFinder.py:330-375); res: the

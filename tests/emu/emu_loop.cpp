@@ -51,7 +51,10 @@ extern "C" void emu_loop_prepare_obs(int N, double* S, const double* prev, doubl
                 for (int c = 0; c < 3; c++) s += A[45 * o + 3 * r + c] * A[45 * o + 3 * q + c];
                 AAt[(size_t)LP_ROWS * LP_ROWS * o + LP_ROWS * r + q] = s;
             }
-    LoopScene sc{n_obs, A, b, AAt.data(), nrows, V, nv};
+    std::vector<double> box((size_t)n_obs * 6, 0.0);
+    std::vector<int> is_box(n_obs, 0);
+    for (int o = 0; o < n_obs; o++) is_box[o] = loop_detect_box(A + 45 * o, b + LP_ROWS * o, nrows[o], box.data() + 6 * o, box.data() + 6 * o + 3) ? 1 : 0;
+    LoopScene sc{n_obs, A, b, AAt.data(), nrows, V, nv, box.data(), is_box.data()};
     for (int pt = 0; pt < 6; pt++)
         for (int ob = 0; ob < n_obs; ob++) loop_collision_pair(&rc, sc, S, pt, ob, colres.data() + (size_t)(pt * n_obs + ob) * LP_CRES);
     for (int i = 0; i < n_w; i++) loop_bound_const(N, i, lbx + i, ubx + i);

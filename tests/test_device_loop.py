@@ -154,14 +154,16 @@ def test_failure_path_matches_host_mirror():
     assert host.mpcs[0].error_count == 0 and max(script) is True
 
 
-def _box_scene(rng, n):
-    """n axis-aligned boxes (as [A, b] + their 8 corners) scattered through the arm's workspace."""
+def _box_scene(rng, n, rotated=0.0):
+    """n boxes (as [A, b] + their 8 corners) scattered through the arm's workspace; a fraction `rotated` of them is
+    turned by a random rotation (general polytopes: the projection then runs Hildreth's iteration, not the box clamp)."""
     sets, pts = [], []
     for _ in range(n):
         c = rng.uniform([-0.7, -0.7, 0.0], [0.7, 0.7, 1.1]); h = rng.uniform(0.03, 0.15, size=3)
-        lo, hi = c - h, c + h
-        sets.append([np.vstack((np.eye(3), -np.eye(3))), np.concatenate((hi, -lo))])
-        pts.append(np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]))
+        Q = R.from_rotvec(rng.normal(size=3)).as_matrix() if rng.uniform() < rotated else np.eye(3)
+        A = np.vstack((Q.T, -Q.T))                    # rows: +-(box axes); x = c + Q u, |u| <= h
+        sets.append([A, np.concatenate((Q.T @ c + h, -(Q.T @ c) + h))])
+        pts.append(np.array([c + Q @ (np.array([sx, sy, sz]) * h) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]))
     return sets, pts
 
 
@@ -179,7 +181,7 @@ def test_collision_sets_with_obstacles_match_host_finder():
     robot = RobotModel(O.fk_batch)
     n_rows_seen = set()
     for trial in range(12):
-        sets, pts = _box_scene(rng, int(rng.integers(1, 9)))
+        sets, pts = _box_scene(rng, int(rng.integers(1, 9)), rotated=0.5 if trial % 2 else 0.0)
         q = rng.uniform(0.6 * Q_LIM_LOWER, 0.6 * Q_LIM_UPPER)
         qf = q + rng.normal(size=7) * rng.choice([0.0, 0.05, 0.4])         # includes the degenerate segment qf == q
         dq = rng.normal(size=7) * 0.1
