@@ -203,7 +203,7 @@ def main():
         import oracle_lib as O               # cpu_baseline leg only
         cores = len(os.sched_getaffinity(0))
         nthr = min(cores, 64)
-        ns = min(B, 64 * nthr)          # ~15 s of host work at ~290 solves/s on 64 threads
+        ns = min(B, 128 * nthr)         # ~12 s of host work at ~670 solves/s on 64 threads
         hess = int(be.opts.hess)
         t0 = time.perf_counter()
         ro = O.solve_batch(N, batch["x0"][:ns], batch["lbx"][:ns], batch["ubx"][:ns], batch["p"][:ns],
@@ -213,7 +213,7 @@ def main():
         both = (ro["status"] == 0) & (st_np[:ns] == 0)
         out["cpu_baseline"] = {
             "value": ns / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
-            "sample": f"first {ns} instances of the same batch, oracle/bmpc_solve.c (same algorithm, FP64, -O2, "
+            "sample": f"first {ns} instances of the same batch, oracle/bmpc_solve.c (same algorithm, FP64, -O3 -march=x86-64-v3, "
                       f"OpenMP over instances) on {nthr} host threads in {tc:.1f} s; the reference's CasADi+IPOPT "
                       "cannot run here (no wheel, no network)",
             "iters_mean": float(ro["iters"].mean()),
