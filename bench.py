@@ -2,16 +2,23 @@
 """Benchmark of the hot path: batched BoundMPC NLP solves on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-gather of the solutions)
 
-One "step" = one pass of the hot path over one batch of synthetic problem instances:
-BASELINE.json configs[2] -- 8192 instances per GPU, randomized convex-set obstacles, horizon
-N = 20, iiwa14 (SURVEY.md 8(d) generator, seed 8192 + rank).  Inputs are resident in HBM when the
-timed region starts (bmpc_solve_dev with device pointers).  Prints ONE JSON line on rank 0.
+N = 1: BASELINE.json configs[2] -- 8192 instances, randomized convex-set obstacles, horizon 20, iiwa14 (SURVEY.md
+8(d) generator; step 0 is seed 8192, step s > 0 is seed [8192, s]: a fresh batch every step).
+N > 1: BASELINE.json configs[3] -- one batch of 8192*N instances (seed 65536; shard r of step s is generated from seed
+[65536, s, r]) cut into contiguous shards, one process per GPU, no data-path collective, RCCL all-gather of the solution
+blocks.  Started either by the driver (`python -m torch.distributed.run ... bench.py --gpus N ...`) or by this script
+itself: without WORLD_SIZE in the environment `--gpus N` launches the N ranks as a child `torch.distributed.run` before
+anything touches the GPU, and exits with the child's code.  It refuses (non-zero exit) when fewer than N GPUs are visible.
+
+One "step" = one pass of the hot path over one batch.  Inputs are resident in HBM when the timed region starts
+(bmpc_solve_dev_async with device pointers).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +32,7 @@ HORIZON = 20
 BATCH_PER_GPU = 8192
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VEC_PEAK_TFLOPS = 78.6    # vector FP64 peak (spec); the binding resource of this kernel
+MAX_DISTINCT = 8               # distinct batches resident at once (231 MB each); longer runs cycle through them
 
 
 def alg_bytes_per_solve(N):
@@ -37,6 +45,38 @@ def alg_flops_per_solve(N, iters):
     return iters * N * 1.2e5
 
 
+def batch_seed(world, rank, step):
+    """Seed of the batch rank `rank` solves in step `step` (see the module docstring)."""
+    if world == 1:
+        return 8192 if step == 0 else [8192, step]
+    return [65536, step, rank]
+
+
+def block_diffs(N, xa, xb):
+    """max |xa - xb| per block of the decision vector (casadi_ocp_formulation.py:89-101), over the rows given."""
+    blocks = {"q": (0, 7 * N), "dq": (7 * N, 14 * N), "ddq": (14 * N, 21 * N), "u": (21 * N, 28 * N),
+              "p": (28 * N, 34 * N), "v": (34 * N, 40 * N), "slacks": (40 * N, 44 * N + 6)}
+    d = np.abs(xa - xb)
+    return {k: float(d[:, a:b].max()) if d.size else None for k, (a, b) in blocks.items()}
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start N ranks as a child torch.distributed.run (a child process, before this
+    process has touched the GPU -- never a re-exec) and return its exit code."""
+    import torch
+    have = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to print a line for fewer ranks",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,34 +87,57 @@ def main():
     ap.add_argument("--hess", type=int, default=None)
     ap.add_argument("--wpi", type=int, default=None, help="wavefronts per instance (1, 2, 4)")
     ap.add_argument("--bpc", type=int, default=None, help="resident workgroups per CU")
-    ap.add_argument("--depth", type=int, default=3, help="solves in flight (2: the straggler tail of one batch overlaps "
-                    "the bulk of the next, two handles used alternately; 1: one at a time)")
-    ap.add_argument("--merge", type=int, default=2, help="8192-instance batches handed to the solver per call (they are independent: "
+    ap.add_argument("--depth", type=int, default=3, help="solver calls in flight (the straggler tail of one overlaps the bulk of "
+                    "the next); 1: one at a time")
+    ap.add_argument("--merge", type=int, default=2, help="batches handed to the solver per call (they are independent: "
                     "a larger launch amortises the straggler tail over more bulk work)")
     ap.add_argument("--gate", type=float, default=1.0, help="start the next solver call when the others have < gate * their instances "
-                    "active (1.0: at once -- with two batches per call holding calls back no longer pays)")
+                    "active (1.0: at once)")
     ap.add_argument("--engine", type=int, default=None, help="0 pipeline (default), 1 persistent kernel")
+    ap.add_argument("--same-batch", action="store_true", help="every step solves the seed-8192 batch (profiling passes)")
+    ap.add_argument("--gen-workers", type=int, default=None, help="processes building problem instances (0: in this process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the single-batch and PCIe-inclusive measurements")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    from boundplanner_amd import scenes
+    N, B = args.horizon, args.batch
+    depth = max(1, min(args.depth, 4))
+    M = max(1, min(args.merge, 4))
+    n_distinct = 1 if args.same_batch else min(args.steps + args.warmup, MAX_DISTINCT)
+    n_distinct = M * ((n_distinct + M - 1) // M)
+    # instance-building workers: forked BEFORE this process initialises the GPU; they never touch it
+    pool = None
+    n_workers = args.gen_workers if args.gen_workers is not None else max(0, min(16, len(os.sched_getaffinity(0)) // max(1, world) - 2))
+    if n_workers > 0 and n_distinct > 1:
+        import multiprocessing as mp
+        pool = mp.get_context("fork").Pool(n_workers)
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL sees {dist.get_world_size()} ranks, --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from boundplanner_amd import scenes
+    from boundplanner_amd.batch_stream import BatchStream, HipHandle
     from boundplanner_amd.solver import HipBoundMPC
 
-    N, B = args.horizon, args.batch
     kw = {} if args.hess is None else {"hess": args.hess}
     if args.wpi is not None:
         kw["waves_per_instance"] = args.wpi
@@ -82,60 +145,40 @@ def main():
         kw["blocks_per_cu"] = args.bpc
     if args.engine is not None:
         kw["engine"] = args.engine
-    depth = max(1, min(args.depth, 4))
-    M = max(1, min(args.merge, 4))
     bes = [HipBoundMPC(N, device=local_rank, max_batch=M * B, **kw) for _ in range(depth)]
     be = bes[0]
-    t0 = time.time()
-    batch = scenes.make_batch(B, N, 8192 + rank, be.fk, randomize_sets=True)
-    t_gen = time.time() - t0
-    big = lambda a: np.nan_to_num(a, posinf=1e20, neginf=-1e20)
-    # M batches per solver call: the synthetic batch repeated M times (every batch of the run is this same batch anyway)
-    d = {k: torch.from_numpy(big(batch[k])).to(dev).repeat(M, 1).contiguous() for k in ("x0", "lbx", "ubx", "p")}
     n_w = be.n_w
-    # one set of output buffers per handle in flight
-    outs = [dict(x=torch.empty((M * B, n_w), dtype=torch.float64, device=dev), f=torch.empty(M * B, dtype=torch.float64, device=dev),
-                 viol=torch.empty(M * B, dtype=torch.float64, device=dev), iters=torch.empty(M * B, dtype=torch.int32, device=dev),
-                 status=torch.empty(M * B, dtype=torch.int32, device=dev)) for _ in range(depth)]
+    big = lambda a: np.nan_to_num(a, posinf=1e20, neginf=-1e20)
+
+    # ---- problem instances: n_distinct fresh batches (steps cycle through them), resident in HBM ----
+    t0 = time.time()
+    host0 = None
+    d = {k: torch.empty((n_distinct * B, be.n_p if k == "p" else n_w), dtype=torch.float64, device=dev) for k in ("x0", "lbx", "ubx", "p")}
+    for s in range(n_distinct):
+        if args.same_batch and s > 0:
+            for k in d:
+                d[k][s * B:(s + 1) * B] = d[k][:B]
+            continue
+        batch = scenes.make_batch(B, N, batch_seed(world, rank, s), be.fk, randomize_sets=True, pool=pool)
+        hb = {k: big(batch[k]) for k in ("x0", "lbx", "ubx", "p")}
+        if s == 0:
+            host0 = hb
+        for k in d:
+            d[k][s * B:(s + 1) * B] = torch.from_numpy(hb[k]).to(dev)
+    if pool is not None:
+        pool.close(); pool.join()
+    t_gen = time.time() - t0
+
+    def make_outs(n):
+        return dict(x=torch.empty((n, n_w), dtype=torch.float64, device=dev), f=torch.empty(n, dtype=torch.float64, device=dev),
+                    viol=torch.empty(n, dtype=torch.float64, device=dev), iters=torch.empty(n, dtype=torch.int32, device=dev),
+                    status=torch.empty(n, dtype=torch.int32, device=dev))
+    outs = [make_outs(M * B) for _ in range(depth)]      # one set of output buffers per handle in flight
     gathered = torch.empty((world * M * B, n_w), dtype=torch.float64, device=dev) if world > 1 else None
     torch.cuda.synchronize(dev)      # inputs complete before any handle's own stream reads them
-    busy = [0] * depth               # batches in the solve in flight on each handle
-    kernel_ms = []
-
-    def retire(j):
-        """Wait for the solve in flight on handle j; all-gather its solutions (RCCL over xGMI)."""
-        if not busy[j]:
-            return
-        bes[j].wait()
-        m, busy[j] = busy[j], 0
-        kernel_ms.append(bes[j].last_kernel_ms() / m)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered[:world * m * B], outs[j]["x"][:m * B])
-            # the next solve on this handle overwrites outs[j]["x"]: the gather must have read it (only torch's current
-            # stream is waited for, the other handles' solver streams keep running)
-            torch.cuda.current_stream(dev).synchronize()
-
-    def run(nsteps):
-        """nsteps batches, M per solver call (the last call takes what is left)."""
-        calls, left = 0, nsteps
-        while left > 0:
-            m = min(M, left)
-            j = calls % depth
-            retire(j)
-            # start the next call when the solves in flight have left their bulk phase (most of their
-            # instances finished): the launch-latency-bound straggler tail of one solve then runs beside
-            # the throughput-bound bulk of the next
-            while any(busy[q] and bes[q].active() > args.gate * busy[q] * B for q in range(depth)):
-                time.sleep(0.0005)
-            o = outs[j]
-            bes[j].solve_dev_async(m * B, d["x0"].data_ptr(), d["lbx"].data_ptr(), d["ubx"].data_ptr(), d["p"].data_ptr(),
-                                   o["x"].data_ptr(), o["f"].data_ptr(), o["iters"].data_ptr(), o["status"].data_ptr(),
-                                   o["viol"].data_ptr())
-            busy[j] = m
-            calls += 1
-            left -= m
-        for j in range(depth):
-            retire((calls + j) % depth)
+    # the gather runs on torch's current stream; the next solve on the handle overwrites its x: wait for the read
+    stream = BatchStream([HipHandle(b_) for b_ in bes], outs, d, B, merge=M, gate=args.gate, dist=dist, gathered=gathered,
+                         sync_gather=lambda: torch.cuda.current_stream(dev).synchronize())
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -143,61 +186,113 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run(args.warmup)
+    stream.run(args.warmup)
     barrier()
-    kernel_ms.clear()
+    stream.kernel_ms.clear()
     t0 = time.perf_counter()
-    run(args.steps)
+    stream.run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    x, iters, status, viol = outs[0]["x"][:B], outs[0]["iters"][:B], outs[0]["status"][:B], outs[0]["viol"][:B]
+    event_ms = float(np.mean(stream.kernel_ms)) if stream.kernel_ms else None
 
-    it_np, st_np, viol_np = iters.cpu().numpy(), status.cpu().numpy(), viol.cpu().numpy()
+    # ---- untimed: the seed-of-step-0 batch alone on one handle -> solver statistics, parity sample, shard check ----
+    one = BatchStream([HipHandle(be)], [outs[0]], {k: v[:B] for k, v in d.items()}, B, merge=1, dist=dist,
+                      gathered=gathered, sync_gather=lambda: torch.cuda.current_stream(dev).synchronize())
+    if world > 1 or not (depth == 1 and M == 1 and n_distinct == 1):     # (profiling passes: the timed batch IS that solve)
+        one.run(1)
+    torch.cuda.synchronize(dev)
+    x = outs[0]["x"][:B]
+    it_np, st_np, viol_np = (outs[0][k][:B].cpu().numpy() for k in ("iters", "status", "viol"))
     ok = (st_np == 0) | (viol_np < 1e-4)            # the reference's acceptance test (BoundMPC.py:617)
+    shard_check = None
+    if world > 1:
+        # batch independence across the sharding: rank 0 solves the first 512 instances of two different shards
+        # alone and compares them bitwise with the rows the all-gather delivered
+        ns = min(512, B)
+        xg = gathered[:world * B].clone()
+        heads = {k: torch.empty((world * ns, v.shape[1]), dtype=torch.float64, device=dev) for k, v in d.items()}
+        for k, v in d.items():
+            dist.all_gather_into_tensor(heads[k], v[:ns].contiguous())
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            shard_check = {}
+            for r in sorted({0, world - 1}):
+                o = make_outs(ns)
+                torch.cuda.synchronize(dev)
+                HipHandle(be).solve_async(ns, {k: v[r * ns:(r + 1) * ns] for k, v in heads.items()}, o)
+                be.wait()
+                torch.cuda.synchronize(dev)
+                same = bool(torch.equal(o["x"], xg[r * B:r * B + ns]))
+                shard_check[f"shard{r}_first{ns}_bitwise_equal"] = same
+                if not same:
+                    raise SystemExit(f"bench.py: shard {r}: gathered solutions differ from a stand-alone solve")
+
     total_solves = world * B * args.steps
     value = total_solves / elapsed
-    # GPU time per batch: HIP events on the solver's own stream around one batch (with two batches in
-    # flight they overlap, so the per-batch share of the timed region is the honest denominator)
-    k_ms = float(np.mean(kernel_ms)) if depth == 1 else 1e3 * elapsed / args.steps
+    # GPU time per batch: with several calls in flight they overlap, so the per-batch share of the timed region is the
+    # honest denominator (event_ms_per_batch = HIP events around one call on its own stream / its batches)
+    k_ms = event_ms if depth == 1 else 1e3 * elapsed / args.steps
     ach_gbs = alg_bytes_per_solve(N) * B / (k_ms * 1e-3) / 1e9
     mean_it = float(it_np.mean())
     ach_tf = alg_flops_per_solve(N, mean_it) * B / (k_ms * 1e-3) / 1e12
 
-    # HBM bytes of one batch from the PMC passes of tools/profile_round.sh (separate rocprofv3 --pmc runs of
-    # one synchronous batch of this same workload; FETCH_SIZE raw, see the note) -- null for other sizes
+    # HBM bytes of one batch from the PMC passes of tools/profile_round.sh (separate rocprofv3 --pmc runs of one
+    # synchronous batch of this same workload), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
     traffic, traffic_note = None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj) and (B, N) == (BATCH_PER_GPU, HORIZON):
         t = json.load(open(tj))
-        traffic = t["fetch_bytes_raw"] + t["write_bytes"]
-        traffic_note = ("profiles/pmc_traffic.json: FETCH_SIZE (raw, 8-byte-per-lane loads are uncalibrated on gfx950, at most 2x low) "
-                        f"{t['fetch_bytes_raw'] / 1e9:.1f} GB + WRITE_SIZE {t['write_bytes'] / 1e9:.1f} GB per batch, all kernels")
+        traffic = 2.0 * t["fetch_bytes_raw"] + t["write_bytes"]
+        traffic_note = (f"profiles/pmc_traffic.json ({t.get('build', 'round-1 build')}): 2 x FETCH_SIZE {t['fetch_bytes_raw'] / 1e9:.1f} GB (gfx950 "
+                        f"correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE {t['write_bytes'] / 1e9:.1f} GB per batch, all kernels")
 
     out = {
         "metric": "MPC solves/sec (whole node), iiwa14 7-DOF, N=20",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: {B}-batch per GPU, randomized convex-set obstacles, N={N}, "
-                               "cold start, tol 1e-5, max_iter 100", "batch_per_gpu": B, "horizon": N,
-                   "sharding": "independent instances per rank + RCCL all-gather of x" if world > 1 else "single GPU",
+        "config": {"workload": (f"BASELINE configs[2]: {B}-batch, randomized convex-set obstacles, N={N}, cold start, tol 1e-5, "
+                                "max_iter 100; a fresh batch every step" if world == 1 else
+                                f"BASELINE configs[3]: one {world * B}-batch (seed 65536) cut into {world} contiguous shards of {B}, "
+                                f"randomized convex-set obstacles, N={N}, cold start, RCCL all-gather of x"),
+                   "value_is": "device-resident inputs, pipelined solver calls (see solver_handles_in_flight / batches_per_solver_call); "
+                               "value_single_batch and value_pcie_inclusive are the SURVEY 8(d) one-batch figures",
+                   "batch_per_gpu": B, "horizon": N, "distinct_batches": n_distinct,
+                   "sharding": "contiguous shards, no data-path collective, RCCL all-gather of x" if world > 1 else "single GPU",
                    "hess": int(be.opts.hess), "engine": int(be.opts.engine), "solver_handles_in_flight": depth,
                    "batches_per_solver_call": M, "batches_in_flight": depth * M},
         "solver": {"iters_mean": mean_it, "iters_p50": float(np.median(it_np)), "iters_p99": float(np.percentile(it_np, 99)),
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
-                   "accepted_frac": float(ok.mean()), "gen_s": t_gen},
+                   "accepted_frac": float(ok.mean()), "gen_s": t_gen, "stats_of": "the step-0 batch solved alone"},
         "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": "bmpc_k_ric (+ bmpc_k_eval, k_step, k_trial): one batch",
-                     "kernel_ms": k_ms, "event_ms_per_batch": float(np.mean(kernel_ms)), "alg_bytes_per_solve": alg_bytes_per_solve(N),
+                     "kernel_ms": k_ms, "event_ms_per_batch": event_ms, "alg_bytes_per_solve": alg_bytes_per_solve(N),
                      "note": "not HBM- or MFMA-bound: latency/VALU/LDS-bound small-matrix IP loop (DESIGN.md); "
                              "the meaningful limiter is FP64 VALU, reported in valu_fp64"},
         "valu_fp64": {"achieved": ach_tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": ach_tf / FP64_VEC_PEAK_TFLOPS, "alg_flops_per_solve": alg_flops_per_solve(N, mean_it)},
     }
+    if shard_check is not None:
+        out["shard_check"] = shard_check
+
+    if rank == 0 and not args.no_extra:
+        # SURVEY 8(d) as written: ONE batch at a time (depth 1, merge 1) ...
+        solo = BatchStream([HipHandle(be)], [outs[0]], {k: v[:B] for k, v in d.items()}, B, merge=1)     # no gather: rank 0 only
+        t1 = time.perf_counter()
+        solo.run(2)
+        torch.cuda.synchronize(dev)
+        out["value_single_batch"] = 2 * B / (time.perf_counter() - t1)
+        # ... and through the host-pointer entry: H2D of x0, lbx, ubx, p and D2H of x, f, iters, status, viol inside the time
+        be.solve_batch(host0["x0"][:64], host0["lbx"][:64], host0["ubx"][:64], host0["p"][:64])     # staging buffers
+        t1 = time.perf_counter()
+        rh = be.solve_batch(host0["x0"], host0["lbx"], host0["ubx"], host0["p"])
+        out["value_pcie_inclusive"] = B / (time.perf_counter() - t1)
+        out["pcie_note"] = "bmpc_solve with pageable host arrays: 3 x 58 MB + 57 MB H2D, 58 MB D2H per batch inside the timed call"
+        assert np.array_equal(rh["x"], x.cpu().numpy()), "host-pointer and device-pointer entries disagree"
 
     if rank == 0 and not args.no_cpu_baseline:
         import oracle_lib as O               # cpu_baseline leg only
@@ -206,18 +301,21 @@ def main():
         ns = min(B, 128 * nthr)         # ~12 s of host work at ~670 solves/s on 64 threads
         hess = int(be.opts.hess)
         t0 = time.perf_counter()
-        ro = O.solve_batch(N, batch["x0"][:ns], batch["lbx"][:ns], batch["ubx"][:ns], batch["p"][:ns],
-                           nthreads=nthr, hess=hess)
+        ro = O.solve_batch(N, host0["x0"][:ns], host0["lbx"][:ns], host0["ubx"][:ns], host0["p"][:ns], nthreads=nthr, hess=hess)
         tc = time.perf_counter() - t0
         x_gpu = x[:ns].cpu().numpy()
         both = (ro["status"] == 0) & (st_np[:ns] == 0)
+        same_it = both & (ro["iters"] == it_np[:ns])
         out["cpu_baseline"] = {
             "value": ns / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
-            "sample": f"first {ns} instances of the same batch, oracle/bmpc_solve.c (same algorithm, FP64, -O3 -march=x86-64-v3, "
+            "sample": f"first {ns} instances of the step-0 batch, oracle/bmpc_solve.c (same algorithm, FP64, -O3 -march=x86-64-v3, "
                       f"OpenMP over instances) on {nthr} host threads in {tc:.1f} s; the reference's CasADi+IPOPT "
                       "cannot run here (no wheel, no network)",
             "iters_mean": float(ro["iters"].mean()),
-            "max_abs_dx_vs_gpu": float(np.abs(ro["x"][both][:, :40 * N] - x_gpu[both][:, :40 * N]).max()) if both.any() else None,
+            "status_equal_frac": float((ro["status"] == st_np[:ns]).mean()),
+            "iters_equal_frac_of_both_converged": float(same_it.sum() / max(1, both.sum())),
+            "max_abs_dx_vs_gpu_by_block": block_diffs(N, ro["x"][both], x_gpu[both]),
+            "max_abs_dx_vs_gpu_by_block_same_iters": block_diffs(N, ro["x"][same_it], x_gpu[same_it]),
         }
     if rank == 0:
         print(json.dumps(out))

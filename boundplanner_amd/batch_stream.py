@@ -1,0 +1,88 @@
+"""A stream of independent batches through a few solver handles, with the all-gather of the solutions.
+
+This is the schedule `bench.py` runs (BASELINE.json configs[2]/[3]): the instances of a batch are
+independent, so every rank (one process per GPU) solves its own contiguous shard and there is NO collective on the
+data path; the only exchange is the all-gather of the solution block `x` that `north_star` asks for (RCCL over xGMI on
+GPUs, gloo in the CPU tests).  Several handles are kept in flight so that the launch-bound straggler tail of one solver
+call overlaps the bulk of the next.
+
+The handles are duck-typed (`solve_async(n, inputs, outputs)`, `wait()`, `active()`, `last_kernel_ms()`), so the same
+code runs with the HIP backend (`HipHandle`) and with an injected solver in `tests/test_distributed.py`.
+"""
+import time
+
+
+class HipHandle:
+    """Adapter of one `HipBoundMPC` handle: device tensors in, device tensors out, asynchronous on the handle's stream."""
+
+    def __init__(self, backend):
+        self.be = backend
+
+    def solve_async(self, n, d, o):
+        self.be.solve_dev_async(n, d["x0"].data_ptr(), d["lbx"].data_ptr(), d["ubx"].data_ptr(), d["p"].data_ptr(),
+                                o["x"].data_ptr(), o["f"].data_ptr(), o["iters"].data_ptr(), o["status"].data_ptr(),
+                                o["viol"].data_ptr())
+
+    def wait(self):
+        self.be.wait()
+
+    def active(self):
+        return self.be.active()
+
+    def last_kernel_ms(self):
+        return self.be.last_kernel_ms()
+
+
+class BatchStream:
+    """`handles`: solver handles used round-robin; `outs[j]`: output tensors of handle j (x [M*B, n_w], f, viol, iters,
+    status [M*B]); `inputs`: tensors [nd*B, .] holding `nd` distinct batches back to back (nd a multiple of `merge`);
+    `gathered`: [world*M*B, n_w] or None; `dist`: initialised torch.distributed module or None;
+    `sync_gather`: callable that makes the gather's read of `outs[j]["x"]` complete (the next solve on the handle
+    overwrites it)."""
+
+    def __init__(self, handles, outs, inputs, B, merge=1, gate=1.0, dist=None, gathered=None, sync_gather=None):
+        self.h, self.outs, self.inputs, self.B = handles, outs, inputs, B
+        self.depth, self.M, self.gate = len(handles), merge, gate
+        self.dist, self.gathered, self.sync_gather = dist, gathered, sync_gather
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.nd = inputs["x0"].shape[0] // B
+        assert self.nd % merge == 0 or self.nd == 1, "distinct batches must fill whole solver calls"
+        self.busy = [0] * self.depth          # batches of the solve in flight on each handle
+        self.kernel_ms = []                   # HIP-event time of each retired call / its batches
+        self.calls = 0
+
+    def retire(self, j):
+        """Wait for the solve in flight on handle j; all-gather its solutions."""
+        if not self.busy[j]:
+            return
+        self.h[j].wait()
+        m, self.busy[j] = self.busy[j], 0
+        self.kernel_ms.append(self.h[j].last_kernel_ms() / m)
+        if self.world > 1:
+            n = m * self.B
+            self.dist.all_gather_into_tensor(self.gathered[:self.world * n], self.outs[j]["x"][:n])
+            if self.sync_gather is not None:
+                self.sync_gather()
+
+    def run(self, nbatches):
+        """`nbatches` batches, `merge` per solver call (the last call takes what is left)."""
+        left = nbatches
+        while left > 0:
+            m = min(self.M, left)
+            j = self.calls % self.depth
+            self.retire(j)
+            # start the next call when the solves in flight have left their bulk phase (most of their instances
+            # finished): the launch-latency-bound tail of one solve then runs beside the throughput-bound bulk of the next
+            while any(self.busy[q] and self.h[q].active() > self.gate * self.busy[q] * self.B for q in range(self.depth)):
+                time.sleep(0.0005)
+            s = (self.calls * self.M) % self.nd if self.nd > 1 else 0
+            d = {k: v[s * self.B:(s + m) * self.B] for k, v in self.inputs.items()}
+            self.h[j].solve_async(m * self.B, d, self.outs[j])
+            self.busy[j] = m
+            self.calls += 1
+            left -= m
+        self.drain()
+
+    def drain(self):
+        for q in range(self.depth):
+            self.retire((self.calls + q) % self.depth)

@@ -57,6 +57,8 @@ struct bmpc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
+    std::atomic<int> n_loops{0};   // device loops borrowing this handle (bmpc_loop_create / bmpc_loop_destroy)
+    bool destroy_pending = false;  // bmpc_destroy called while loops were alive: the last loop frees the handle
     std::string err;
 };
 
@@ -121,9 +123,18 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     return 0;
 }
 
+// device loops (bmpc_loop.hip) register with the handle they borrow, so that destroying the handle first is safe
+extern "C" void bmpc_handle_retain(bmpc_handle* h) { if (h) h->n_loops.fetch_add(1); }
+extern "C" void bmpc_handle_release(bmpc_handle* h) {
+    if (!h) return;
+    if (h->n_loops.fetch_sub(1) == 1 && h->destroy_pending) { h->destroy_pending = false; bmpc_destroy(h); }
+}
+
 extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (!h) return;
+    if (h->n_loops.load() > 0) { h->destroy_pending = true; return; }     // deferred until the last loop is gone
     if (h->worker.joinable()) h->worker.join();
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     double* bufs[] = {h->d_x0, h->d_lbx, h->d_ubx, h->d_p, h->d_x, h->d_g, h->d_f, h->d_viol, h->d_ws};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->d_iters) (void)hipFree(h->d_iters);
@@ -241,6 +252,9 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     h->last_steps = steps;
     HIPCHK(h, bmpc_pipe_launch_out(&A, st));
     HIPCHK(h, hipEventRecord(h->ev1, st));
+    // the outputs are complete and the per-handle workspace is free when the call returns: a following call on another
+    // stream must not start k_init on the workspace k_out is still reading (the loop above synchronised anyway)
+    HIPCHK(h, hipStreamSynchronize(st));
     return 0;
 }
 
@@ -267,6 +281,7 @@ static int launch(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx
                   : (wpi == 2) ? bmpc_launch_solve_nt128(&A, nblocks, st) : bmpc_launch_solve_nt64(&A, nblocks, st);
     HIPCHK(h, le);
     HIPCHK(h, hipEventRecord(h->ev1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
     return 0;
 }
 
@@ -277,6 +292,9 @@ extern "C" int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const d
         if (h) h->err = "bmpc_solve_dev: null argument";
         return 1;
     }
+    int wrc = bmpc_wait(h);        // an asynchronous solve in flight owns the workspace
+    if (wrc) return wrc;
+    if (B == 0) return 0;
     HIPCHK(h, hipSetDevice(h->o.device));
     return launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, (hipStream_t)stream);
 }
@@ -306,6 +324,7 @@ extern "C" int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, c
     }
     int rc = bmpc_wait(h);
     if (rc) return rc;
+    if (B == 0) return 0;
     h->n_active.store(B);
     h->worker = std::thread([=]() {
         if (hipSetDevice(h->o.device) != hipSuccess) { h->err = "hipSetDevice failed in the worker"; h->worker_rc = 2; return; }
@@ -347,8 +366,10 @@ extern "C" int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double*
         return 1;
     }
     if (B == 0) return 0;
+    int rc = bmpc_wait(h);         // an asynchronous solve in flight owns the workspace
+    if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->o.device));
-    int rc = ensure_cap(h, B, g != nullptr);
+    rc = ensure_cap(h, B, g != nullptr);
     if (rc) return rc;
     size_t nw = (size_t)B * h->n_w * sizeof(double);
     hipStream_t st = h->stream;
@@ -386,24 +407,30 @@ extern "C" int bmpc_fk(bmpc_handle* h, int B, const double* q, const double* dq,
     if (B == 0) return 0;
     HIPCHK(h, hipSetDevice(h->o.device));
     double *d_q = nullptr, *d_dq = nullptr, *d_out = nullptr;
-    size_t per = 3 + 9 + 18 + 42 + 42;
-    HIPCHK(h, hipMalloc((void**)&d_q, (size_t)B * 7 * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&d_dq, (size_t)B * 7 * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&d_out, (size_t)B * per * sizeof(double)));
-    HIPCHK(h, hipMemcpy(d_q, q, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice));
-    if (dq) HIPCHK(h, hipMemcpy(d_dq, dq, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice));
-    else HIPCHK(h, hipMemset(d_dq, 0, (size_t)B * 7 * sizeof(double)));
-    double* o_pos = d_out; double* o_rot = o_pos + (size_t)B * 3; double* o_col = o_rot + (size_t)B * 9;
-    double* o_jac = o_col + (size_t)B * 18; double* o_dv = o_jac + (size_t)B * 42;
-    HIPCHK(h, bmpc_launch_fk(B, h->d_rc, d_q, d_dq, o_pos, o_rot, o_col, o_jac, o_dv, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (ee_pos) HIPCHK(h, hipMemcpy(ee_pos, o_pos, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (ee_rot) HIPCHK(h, hipMemcpy(ee_rot, o_rot, (size_t)B * 9 * sizeof(double), hipMemcpyDeviceToHost));
-    if (col_pts) HIPCHK(h, hipMemcpy(col_pts, o_col, (size_t)B * 18 * sizeof(double), hipMemcpyDeviceToHost));
-    if (jac) HIPCHK(h, hipMemcpy(jac, o_jac, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
-    if (dvdq) HIPCHK(h, hipMemcpy(dvdq, o_dv, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d_q); (void)hipFree(d_dq); (void)hipFree(d_out);
-    return 0;
+    const size_t per = 3 + 9 + 18 + 42 + 42;
+    auto body = [&]() -> int {
+        HIPCHK(h, hipMalloc((void**)&d_q, (size_t)B * 7 * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&d_dq, (size_t)B * 7 * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&d_out, (size_t)B * per * sizeof(double)));
+        HIPCHK(h, hipMemcpy(d_q, q, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice));
+        if (dq) HIPCHK(h, hipMemcpy(d_dq, dq, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice));
+        else HIPCHK(h, hipMemset(d_dq, 0, (size_t)B * 7 * sizeof(double)));
+        double* o_pos = d_out; double* o_rot = o_pos + (size_t)B * 3; double* o_col = o_rot + (size_t)B * 9;
+        double* o_jac = o_col + (size_t)B * 18; double* o_dv = o_jac + (size_t)B * 42;
+        HIPCHK(h, bmpc_launch_fk(B, h->d_rc, d_q, d_dq, o_pos, o_rot, o_col, o_jac, o_dv, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (ee_pos) HIPCHK(h, hipMemcpy(ee_pos, o_pos, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (ee_rot) HIPCHK(h, hipMemcpy(ee_rot, o_rot, (size_t)B * 9 * sizeof(double), hipMemcpyDeviceToHost));
+        if (col_pts) HIPCHK(h, hipMemcpy(col_pts, o_col, (size_t)B * 18 * sizeof(double), hipMemcpyDeviceToHost));
+        if (jac) HIPCHK(h, hipMemcpy(jac, o_jac, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
+        if (dvdq) HIPCHK(h, hipMemcpy(dvdq, o_dv, (size_t)B * 42 * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    const int rc = body();          // temporaries are freed on the error paths too
+    if (d_q) (void)hipFree(d_q);
+    if (d_dq) (void)hipFree(d_dq);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
 }
 
 // diagnostic: per-phase cycle sums accumulated by a -DBMPC_PROFILE build (zeros otherwise)

@@ -16,6 +16,9 @@
 
 using namespace bmpc;
 
+extern "C" void bmpc_handle_retain(bmpc_handle* h);
+extern "C" void bmpc_handle_release(bmpc_handle* h);
+
 __global__ __launch_bounds__(256) void bmpc_loop_k_bounds(int R, int N, double* lbx, double* ubx) {
     const int n_w = 44 * N + 6;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -111,6 +114,7 @@ extern "C" const char* bmpc_loop_last_error(const bmpc_loop* L) { return L ? L->
 
 extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
     if (!L) return;
+    if (L->st) { (void)hipSetDevice(L->dev); (void)hipStreamSynchronize(L->st); }     // nothing of the loop still in flight
     double* bufs[] = {L->d_S, L->d_prev, L->d_x0, L->d_lbx, L->d_ubx, L->d_p, L->d_x, L->d_f, L->d_viol, L->d_log};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (L->d_iters) (void)hipFree(L->d_iters);
@@ -121,6 +125,7 @@ extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
     if (L->d_colres) (void)hipFree(L->d_colres);
     if (L->e0) (void)hipEventDestroy(L->e0);
     if (L->e1) (void)hipEventDestroy(L->e1);
+    if (L->h) bmpc_handle_release(L->h);     // a bmpc_destroy deferred because of this loop runs now
     delete L;
 }
 
@@ -128,7 +133,7 @@ extern "C" int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out) {
     if (!h || !out || R <= 0) return 1;
     bmpc_loop* L = new bmpc_loop();
     *out = L;
-    L->h = h; L->R = R;
+    L->R = R;
     bmpc_opts o;
     if (bmpc_get_opts(h, &o) != 0) { L->err = "bmpc_get_opts failed"; return 1; }
     if (o.N > LP_NMAX) { L->err = "horizon too long for the device loop"; return 1; }
@@ -152,6 +157,8 @@ extern "C" int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out) {
     LCHK(L, hipMemset(L->d_viol, 0, (size_t)R * sizeof(double)));
     LCHK(L, hipMemset(L->d_iters, 0, (size_t)R * sizeof(int)));
     LCHK(L, hipMemset(L->d_status, 0, (size_t)R * sizeof(int)));
+    L->h = h;
+    bmpc_handle_retain(h);                    // the handle outlives the loop even if the caller destroys it first
     L->st = (hipStream_t)bmpc_stream(h);      // the handle's stream: one stream (one hardware queue) per solver handle
     LCHK(L, hipEventCreate(&L->e0));
     LCHK(L, hipEventCreate(&L->e1));

@@ -47,24 +47,59 @@ def sample_start_goal(rng, fk_batch, n):
     return np.array(qs), np.array(qg)
 
 
-def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1):
-    """Returns dict with x0, lbx, ubx, p ([B, n] float64, row-major per instance) + the state
-    needed to drive closed loops."""
-    rng = np.random.default_rng(seed)
+_ERB = np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180
+_WS_LO, _WS_HI = [-1.0, -1.0, 0.0], [1.0, 1.0, 1.2]
+
+
+def _build_instance(args):
+    """Deterministic part of one instance (no random draws, no kinematics calls): the reference's seeding sequence
+    BoundMPC() -> update() -> step() preparation on a 2-via-point path.  Runs in a worker process when make_batch is
+    given a pool.  Returns (x0, lbx, ubx, p, mpc)."""
+    N, dt, q0, p0, p1, rot0, rot1, col0, a_ee, b_ee, aj_extra, bj_extra, keep_mpc = args
     base = get_default_params()
     prm = Params(n=N, dt=dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    sets = normalize_set_size([[a_ee, b_ee]], 15)
+    mpc = BoundMPC([p0[:3].copy(), p0[:3].copy()], [rot0.copy(), rot0.copy()],
+                   [np.array([1.0, 0.0, 0.0])], [np.array([1.0, 0.0, 0.0])], [_ERB.copy()],
+                   [np.zeros((15, 3))], [np.ones(15)], [], p0=p0, params=prm)
+    mpc.update([p0[:3].copy(), p1.copy()], [rot0.copy(), rot1.copy()],
+               [np.array([0.0, 0.0, 1.0])], [np.array([0.0, 0.0, 1.0])], [_ERB.copy()],
+               [sets[0][0]], [sets[0][1]], [], np.zeros(6), p0=p0, params=prm)
+    w0, lbx, ubx, p, _ = mpc.prepare(q0, np.zeros(7), np.zeros(7), p0, np.zeros(6),
+                                     np.zeros(7), q0, col_pts0=col0, col_ptsf=col0)
+    if aj_extra is not None:
+        # extra random halfspaces on the 6 collision sets, appended after the 6 box rows
+        aj = p[515:785].reshape(6, 3, 15).transpose(0, 2, 1).copy()   # [pt][row][c]
+        bj = p[785:875].reshape(15, 6).T.copy()                       # [pt][row]
+        for i in range(6):
+            k = len(bj_extra[i])
+            aj[i, 6:6 + k] = aj_extra[i]
+            bj[i, 6:6 + k] = bj_extra[i]
+        p[515:785] = aj.transpose(0, 2, 1).reshape(-1)
+        p[785:875] = bj.T.reshape(-1)
+    return w0, lbx, ubx, p, (mpc if keep_mpc else None)
+
+
+def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1, pool=None):
+    """Returns dict with x0, lbx, ubx, p ([B, n] float64, row-major per instance) + the state
+    needed to drive closed loops.  All random draws happen here, in instance order, from one PCG64 stream; the
+    per-instance host construction (1.3 ms of Python each) is deterministic given the draws and is mapped over
+    `pool` (a multiprocessing pool of processes that never touch the GPU) when one is given -- same result, and
+    `mpcs` is then not returned."""
+    rng = np.random.default_rng(seed)
     q_start, q_goal = sample_start_goal(rng, fk_batch, B)
     fs, fg = fk_batch(q_start), fk_batch(q_goal)
     n_w = 44 * N + 6
     out = {k: np.zeros((B, n_w)) for k in ("x0", "lbx", "ubx")}
     out["p"] = np.zeros((B, 875))
     out["q_start"], out["q_goal"] = q_start, q_goal
-    out["mpcs"] = []
-    ws_lo, ws_hi = [-1.0, -1.0, 0.0], [1.0, 1.0, 1.2]
+    jobs = []
     for b in range(B):
         p0 = np.concatenate((fs["ee_pos"][b], R.from_matrix(fs["ee_rot"][b]).as_rotvec()))
         p1 = fg["ee_pos"][b]
-        a_ee, b_ee = _box_set(ws_lo, ws_hi)
+        col0 = fs["col_pts"][b]
+        a_ee, b_ee = _box_set(_WS_LO, _WS_HI)
+        aj_extra = bj_extra = None
         if randomize_sets:
             k = rng.integers(3, 10)
             rows_a, rows_b = [], []
@@ -75,33 +110,24 @@ def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1):
                 if a @ p1 <= bb:       # both path ends must satisfy the row
                     rows_a.append(a); rows_b.append(bb)
             a_ee = np.vstack((a_ee, rows_a)); b_ee = np.concatenate((b_ee, rows_b))
-        sets = normalize_set_size([[a_ee, b_ee]], 15)
-        mpc = BoundMPC([p0[:3].copy(), p0[:3].copy()],
-                       [fs["ee_rot"][b].copy(), fs["ee_rot"][b].copy()],
-                       [np.array([1.0, 0.0, 0.0])], [np.array([1.0, 0.0, 0.0])],
-                       [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180],
-                       [np.zeros((15, 3))], [np.ones(15)], [], p0=p0, params=prm)
-        mpc.update([p0[:3].copy(), p1.copy()], [fs["ee_rot"][b].copy(), fg["ee_rot"][b].copy()],
-                   [np.array([0.0, 0.0, 1.0])], [np.array([0.0, 0.0, 1.0])],
-                   [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180],
-                   [sets[0][0]], [sets[0][1]], [], np.zeros(6), p0=p0, params=prm)
-        col0 = fs["col_pts"][b]
-        w0, lbx, ubx, p, _ = mpc.prepare(q_start[b], np.zeros(7), np.zeros(7), p0, np.zeros(6),
-                                         np.zeros(7), q_start[b], col_pts0=col0, col_ptsf=col0)
-        if randomize_sets:
-            # extra random halfspaces on the 6 collision sets, appended after the 6 box rows
-            aj = p[515:785].reshape(6, 3, 15).transpose(0, 2, 1).copy()   # [pt][row][c]
-            bj = p[785:875].reshape(15, 6).T.copy()                       # [pt][row]
+            aj_extra, bj_extra = [], []
             for i in range(6):
                 k = rng.integers(3, 10)
-                for r in range(6, 6 + k):
+                ra, rb = np.zeros((k, 3)), np.zeros(k)
+                for r in range(k):
                     a = _rand_unit(rng)
-                    aj[i, r] = a
-                    bj[i, r] = a @ col0[i] + rng.uniform(0.05, 0.4) - COL_JOINT_SIZES[i]
-            p[515:785] = aj.transpose(0, 2, 1).reshape(-1)
-            p[785:875] = bj.T.reshape(-1)
+                    ra[r] = a
+                    rb[r] = a @ col0[i] + rng.uniform(0.05, 0.4) - COL_JOINT_SIZES[i]
+                aj_extra.append(ra); bj_extra.append(rb)
+        jobs.append((N, dt, q_start[b], p0, p1, fs["ee_rot"][b], fg["ee_rot"][b], col0, a_ee, b_ee, aj_extra, bj_extra,
+                     pool is None))
+    res = map(_build_instance, jobs) if pool is None else pool.imap(_build_instance, jobs, chunksize=64)
+    mpcs = []
+    for b, (w0, lbx, ubx, p, mpc) in enumerate(res):
         out["x0"][b], out["lbx"][b], out["ubx"][b], out["p"][b] = w0, lbx, ubx, p
-        out["mpcs"].append(mpc)
+        mpcs.append(mpc)
+    if pool is None:
+        out["mpcs"] = mpcs
     return out
 
 

@@ -76,7 +76,9 @@ int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double* lbx, const
 
 /* Same with DEVICE pointers; all work is enqueued on `stream` (a hipStream_t).  The call returns
  * when the batch is solved: the interior-point iteration count is data dependent, so the host
- * polls the number of unfinished instances between bursts of launches (engine 0). */
+ * polls the number of unfinished instances between bursts of launches (engine 0).  On return `stream`
+ * has been synchronised: the outputs are complete and the handle's workspace is free for the next call
+ * (on any stream).  A solve started with bmpc_solve_dev_async is waited for first. */
 int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
                    const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
                    int* d_iters, int* d_status, double* d_viol, void* stream);
@@ -117,8 +119,9 @@ int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16);
  * Per-step collision sets (ConvexSetFinder.find_set_collision_avoidance, ConvexSetFinder.py:309-375) are computed on the
  * device too: boxes around the collision points, plus separating halfspaces of the scene obstacles set with
  * bmpc_loop_set_obstacles (shared by all rollouts of the loop).
- * All pointers below are HOST pointers.  The loop borrows the handle's solver: do not use the handle
- * for other solves while a loop call is running. */
+ * All pointers below are HOST pointers.  The loop borrows the handle's solver and stream: do not use the handle
+ * for other solves while a loop call is running.  The loop keeps the handle alive: a bmpc_destroy(handle)
+ * issued while loops exist is deferred until the last bmpc_loop_destroy. */
 typedef struct bmpc_loop bmpc_loop;
 int bmpc_loop_state_doubles(void);
 int bmpc_loop_log_doubles(void);
