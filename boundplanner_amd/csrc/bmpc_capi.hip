@@ -25,6 +25,7 @@ extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* 
 extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_out(const PipeArgsH* A, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_mult(const PipeArgsH* A, hipStream_t st);
 extern "C" void bmpc_pipe_build_table(int* tbl);
 extern "C" size_t bmpc_pipe_state_bytes(void);
 
@@ -44,6 +45,10 @@ struct bmpc_handle {
     int* d_pipe_tbl = nullptr;     // scatter table of the stage record
     int* h_cnt = nullptr;          // pinned host copy of the counters
     int last_steps = 0;
+    PipeArgsH last_args;           // arguments of the most recent pipeline solve (its final iterate stays in the workspace)
+    bool last_valid = false;
+    double *d_lam_g = nullptr, *d_lam_x = nullptr;   // staging of the multipliers for the host-pointer entry
+    int cap_lam = 0;
     // asynchronous solves: one in flight per handle, driven by a worker thread on the handle's stream
     std::thread worker;
     int worker_rc = 0;
@@ -146,6 +151,8 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (h->d_pipe_st) (void)hipFree(h->d_pipe_st);
     if (h->d_pipe_lists) (void)hipFree(h->d_pipe_lists);
     if (h->d_pipe_tbl) (void)hipFree(h->d_pipe_tbl);
+    if (h->d_lam_g) (void)hipFree(h->d_lam_g);
+    if (h->d_lam_x) (void)hipFree(h->d_lam_x);
     if (h->h_cnt) (void)hipHostFree(h->h_cnt);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -231,6 +238,8 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.L.trial_next = L + 4 * (size_t)cap; A.L.cnt = L + 5 * (size_t)cap;
     A.tbl = h->d_pipe_tbl;
     A.prof = h->d_prof;
+    A.lam_g = nullptr; A.lam_x = nullptr;
+    h->last_valid = false;
     int cnt0[8] = {B, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(A.L.cnt, cnt0, sizeof cnt0, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipEventRecord(h->ev0, st));
@@ -255,6 +264,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     // the outputs are complete and the per-handle workspace is free when the call returns: a following call on another
     // stream must not start k_init on the workspace k_out is still reading (the loop above synchronised anyway)
     HIPCHK(h, hipStreamSynchronize(st));
+    h->last_args = A; h->last_valid = true;
     return 0;
 }
 
@@ -335,6 +345,23 @@ extern "C" int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, c
     return 0;
 }
 
+// Multipliers of the most recent solve on this handle (pipeline engine): its final iterate and row multipliers are still
+// in the workspace.  d_lam_g [B][n_g], d_lam_x [B][n_w]: device pointers; enqueued on `stream` and waited for.
+extern "C" int bmpc_multipliers_dev(bmpc_handle* h, int B, double* d_lam_g, double* d_lam_x, void* stream) {
+    if (!h || !d_lam_g || !d_lam_x) { if (h) h->err = "bmpc_multipliers_dev: null argument"; return 1; }
+    int rc = bmpc_wait(h);
+    if (rc) return rc;
+    if (h->o.engine != 0) { h->err = "bmpc_multipliers_dev: only the pipeline engine (engine 0) keeps the final iterate"; return 1; }
+    if (!h->last_valid || h->last_args.B != B) { h->err = "bmpc_multipliers_dev: no finished solve of this batch size on the handle"; return 1; }
+    HIPCHK(h, hipSetDevice(h->o.device));
+    PipeArgsH A = h->last_args;
+    A.lam_g = d_lam_g; A.lam_x = d_lam_x;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(h, bmpc_pipe_launch_mult(&A, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return 0;
+}
+
 static int ensure_cap(bmpc_handle* h, int B, bool want_g) {
     if (B <= h->cap && (!want_g || h->cap_g)) return 0;
     int cap = B > h->cap ? B : h->cap;
@@ -388,8 +415,20 @@ extern "C" int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double*
     HIPCHK(h, hipMemcpyAsync(status, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-    if (lam_g) memset(lam_g, 0, (size_t)B * h->n_g * sizeof(double));
-    if (lam_x) memset(lam_x, 0, (size_t)B * h->n_w * sizeof(double));
+    if (lam_g || lam_x) {
+        if (B > h->cap_lam) {
+            if (h->d_lam_g) { (void)hipFree(h->d_lam_g); h->d_lam_g = nullptr; }
+            if (h->d_lam_x) { (void)hipFree(h->d_lam_x); h->d_lam_x = nullptr; }
+            h->cap_lam = 0;
+            HIPCHK(h, hipMalloc((void**)&h->d_lam_g, (size_t)B * h->n_g * sizeof(double)));
+            HIPCHK(h, hipMalloc((void**)&h->d_lam_x, (size_t)B * h->n_w * sizeof(double)));
+            h->cap_lam = B;
+        }
+        rc = bmpc_multipliers_dev(h, B, h->d_lam_g, h->d_lam_x, st);
+        if (rc) return rc;
+        if (lam_g) HIPCHK(h, hipMemcpy(lam_g, h->d_lam_g, (size_t)B * h->n_g * sizeof(double), hipMemcpyDeviceToHost));
+        if (lam_x) HIPCHK(h, hipMemcpy(lam_x, h->d_lam_x, (size_t)B * h->n_w * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

@@ -1178,4 +1178,151 @@ BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     A.part[PT_F1 * A.NP + pi] = V.viol;      // reduced per instance by k_fin
 }
 
+// ------------------------------------------------------------------------------------------
+// k_mult: multipliers of the full-space NLP in the reference's layout and CasADi's sign convention
+// (grad f + J_g^T lam_g + lam_x = 0; BoundMPC.py:638-645 reads sol["lam_g"], sol["lam_x"]).  Thread per pair, at the
+// final point of the instance: inequality rows of g and bound rows of x get the row multipliers z of the barrier method;
+// the equality rows (35 per stage transition, casadi_ocp_formulation.py:145-164) follow from stationarity in the one
+// variable each of them carries a -1 on -- an adjoint sweep backwards over the stages (k_mult_sweep) for which this
+// kernel leaves the stage-local terms in a per-pair record.  Algebra: oracle/bmpc_solve.c recover_multipliers.
+// ------------------------------------------------------------------------------------------
+struct MultVisitor {
+    const PipeArgs* A; size_t pi; int N, k;
+    GD lg;               // inequality rows of this stage in lam_g
+    GD lx;               // lam_x of the instance
+    double bz[6], Fc[6][3], sPS, sRS, sD[6], lxq[7], lxdq[7], lxddq[7], znn[4], z1[2];
+    BMPC_INL double zrow(int s) const { return A->z[(size_t)s * A->NP + pi]; }
+    BMPC_INL void skip(int s) {
+        if (s >= S_EE && s < (k == N - 1 ? S_END : S_TSET)) lg[s - S_EE] = 0.0;
+    }
+    BMPC_INL void diag(int s, int pos, double coef, double) {
+        const double z = zrow(s);
+        if (s < S_NONNEG) {
+            const int blk = s / 14, jj = (s / 2) % 7;
+            lx[(size_t)blk * 7 * N + (size_t)jj * N + k] += coef * z;       // both bound rows of a variable add up
+            if (blk == 0) lxq[jj] += coef * z; else if (blk == 1) lxdq[jj] += coef * z; else if (blk == 2) lxddq[jj] += coef * z;
+        } else if (s < S_RS1) {
+            const int m = s - S_NONNEG;                                          // rs, drs, ps, dps >= 0
+            lx[(size_t)(40 + m) * N + 6 + k] = -z;
+            znn[m] = z;
+        } else lx[(size_t)40 * N + (s - S_D1)] = -z;                              // dslacks >= 0 (k == 1 only)
+    }
+    BMPC_INL void zdiag(int s, int, double, double) { z1[s - S_RS1] = zrow(s); }
+    BMPC_INL void pose(int s, const double* a, int sel, double) {
+        const double z = zrow(s);
+        const bool lower = (s >= S_ROTL && s < S_COL) || (s >= S_TROTL);
+        lg[s - S_EE] = lower ? -z : z;
+        BMPC_UNROLL
+        for (int c = 0; c < 6; c++) bz[c] += z * a[c];
+        if (sel == 1) sPS -= z; else if (sel == 2) sRS -= z; else if (sel == 3) sD[5] -= z;
+    }
+    template <int C> BMPC_INL void point_begin() {}
+    template <int C> BMPC_INL void point(int s, const double* a, double) {
+        const double z = zrow(s);
+        lg[s - S_EE] = z;
+        Fc[C][0] += z * a[0]; Fc[C][1] += z * a[1]; Fc[C][2] += z * a[2];
+        sD[C] -= z;
+    }
+    template <int C> BMPC_INL void point_end() {}
+};
+
+template <int C>
+BMPC_INL void point_forces_to_q(const KinT& K, const double Fc[6][3], double* cq) {
+    if constexpr (C < 6) {
+        constexpr int nj = PointNJ<C>::value;
+        const double* pc = kin_point<C>(K);
+        BMPC_UNROLL
+        for (int i = 0; i < nj; i++) {
+            double r[3] = {pc[0] - K.o[i][0], pc[1] - K.o[i][1], pc[2] - K.o[i][2]}, c[3];
+            cross3r(K.zx[i], r, c);
+            cq[i] += c[0] * Fc[C][0] + c[1] * Fc[C][1] + c[2] * Fc[C][2];
+        }
+        point_forces_to_q<C + 1>(K, Fc, cq);
+    }
+}
+
+BMPC_DEV void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
+    const int count = A.B, N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    PairMap m;
+    {
+        const int S_ = N - 1, ipw = ipw_of(N);
+        int li = lane / S_, kk = lane - li * S_;
+        int e = wave * ipw + li;
+        m.valid = (li < ipw) && (e < count);
+        if (!m.valid) { e = wave * ipw; kk = 0; li = 0; }
+        m.b = e; m.k = kk + 1; m.li = li; m.pi = pair_of(A, m.b, m.k);
+    }
+    PGP pg = stage_params(A, (GCI)nullptr, count, wave, lane, m, lds_par);
+    if (!m.valid) return;
+    const int b = m.b, k = m.k, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
+    const bool term = (k == N - 1);
+    const size_t pi = m.pi;
+    const DynC dc = make_dync(A.o.dt);
+    GCD lbx = A.lbx + (size_t)b * n_w;
+    GCD ubx = A.ubx + (size_t)b * n_w;
+    PGP wts = pg + P_W;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    StagePoint S;
+    load_zeta(A.zeta_t, A.NP, pi, S.zeta);     // the final point of the instance
+    stage_point(A, pg, iw0, k, dc, S);
+    double G[6][7], g12[12];
+    kin_G(S.K, S.Jl, S.y + Z_DQ, G);
+    cost_grad12(pg, S.C, term, g12);
+    GD lx = A.lam_x + (size_t)b * n_w;
+    // bound multipliers of this stage's columns start from zero (p and v are unbounded)
+    BMPC_UNROLL
+    for (int f = 0; f < 40; f++) lx[(size_t)f * N + k] = 0.0;
+    MultVisitor V;
+    V.A = &A; V.pi = pi; V.N = N; V.k = k;
+    V.lg = A.lam_g + (size_t)b * n_g + 35 * (N - 1) + 112 * (k - 1);
+    V.lx = lx;
+    V.sPS = 0; V.sRS = 0; V.z1[0] = 0; V.z1[1] = 0;
+    BMPC_UNROLL
+    for (int c = 0; c < 6; c++) { V.bz[c] = 0; V.sD[c] = 0; V.Fc[c][0] = 0; V.Fc[c][1] = 0; V.Fc[c][2] = 0; }
+    BMPC_UNROLL
+    for (int j = 0; j < 7; j++) { V.lxq[j] = 0; V.lxdq[j] = 0; V.lxddq[j] = 0; }
+    BMPC_UNROLL
+    for (int i = 0; i < 4; i++) V.znn[i] = 0;
+    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    double bz[6], bzv[6], fa[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 6; c++) { bz[c] = V.bz[c] + g12[c]; bzv[c] = g12[6 + c]; }
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) fa[a] = bzv[3 + a] + 0.5 * dc.dt * bz[3 + a];     // stage-local part of lam_v (angular)
+    double cq[7], cdq[7];
+    BMPC_UNROLL
+    for (int j = 0; j < 7; j++) {
+        double sq = V.lxq[j], sd = V.lxdq[j];
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) {
+            sq += S.Jl[a][j] * bz[a] + G[a][j] * bzv[a] + G[3 + a][j] * fa[a];
+            sd += S.Jl[a][j] * bzv[a] + S.K.zx[j][a] * fa[a];
+        }
+        if (j >= 2 && j <= 4) sd += 2 * wts[6] * S.y[Z_DQ + j];                      // joint-velocity cost (Q9)
+        cq[j] = sq; cdq[j] = sd;
+    }
+    point_forces_to_q<0>(S.K, V.Fc, cq);
+    GD rec = A.hrec + pi * HREC;
+    BMPC_UNROLL
+    for (int j = 0; j < 7; j++) { rec[M_CQ + j] = cq[j]; rec[M_CDQ + j] = cdq[j]; rec[M_CDDQ + j] = V.lxddq[j]; }
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++)
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) { rec[M_GANG + 7 * a + j] = G[3 + a][j]; rec[M_ZX + 7 * a + j] = S.K.zx[j][a]; }
+    BMPC_UNROLL
+    for (int c = 0; c < 6; c++) { rec[M_BZ + c] = bz[c]; rec[M_BZV + c] = bzv[c]; }
+    rec[M_GRS] = 2 * wts[9] * S.y[Z_RS] + V.sRS - V.znn[0];
+    rec[M_GPS] = 2 * wts[9] * S.y[Z_PS] + V.sPS - V.znn[2];
+    if (k == 1) {
+        // stage-0 column: zero here, filled from stationarity by k_mult_sweep
+        BMPC_UNROLL
+        for (int f = 0; f < 40; f++) lx[(size_t)f * N] = 0.0;
+        BMPC_UNROLL
+        for (int f = 0; f < 4; f++) lx[(size_t)(40 + f) * N + 6] = 0.0;
+    }
+}
+
 }  // namespace bmpc

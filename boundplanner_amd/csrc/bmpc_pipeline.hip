@@ -65,6 +65,8 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) {
 __global__ __launch_bounds__(64) void bmpc_k_ls(PipeArgsH H) { k_ls_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_mult(PipeArgsH H) { k_mult_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64) void bmpc_k_mult_sweep(PipeArgsH H) { k_mult_sweep_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64) void bmpc_k_fin(PipeArgsH H) { k_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 
 #define LAUNCH(kern, nb, nt)                                            \
@@ -107,6 +109,13 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
 extern "C" hipError_t bmpc_pipe_launch_out(const PipeArgsH* A, hipStream_t st) {
     LAUNCH_DYN(bmpc_k_out, waves_for(A->N, A->B), 64, pair_lds_doubles(A->N, false));
     LAUNCH(bmpc_k_fin, (A->B + 63) / 64, 64);
+    return hipGetLastError();
+}
+
+// multipliers of the solve whose final iterate is still in the workspace (A->lam_g, A->lam_x: device outputs)
+extern "C" hipError_t bmpc_pipe_launch_mult(const PipeArgsH* A, hipStream_t st) {
+    LAUNCH_DYN(bmpc_k_mult, waves_for(A->N, A->B), 64, pair_lds_doubles(A->N, false));
+    LAUNCH(bmpc_k_mult_sweep, (A->B + 63) / 64, 64);
     return hipGetLastError();
 }
 

@@ -65,6 +65,11 @@ static_assert(PT_SIDE + SD_END <= NPART, "partials layout");
 enum { PT_CMAX = 0, PT_CSUM, PT_CMIN, PT_ZSUM, PT_PRIM, PT_THETA, PT_LOGS, PT_NROWS, PT_FVAL,
        PT_AP, PT_AD, PT_DBAR, PT_DPHIF, PT_F1, PT_TH1, PT_LS1 };
 
+// per-pair record of k_mult (written over the stage record once the solve is over), read by k_mult_sweep
+constexpr int M_CQ = 0, M_CDQ = 7, M_CDDQ = 14, M_GANG = 21 /*[3][7]*/, M_ZX = 42 /*[3][7]*/, M_BZ = 63 /*6*/, M_BZV = 69 /*6*/,
+              M_GRS = 75, M_GPS = 76, M_END = 77;
+static_assert(M_END <= HREC, "multiplier record fits the stage record");
+
 enum { ST_EVAL = 0, ST_STEP = 1, ST_TRIAL = 2, ST_DONE = 3 };
 
 // per-instance solver state (AoS, one per instance)
@@ -111,6 +116,7 @@ template <int DEV> struct PipeArgsT {
     ListsT<DEV> L;
     typename PT::CI tbl;                 // scatter table of the stage record (3 ints per field)
     typename PT::D prof;                 // diagnostic builds (-DBMPC_PROFILE): phase cycle sums, else unused
+    typename PT::D lam_g, lam_x;         // multiplier outputs of k_mult / k_mult_sweep ([B][n_g], [B][n_w]) or null
 };
 typedef PipeArgsT<0> PipeArgsH;          // host view
 typedef PipeArgsT<1> PipeArgs;           // device view (same layout)

@@ -957,5 +957,51 @@ BMPC_DEV void k_fin_body(const PipeArgs& A, int b) {
     A.status[b] = st->status;
 }
 
+// adjoint sweep of the multiplier recovery (see k_mult): one thread per instance, backwards over the stages
+BMPC_DEV void k_mult_sweep_body(const PipeArgs& A, int b) {
+    if (b >= A.B) return;
+    const int N = A.N, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
+    const double dt = A.o.dt;
+    GD lg = A.lam_g + (size_t)b * n_g;
+    GD lx = A.lam_x + (size_t)b * n_w;
+    double lq[7], ldq[7], lddq[7], lprot[3] = {0, 0, 0}, lrs = 0, lps = 0;
+    for (int j = 0; j < 7; j++) { lq[j] = 0; ldq[j] = 0; lddq[j] = 0; }
+    for (int k = N - 1; k >= 1; k--) {
+        GCD rec = A.hrec + pair_of(A, b, k) * HREC;
+        GD blk = lg + 35 * (k - 1);
+        const double n0 = lprot[0], n1 = lprot[1], n2 = lprot[2];          // lam_p_rot of the next block
+        double nq[7], ndq[7], nddq[7];
+        for (int j = 0; j < 7; j++) {
+            const double gl = dt * (rec[M_GANG + j] * n0 + rec[M_GANG + 7 + j] * n1 + rec[M_GANG + 14 + j] * n2);
+            const double zl = dt * (rec[M_ZX + j] * n0 + rec[M_ZX + 7 + j] * n1 + rec[M_ZX + 14 + j] * n2);
+            nq[j] = rec[M_CQ + j] + lq[j] + gl;
+            ndq[j] = rec[M_CDQ + j] + ldq[j] + dt * lq[j] + zl;
+            nddq[j] = rec[M_CDDQ + j] + lddq[j] + dt * ldq[j] + 0.5 * dt * dt * lq[j];
+        }
+        for (int j = 0; j < 7; j++) { lq[j] = nq[j]; ldq[j] = ndq[j]; lddq[j] = nddq[j]; blk[j] = nq[j]; blk[7 + j] = ndq[j]; blk[14 + j] = nddq[j]; }
+        for (int a = 0; a < 3; a++) {
+            const double nx = (a == 0 ? n0 : a == 1 ? n1 : n2);
+            lprot[a] = rec[M_BZ + 3 + a] + nx;
+            blk[21 + a] = rec[M_BZ + a];
+            blk[24 + a] = lprot[a];
+            blk[27 + a] = rec[M_BZV + a];
+            blk[30 + a] = rec[M_BZV + 3 + a] + 0.5 * dt * (lprot[a] + nx);
+        }
+        lrs = rec[M_GRS] + lrs; lps = rec[M_GPS] + lps;
+        blk[33] = lrs; blk[34] = lps;
+    }
+    // stage-0 variables (pinned by lbx == ubx / the eliminated stage-0 slacks): lam_x = -(grad f + J_g^T lam_g), what
+    // IPOPT reports for fixed variables under fixed_variable_treatment=make_parameter
+    for (int j = 0; j < 7; j++) {
+        lx[(size_t)j * N] = -lq[j];
+        lx[(size_t)(7 + j) * N] = -(ldq[j] + dt * lq[j]);
+        lx[(size_t)(14 + j) * N] = -(lddq[j] + dt * ldq[j] + 0.5 * dt * dt * lq[j]);
+        lx[(size_t)(21 + j) * N] = -(dt * dt * dt / 8 * lq[j] + dt * dt / 3 * ldq[j] + dt / 2 * lddq[j]);
+    }
+    for (int a = 0; a < 3; a++) lx[(size_t)(37 + a) * N] = -0.5 * dt * lprot[a];      // v_0 (angular); p_0: zero (the NLP
+    lx[(size_t)40 * N + 6] = -lrs; lx[(size_t)41 * N + 6] = -0.5 * dt * lrs;           // is invariant to a common shift of
+    lx[(size_t)42 * N + 6] = -lps; lx[(size_t)43 * N + 6] = -0.5 * dt * lps;           // all p_rot_k)
+}
+
 #undef RL
 }  // namespace bmpc

@@ -25,7 +25,7 @@ class BmpcOpts(ctypes.Structure):
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
-           "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_solve_dev_async", "bmpc_wait", "bmpc_active", "bmpc_fk",
+           "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_solve_dev_async", "bmpc_multipliers_dev", "bmpc_wait", "bmpc_active", "bmpc_fk",
            "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream",
            "bmpc_debug_phase_cycles",
            "bmpc_loop_state_doubles", "bmpc_loop_log_doubles", "bmpc_loop_field", "bmpc_loop_create", "bmpc_loop_destroy",
@@ -51,6 +51,7 @@ def load_library():
         lib.bmpc_solve.argtypes = [ctypes.c_void_p, ctypes.c_int] + [_dp] * 4 + [_dp] * 4 + [_dp, _ip, _ip, _dp]
         lib.bmpc_solve_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_void_p]
         lib.bmpc_solve_dev_async.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10
+        lib.bmpc_multipliers_dev.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.bmpc_wait.argtypes = [ctypes.c_void_p]
         lib.bmpc_active.argtypes = [ctypes.c_void_p]
         lib.bmpc_fk.argtypes = [ctypes.c_void_p, ctypes.c_int] + [_dp] * 7
@@ -115,17 +116,23 @@ class HipBoundMPC:
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self.lib.bmpc_last_error(self._h).decode()}")
 
-    def solve_batch(self, x0, lbx, ubx, p, want_g=False):
+    def solve_batch(self, x0, lbx, ubx, p, want_g=False, want_lam=False):
         x0, lbx, ubx, p = (np.ascontiguousarray(np.atleast_2d(a), float) for a in (x0, lbx, ubx, p))
         B = x0.shape[0]
         assert x0.shape == (B, self.n_w) and lbx.shape == x0.shape and ubx.shape == x0.shape and p.shape == (B, self.n_p)
         x = np.empty((B, self.n_w)); f = np.empty(B); viol = np.empty(B)
         g = np.empty((B, self.n_g)) if want_g else None
         iters = np.empty(B, np.int32); status = np.empty(B, np.int32)
-        rc = self.lib.bmpc_solve(self._h, B, _P(x0), _P(lbx), _P(ubx), _P(p), _P(x), _P(g), None, None, _P(f),
+        lam_g = np.empty((B, self.n_g)) if want_lam else None
+        lam_x = np.empty((B, self.n_w)) if want_lam else None
+        rc = self.lib.bmpc_solve(self._h, B, _P(x0), _P(lbx), _P(ubx), _P(p), _P(x), _P(g), _P(lam_g), _P(lam_x), _P(f),
                                  iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip), _P(viol))
         self._chk(rc, "bmpc_solve")
-        return dict(x=x, g=g, f=f, iters=iters, status=status, viol=viol)
+        return dict(x=x, g=g, f=f, iters=iters, status=status, viol=viol, lam_g=lam_g, lam_x=lam_x)
+
+    def multipliers_dev(self, B, d_lam_g, d_lam_x, stream=0):
+        """lam_g, lam_x (raw device pointers) of the most recent finished solve on this handle."""
+        self._chk(self.lib.bmpc_multipliers_dev(self._h, B, d_lam_g, d_lam_x, stream or None), "bmpc_multipliers_dev")
 
     def solve_dev(self, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_f, d_iters, d_status, d_viol, d_g=0, stream=0):
         """Raw device pointers (ints), asynchronous on `stream`."""
@@ -191,7 +198,7 @@ class HipNlpSolver:
     def __call__(self, x0, lbx, ubx, p, lbg=None, ubg=None, **_):
         inf2big = lambda a: np.nan_to_num(np.asarray(a, float), posinf=1e20, neginf=-1e20)
         r = self.backend.solve_batch(np.asarray(x0, float)[None], inf2big(lbx)[None], inf2big(ubx)[None],
-                                     np.asarray(p, float)[None], want_g=True)
+                                     np.asarray(p, float)[None], want_g=True, want_lam=self.backend.opts.engine == 0)
         st = int(r["status"][0])
         self._stats = {"iter_count": int(r["iters"][0]), "success": st == 0,
                        "return_status": ["Solve_Succeeded", "Maximum_Iterations_Exceeded",
@@ -199,7 +206,8 @@ class HipNlpSolver:
                        "g_viol": float(r["viol"][0]), "t_kernel_ms": self.backend.last_kernel_ms()}
         n_w, n_g = self.backend.n_w, self.backend.n_g
         return {"x": _DM(r["x"][0]), "g": _DM(r["g"][0]), "f": _DM(r["f"][0]),
-                "lam_g": _DM(np.zeros(n_g)), "lam_x": _DM(np.zeros(n_w))}
+                "lam_g": _DM(r["lam_g"][0] if r["lam_g"] is not None else np.zeros(n_g)),      # (engine 1 keeps no multipliers)
+                "lam_x": _DM(r["lam_x"][0] if r["lam_x"] is not None else np.zeros(n_w))}
 
     def stats(self):
         return dict(self._stats)

@@ -64,8 +64,11 @@ int bmpc_get_opts(const bmpc_handle* h, bmpc_opts* o);
 int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg);
 
 /* B independent solves = B calls of self.solver(...) (BoundMPC.py:594-603).  Host pointers.
- * x0/lbx/ubx/x: [B][n_w]; p: [B][875]; g: [B][n_g] or NULL; lam_g/lam_x: NULL or zero-filled
- * (multipliers are not produced yet); f/viol: [B]; iters/status: [B].
+ * x0/lbx/ubx/x: [B][n_w]; p: [B][875]; g: [B][n_g] or NULL; lam_g: [B][n_g] or NULL; lam_x: [B][n_w] or
+ * NULL -- sol["lam_g"], sol["lam_x"] (BoundMPC.py:638-645) in CasADi's convention: grad f + J_g^T lam_g + lam_x = 0,
+ * positive at an active upper bound, negative at an active lower bound; the entries of the variables that are fixed
+ * by lbx == ubx follow from stationarity (IPOPT fixed_variable_treatment=make_parameter).  Engine 0 only.
+ * f/viol: [B]; iters/status: [B].
  * status: 0 converged, 1 max_iter, 2 stalled, 3 numerical.  viol = sum of constraint
  * violations exactly as BoundMPC.py:613-615, so the caller reproduces
  * `success = stats["success"] or g_viol < 1e-4`.  Infinite bounds may be passed as +-inf or
@@ -82,6 +85,11 @@ int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double* lbx, const
 int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
                    const double* d_ubx, const double* d_p, double* d_x, double* d_g, double* d_f,
                    int* d_iters, int* d_status, double* d_viol, void* stream);
+
+/* Multipliers lam_g [B][n_g], lam_x [B][n_w] (device pointers) of the most recent finished solve on this handle (any
+ * entry point, pipeline engine): the final iterate stays in the handle's workspace until the next solve.  Enqueued on
+ * `stream` and waited for. */
+int bmpc_multipliers_dev(bmpc_handle* h, int B, double* d_lam_g, double* d_lam_x, void* stream);
 
 /* Asynchronous form: returns at once, the solve runs on the handle's own stream driven by a worker
  * thread; inputs must already be complete on the device.  One solve in flight per handle;

@@ -54,6 +54,10 @@ typedef struct {
     int i0, i1;          /* KIND_SPARSE: y indices (-1 = none) */
     double c0, c1;
     double cst;          /* unused */
+    int gidx;            /* index of the row in the stage's 112 (+21) inequality rows of g, or -1 */
+    int gsign;           /* +1: row is g <= 0 (lam_g = z); -1: row is g >= 0 (lam_g = -z) */
+    int xidx;            /* bound rows: index in w (lam_x += xsign * z), or -1 */
+    int xsign;
 } row_t;
 
 typedef struct {
@@ -282,16 +286,19 @@ static void eval_stage(prob_t* pb, int k, int mode) {
     for (int j = 0; j < 28; j++) {
         double lb = pb->lbq[k * 28 + j], ub = pb->ubq[k * 28 + j];
         memset(&r, 0, sizeof r);
-        r.kind = KIND_SPARSE; r.i1 = -1;
-        if (ub < BIG) { r.i0 = j; r.c0 = 1; add_row(s, &r, y[j] - ub); }
-        if (lb > -BIG) { r.i0 = j; r.c0 = -1; add_row(s, &r, lb - y[j]); }
+        r.kind = KIND_SPARSE; r.i1 = -1; r.gidx = -1;
+        r.xidx = (j / 7) * 7 * N + (j % 7) * N + k;
+        if (ub < BIG) { r.i0 = j; r.c0 = 1; r.xsign = 1; add_row(s, &r, y[j] - ub); }
+        if (lb > -BIG) { r.i0 = j; r.c0 = -1; r.xsign = -1; add_row(s, &r, lb - y[j]); }
     }
     /* slack variables >= 0 (Q6: all four per stage) */
     {
         int idx[4] = {Y_RS, Y_DRS, Y_PS, Y_DPS};
+        int widx[4] = {W_RS(N) + k, W_DRS(N) + k, W_PS(N) + k, W_DPS(N) + k};
         for (int m = 0; m < 4; m++) {
             memset(&r, 0, sizeof r);
             r.kind = KIND_SPARSE; r.i0 = idx[m]; r.c0 = -1; r.i1 = -1;
+            r.gidx = -1; r.xidx = widx[m]; r.xsign = -1;
             add_row(s, &r, -y[idx[m]]);
         }
     }
@@ -299,12 +306,14 @@ static void eval_stage(prob_t* pb, int k, int mode) {
         /* stage-0 slacks: rs_0, drs_0 >= 0 reach any rs~_1 = rs_0 + dt/2 drs_0 >= 0 */
         memset(&r, 0, sizeof r);
         r.kind = KIND_SPARSE; r.i0 = Y_RS; r.c0 = -1; r.i1 = Y_DRS; r.c1 = dt / 2;
+        r.gidx = -1; r.xidx = -1;       /* multipliers of the stage-0 slacks follow from stationarity */
         add_row(s, &r, -(y[Y_RS] - dt / 2 * y[Y_DRS]));
         r.i0 = Y_PS; r.i1 = Y_DPS;
         add_row(s, &r, -(y[Y_PS] - dt / 2 * y[Y_DPS]));
         for (int i = 0; i < 6; i++) {
             memset(&r, 0, sizeof r);
             r.kind = KIND_SPARSE; r.i0 = Y_D + i; r.c0 = -1; r.i1 = -1;
+            r.gidx = -1; r.xidx = W_DSL(N) + i; r.xsign = -1;
             add_row(s, &r, -y[Y_D + i]);
         }
     }
@@ -315,6 +324,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
         memset(&r, 0, sizeof r);
         r.kind = KIND_POSE;
         r.a[0] = a0; r.a[1] = a1; r.a[2] = a2; r.a[L_PS] = -1;
+        r.gidx = rr; r.gsign = 1; r.xidx = -1;
         add_row(s, &r, a0 * pose[0] + a1 * pose[1] + a2 * pose[2] - sc.b_cur[rr] - y[Y_PS]);
     }
     /* orientation bounds (:308-321) */
@@ -327,6 +337,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
             r.kind = KIND_POSE;
             for (int c = 0; c < 6; c++) r.a[c] = nb[m] * gs[m][c];
             r.a[L_RS] = -1;
+            r.gidx = 15 + m; r.gsign = 1; r.xidx = -1;
             add_row(s, &r, pr[m] - sc.ub[m] - y[Y_RS]);
         }
         for (int m = 0; m < 3; m++) { /* lower: proj - lb + rs >= 0  ->  -(...) <= 0 */
@@ -334,6 +345,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
             r.kind = KIND_POSE;
             for (int c = 0; c < 6; c++) r.a[c] = -nb[m] * gs[m][c];
             r.a[L_RS] = -1;
+            r.gidx = 18 + m; r.gsign = -1; r.xidx = -1;
             add_row(s, &r, -(pr[m] - sc.lb[m] + y[Y_RS]));
         }
     }
@@ -347,6 +359,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
             memset(&r, 0, sizeof r);
             r.kind = KIND_PT; r.grp = i;
             r.a[0] = a0; r.a[1] = a1; r.a[2] = a2; r.a[3] = -1;
+            r.gidx = 21 + 15 * i + rr; r.gsign = 1; r.xidx = -1;
             add_row(s, &r, a0 * kin.pc[i][0] + a1 * kin.pc[i][1] + a2 * kin.pc[i][2] - b - sl[i]);
         }
     }
@@ -354,6 +367,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
     memset(&r, 0, sizeof r);
     r.kind = KIND_POSE;
     for (int c = 0; c < 3; c++) r.a[c] = sc.dp[c];
+    r.gidx = 111; r.gsign = 1; r.xidx = -1;
     add_row(s, &r, pe.phi - (sc.phi_end_seg + 0.005));
     if (term) {
         double z1 = dot3(sc.bp1, pe.ep), z2 = dot3(sc.bp2, pe.ep);
@@ -370,6 +384,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
                 r.a[c] = tt;
             }
             r.a[L_D5] = -1;
+            r.gidx = 112 + rr; r.gsign = 1; r.xidx = -1;
             add_row(s, &r, a1 * z1 + a2 * z2 - bnew - sl[5]);
         }
         double cc[3] = {dot3(sc.br1n, sc.br1), dot3(sc.dpnn, sc.dpn), dot3(sc.br2n, sc.br2)};
@@ -380,6 +395,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
             r.kind = KIND_POSE;
             for (int c = 0; c < 6; c++) r.a[c] = cc[m] * gs[m][c];
             r.a[L_D5] = -1;
+            r.gidx = 127 + m; r.gsign = 1; r.xidx = -1;
             add_row(s, &r, pr[m] - sc.ubn[m] - sl[5]);
         }
         for (int m = 0; m < 3; m++) {
@@ -387,6 +403,7 @@ static void eval_stage(prob_t* pb, int k, int mode) {
             r.kind = KIND_POSE;
             for (int c = 0; c < 6; c++) r.a[c] = -cc[m] * gs[m][c];
             r.a[L_D5] = -1;
+            r.gidx = 130 + m; r.gsign = -1; r.xidx = -1;
             add_row(s, &r, -(pr[m] - sc.lbn[m] + sl[5]));
         }
     }
@@ -933,6 +950,69 @@ static void setup_problem(const bmpc_oracle_opts* o, prob_t* pbp, const double* 
 #undef pb
 }
 
+/* Multipliers of the FULL-SPACE NLP in CasADi's convention (grad f + J_g^T lam_g + lam_x = 0; lam > 0 at an active
+ * upper bound, < 0 at an active lower bound; BoundMPC.py:638-645 reads sol["lam_g"], sol["lam_x"]) from the
+ * interior-point iterate:
+ *  - inequality rows of g and bound rows of x: the row multipliers z of the barrier method (sign by row type);
+ *  - the 35 equality rows of block k (new_{k+1} - var_{k+1} = 0, casadi_ocp_formulation.py:145-164) have a -1 on
+ *    exactly one variable of stage k+1 (q, dq, ddq, p, v, rslack, pslack): stationarity in that variable gives the
+ *    multiplier, backwards over the stages (p before v before q, dq, ddq inside a stage: v_new - v and p_new - p couple
+ *    them) -- the adjoint sweep in the full space, done here with the pinned dense Jacobian;
+ *  - stage-0 variables (pinned by lbx == ubx, or the eliminated stage-0 slacks): lam_x = -(grad f + J_g^T lam_g),
+ *    what IPOPT reports for fixed variables under fixed_variable_treatment=make_parameter.
+ * What is left of the stationarity residual sits on u_k, drslack_k, dpslack_k (k >= 1) and dslacks: the dual
+ * infeasibility the solver terminated with. */
+static void recover_multipliers(prob_t* pb, const double* x, double* lam_g, double* lam_x) {
+    const int N = pb->N, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
+    double* J = (double*)malloc(sizeof(double) * (size_t)n_g * n_w);
+    double* gr = (double*)malloc(sizeof(double) * n_w);
+    double* res = (double*)malloc(sizeof(double) * n_w);
+    bmpc_oracle_eval(N, pb->dt, x, pb->p, NULL, NULL, gr, J);
+    memset(lam_g, 0, sizeof(double) * n_g);
+    memset(lam_x, 0, sizeof(double) * n_w);
+    for (int k = 1; k < N; k++) {
+        const stage_t* s = &pb->st[k];
+        const int g0 = 35 * (N - 1) + 112 * (k - 1);
+        for (int i = 0; i < s->nrows; i++) {
+            const row_t* r = &s->rows[i];
+            if (r->gidx >= 0) lam_g[g0 + r->gidx] = r->gsign * s->z[i];
+            if (r->xidx >= 0) lam_x[r->xidx] += r->xsign * s->z[i];
+        }
+    }
+    /* residual with the known multipliers */
+    for (int i = 0; i < n_w; i++) res[i] = gr[i] + lam_x[i];
+    for (int r = 35 * (N - 1); r < n_g; r++)
+        if (lam_g[r] != 0.0)
+            for (int i = 0; i < n_w; i++) res[i] += J[(size_t)r * n_w + i] * lam_g[r];
+    /* equality rows of block k = j - 1: offsets inside the block and the pivot variable of stage j */
+    for (int j = N - 1; j >= 1; j--) {
+        const int blk = 35 * (j - 1);
+        /* order: p (21..26), v (27..32), rslack 33, pslack 34, then q, dq, ddq (0..20) */
+        int order[35], piv[35], n = 0;
+        for (int c = 0; c < 6; c++) { order[n] = 21 + c; piv[n++] = W_P(N) + c * N + j; }
+        for (int c = 0; c < 6; c++) { order[n] = 27 + c; piv[n++] = W_V(N) + c * N + j; }
+        order[n] = 33; piv[n++] = W_RS(N) + j;
+        order[n] = 34; piv[n++] = W_PS(N) + j;
+        for (int c = 0; c < 7; c++) { order[n] = c; piv[n++] = W_Q(N) + c * N + j; }
+        for (int c = 0; c < 7; c++) { order[n] = 7 + c; piv[n++] = W_DQ(N) + c * N + j; }
+        for (int c = 0; c < 7; c++) { order[n] = 14 + c; piv[n++] = W_DDQ(N) + c * N + j; }
+        for (int m = 0; m < 35; m++) {
+            const int row = blk + order[m];
+            const double* Jr = J + (size_t)row * n_w;
+            /* J[row][piv] = -1 (var_{k+1} enters its own defect only there) */
+            const double lam = res[piv[m]] / (-Jr[piv[m]]);
+            lam_g[row] = lam;
+            for (int i = 0; i < n_w; i++)
+                if (Jr[i] != 0.0) res[i] += Jr[i] * lam;
+        }
+    }
+    /* stage-0 variables: multipliers of the fixed variables from stationarity */
+    for (int f = 0; f < 40; f++) { lam_x[f * N] -= res[f * N]; }
+    lam_x[W_RS(N)] -= res[W_RS(N)]; lam_x[W_DRS(N)] -= res[W_DRS(N)];
+    lam_x[W_PS(N)] -= res[W_PS(N)]; lam_x[W_DPS(N)] -= res[W_DPS(N)];
+    free(J); free(gr); free(res);
+}
+
 int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double* lbx,
                       const double* ubx, const double* p, double* x, double* g, double* lam_g,
                       double* lam_x, double* f, int* iters, int* status, double* viol) {
@@ -1163,8 +1243,11 @@ done:
             *viol = vs;
         }
         if (!g) free(gg);
-        if (lam_g) memset(lam_g, 0, sizeof(double) * n_g);
-        if (lam_x) memset(lam_x, 0, sizeof(double) * n_w);
+        if (lam_g && lam_x) recover_multipliers(&pb, x, lam_g, lam_x);
+        else {
+            if (lam_g) memset(lam_g, 0, sizeof(double) * n_g);
+            if (lam_x) memset(lam_x, 0, sizeof(double) * n_w);
+        }
     }
     if (iters) *iters = it;
     if (status) *status = st;

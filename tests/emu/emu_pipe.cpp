@@ -65,7 +65,7 @@ template <class F> static void launch(int nblocks, F body, int nt = 64) {
 extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int hess, double hess_switch, double mu_init,
                               double kappa_mu, double theta_mu, double kappa_eps, int B, const double* x0,
                               const double* lbx, const double* ubx, const double* p, double* x, double* g, double* f,
-                              int* iters, int* status, double* viol, int verbose) {
+                              int* iters, int* status, double* viol, int verbose, double* lam_g, double* lam_x) {
     RobotConst rc;
     fill_robot_const(rc);
     PipeArgs A;   // emulation: BMPC_AS1 is empty, host and device views coincide
@@ -120,5 +120,10 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     }
     launch(nw, [&](int blk, int l) { k_out_body(A, blk, l, lds.data()); });
     launch(nb_inst, [&](int blk, int l) { k_fin_body(A, blk * 64 + l); });
+    if (lam_g && lam_x) {
+        A.lam_g = lam_g; A.lam_x = lam_x;
+        launch(nw, [&](int blk, int l) { k_mult_body(A, blk, l, lds.data()); });
+        launch(nb_inst, [&](int blk, int l) { k_mult_sweep_body(A, blk * 64 + l); });
+    }
     return steps;
 }

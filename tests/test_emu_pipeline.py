@@ -14,7 +14,7 @@ def test_emulated_pipeline_matches_oracle():
     N, B = 6, 5
     batch = scenes.make_batch(B, N, 6, O.fk_batch, randomize_sets=True)
     ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], nthreads=1)
-    r = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    r = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True, want_lam=True)
     assert np.array_equal(r["status"], ro["status"]) and (r["status"] == 0).all()
     assert np.array_equal(r["iters"], ro["iters"])
     assert np.abs(r["x"] - ro["x"]).max() < 1e-5
@@ -22,3 +22,9 @@ def test_emulated_pipeline_matches_oracle():
     for i in range(B):
         _, g, _, _ = O.nlp_eval(N, r["x"][i], batch["p"][i], jac=False)
         assert np.abs(g - r["g"][i]).max() < 1e-9
+        # multipliers (k_mult, k_mult_sweep): every entry written, equal to the oracle's, closing the full-space KKT conditions
+        rs = O.solve(N, batch["x0"][i], batch["lbx"][i], batch["ubx"][i], batch["p"][i])
+        assert np.isfinite(r["lam_g"][i]).all() and np.isfinite(r["lam_x"][i]).all()
+        assert np.abs(r["lam_g"][i] - rs["lam_g"]).max() < 1e-6 and np.abs(r["lam_x"][i] - rs["lam_x"]).max() < 1e-6
+        _, _, gr, J = O.nlp_eval(N, r["x"][i], batch["p"][i])
+        assert np.abs(gr + J.T @ r["lam_g"][i] + r["lam_x"][i]).max() < 1e-4

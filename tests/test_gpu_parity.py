@@ -60,13 +60,14 @@ def test_solve_matches_oracle(backends, N, seed, rnd, B):
     r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
     ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], nthreads=0)
     same = (r["status"] == ro["status"])
-    assert same.mean() > 0.97
     conv = (r["status"] == 0) & (ro["status"] == 0)
-    assert conv.mean() > 0.95
     dit = np.abs(r["iters"] - ro["iters"])
-    assert dit[conv].max() <= 1
     eq = conv & (dit == 0)
-    assert eq.sum() >= 0.9 * conv.sum()
+    print(f"N={N}: status equal {same.sum()}/{B}, both converged {conv.sum()}, same iterations {eq.sum()}, max |d iters| {dit[conv].max()}")
+    assert same.all()                              # every instance ends in the same status
+    assert conv.sum() >= B - 1                     # (N=30: one instance of the 24 runs into max_iter on both sides)
+    assert dit[conv].max() <= 1
+    assert eq.sum() >= conv.sum() - 1              # at most one instance stops an iteration apart
     blk = lambda a, lo, hi: np.abs(a["x"][:, lo * N:hi * N])
     d = lambda lo, hi: np.abs(r["x"][:, lo * N:hi * N] - ro["x"][:, lo * N:hi * N]).max(axis=1)
     d_task, d_joint, d_u = d(28, 40), d(0, 21), d(21, 28)
@@ -152,6 +153,10 @@ def test_nlpsolver_object_matches_reference_call_convention(backends):
     st = s.stats()
     assert st["success"] and st["iter_count"] > 0 and st["return_status"] == "Solve_Succeeded"
     assert sol["x"].full().shape == (44 * N + 6, 1) and sol["g"].full().shape == (147 * (N - 1) + 21, 1)
+    lam_g, lam_x = sol["lam_g"].full().ravel(), sol["lam_x"].full().ravel()
+    assert lam_g.shape == (147 * (N - 1) + 21,) and lam_x.shape == (44 * N + 6,) and np.abs(lam_g).max() > 0
+    _, _, gr, J = O.nlp_eval(N, sol["x"].full().ravel(), batch["p"][0])
+    assert np.abs(gr + J.T @ lam_g + lam_x).max() < 1e-4
 
 
 def test_engines_and_async_entry_agree(backends):
@@ -219,6 +224,91 @@ def test_full_size_batch_properties(backends):
         assert np.array_equal(x[:, blk * 7 * N:(blk + 1) * 7 * N:N], batch["lbx"][:, blk * 7 * N:(blk + 1) * 7 * N:N])
 
 
+BLOCKS = lambda N: {"q": (0, 7 * N), "dq": (7 * N, 14 * N), "ddq": (14 * N, 21 * N), "u": (21 * N, 28 * N),
+                    "p": (28 * N, 34 * N), "v": (34 * N, 40 * N), "slacks": (40 * N, 44 * N + 6)}
+
+
+def test_config2_full_batch_against_oracle(backends):
+    """BASELINE configs[2] at its full size (8192 instances, N=20, randomized convex sets), EVERY instance against the oracle,
+    per block of the decision vector.  Both sides run the same algorithm in FP64 and differ by summation order only; what
+    that rounding noise turns into depends on the instance:
+      * 97.9 % of the instances that converge on both sides take the same number of iterations; they agree to the bars
+        below (worst observed: q 3.7e-4, u 2.9e-3, task 2.8e-4, objective 2.1e-7 relative).  The task-space bar of
+        DESIGN.md (2e-5) holds for 99.7 % of them; the rest are long, ill-conditioned runs (40-90 iterations) in which
+        the noise is amplified by every line-search decision.
+      * the others stop an iteration (or, for the stragglers, up to 30 iterations) apart: both points pass the same
+        optimality test and differ by the size of the last Newton steps.  At tol = 1e-5 an accepted iterate is itself
+        up to 1e-3 rad / 9e-2 (jerk) / 2e-3 (task) away from the exact KKT point -- measured as the distance between the
+        tol = 1e-5 and tol = 1e-8 solutions of the same solver, tests/diag/diag_full_parity.py -- so that is the size of
+        the differences here (worst observed: jerk 2.6e-2 at instance 7445, 66 vs 67 iterations; at tol = 1e-8 the two
+        sides agree on it to 2.4e-5).  Objective values agree to 4.4e-6 relative on every instance.
+    Bars are the observed maxima with a factor ~2 of head room."""
+    from boundplanner_amd import scenes
+    N, B = 20, 8192
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 8192, be.fk, randomize_sets=True)
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], nthreads=0)
+    n_status_diff = int((r["status"] != ro["status"]).sum())
+    conv = (r["status"] == 0) & (ro["status"] == 0)
+    dit = np.abs(r["iters"].astype(int) - ro["iters"].astype(int))
+    eq = conv & (dit == 0)
+    d = np.abs(r["x"] - ro["x"])
+    per = {k: d[:, a:b].max(axis=1) for k, (a, b) in BLOCKS(N).items()}
+    df = np.abs(r["f"] - ro["f"]) / np.maximum(1.0, np.abs(ro["f"]))
+    worst = sorted(set(int(np.nonzero(conv)[0][np.argmax(v[conv])]) for v in per.values()))
+    print(f"configs[2]: status differs on {n_status_diff}, both converged {conv.sum()}/{B}, same iterations {eq.sum()}, "
+          f"|d iters| <= 1: {(dit[conv] <= 1).sum()}, max {dit[conv].max()}")
+    print("  same-iters max   ", {k: f"{v[eq].max():.1e}" for k, v in per.items()}, f"df {df[eq].max():.1e}")
+    print("  both-conv  max   ", {k: f"{v[conv].max():.1e}" for k, v in per.items()}, f"df {df[conv].max():.1e}")
+    print("  worst instances  ", [(i, int(r["iters"][i]), int(ro["iters"][i])) for i in worst])
+    assert n_status_diff <= 16                                   # observed 8 (4 + 4 at the max_iter edge)
+    assert conv.sum() >= 0.995 * B                               # observed 8168
+    assert eq.sum() >= 0.97 * conv.sum() and (dit[conv] <= 1).sum() >= 0.985 * conv.sum() and dit[conv].max() <= 45
+    bars_same = {"q": 1e-3, "dq": 1e-3, "ddq": 2e-3, "u": 1e-2, "p": 5e-4, "v": 5e-4, "slacks": 1e-5}
+    bars_conv = {"q": 2e-3, "dq": 3e-3, "ddq": 8e-3, "u": 6e-2, "p": 2e-3, "v": 2e-3, "slacks": 2e-4}
+    for k in per:
+        assert per[k][eq].max() < bars_same[k], (k, int(np.argmax(np.where(eq, per[k], 0))))
+        assert per[k][conv].max() < bars_conv[k], (k, int(np.argmax(np.where(conv, per[k], 0))))
+    assert df[eq].max() < 1e-6 and df[conv].max() < 1e-5
+    # the stated tight bars (DESIGN.md section 5) hold for all but a few per mille of the same-iteration instances
+    tight = {"q": 2e-3, "dq": 2e-3, "ddq": 2e-3, "u": 2e-2, "p": 2e-5, "v": 2e-5}
+    for k, bar in tight.items():
+        assert (per[k][eq] > bar).sum() <= (0 if k in ("q", "dq", "ddq", "u") else 0.006 * eq.sum()), k
+        assert np.quantile(per[k][eq], 0.99) < 0.5 * bar, k
+    assert np.abs(r["viol"][conv] - ro["viol"][conv]).max() < 1e-6
+
+
+@pytest.mark.parametrize("N,seed,rnd,tol,res_tol", [(10, 1024, False, 1e-5, 1e-4), (20, 8192, True, 1e-5, 1e-4), (15, 15, True, 1e-8, 1e-7)])
+def test_multipliers(backends, N, seed, rnd, tol, res_tol):
+    """sol["lam_g"], sol["lam_x"] (BoundMPC.py:638-645) through the C ABI: they close the KKT conditions of the pinned
+    full-space NLP at the returned point, carry CasADi's signs, are complementary, and equal the oracle's."""
+    from boundplanner_amd import scenes
+    from test_oracle_solver import check_multipliers
+    B = 16
+    be = backends(N, tol=tol)
+    batch = scenes.make_batch(B, N, seed, be.fk, randomize_sets=rnd)
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_lam=True)
+    ro = [O.solve(N, batch["x0"][i], batch["lbx"][i], batch["ubx"][i], batch["p"][i], tol=tol) for i in range(B)]
+    assert (r["status"] == 0).sum() >= B - 1
+    worst = 0.0
+    for i in np.nonzero(r["status"] == 0)[0]:
+        lbx = np.where(np.isinf(batch["lbx"][i]), -1e20, batch["lbx"][i]); ubx = np.where(np.isinf(batch["ubx"][i]), 1e20, batch["ubx"][i])
+        worst = max(worst, check_multipliers(N, r["x"][i], batch["p"][i], lbx, ubx, r["lam_g"][i], r["lam_x"][i], res_tol, 20 * tol))
+        if ro[i]["status"] == 0 and ro[i]["iters"] == r["iters"][i]:
+            sc = max(1.0, np.abs(ro[i]["lam_g"]).max())
+            assert np.abs(r["lam_g"][i] - ro[i]["lam_g"]).max() < 1e-3 * sc and np.abs(r["lam_x"][i] - ro[i]["lam_x"]).max() < 1e-3 * sc
+    print(f"N={N} tol={tol}: max stationarity residual {worst:.1e}")
+    # device-pointer entry: multipliers of the most recent solve on the handle
+    import torch
+    dev = torch.device("cuda", 0)
+    lg = torch.empty((B, be.n_g), dtype=torch.float64, device=dev); lx = torch.empty((B, be.n_w), dtype=torch.float64, device=dev)
+    be.multipliers_dev(B, lg.data_ptr(), lx.data_ptr())
+    assert np.array_equal(lg.cpu().numpy(), r["lam_g"]) and np.array_equal(lx.cpu().numpy(), r["lam_x"])
+    with pytest.raises(RuntimeError):
+        be.multipliers_dev(B + 1, lg.data_ptr(), lx.data_ptr())       # no solve of that size on the handle
+
+
 def test_hip_matches_committed_slsqp_solutions(backends, golden_dir):
     """SURVEY 8(c) bridge (ii) on the product path: the HIP solve (through the C ABI) of the committed
     N=10 instances lands on the solutions an independent SLSQP run found (tests/golden/gen/gen_slsqp.py)."""
@@ -266,16 +356,17 @@ def test_config1_full_batch_against_oracle(backends):
     batch = scenes.make_batch(B, N, 1024, be.fk, randomize_sets=False)
     r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
     ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], nthreads=0)
-    assert (r["status"] == ro["status"]).mean() > 0.995
+    assert (r["status"] == ro["status"]).all()
     conv = (r["status"] == 0) & (ro["status"] == 0)
-    assert conv.mean() > 0.99
+    assert conv.all()                                   # observed 1024/1024
     dit = np.abs(r["iters"] - ro["iters"])
-    assert (dit[conv] == 0).mean() > 0.97 and (dit[conv] <= 1).mean() > 0.99 and dit[conv].max() <= 5
+    # observed: 1017 identical iteration counts, the rest within 5
+    assert (dit[conv] == 0).sum() >= 1010 and (dit[conv] <= 1).sum() >= 1018 and dit[conv].max() <= 5
     d_task = np.abs(r["x"][:, 28 * N:40 * N] - ro["x"][:, 28 * N:40 * N]).max(axis=1)
     eq = conv & (dit == 0)
     print(f"configs[1]: converged {conv.sum()}/{B}, same iterations {eq.sum()}, max |d task| same-iters {d_task[eq].max():.1e} all {d_task[conv].max():.1e}")
-    assert np.quantile(d_task[eq], 0.99) < 2e-5      # the stated bar; a handful of instances branch and rejoin
-    assert d_task[conv].max() < 1e-3
+    assert (d_task[eq] < 2e-5).sum() >= eq.sum() - 3     # the stated bar, per instance
+    assert d_task[eq].max() < 2e-4 and d_task[conv].max() < 1e-3
     assert (np.abs(r["f"][conv] - ro["f"][conv]) <= 1e-5 * np.maximum(1.0, np.abs(ro["f"][conv]))).all()
     assert abs(r["iters"].mean() - ro["iters"].mean()) < 0.05
 

@@ -63,3 +63,37 @@ def test_warm_start_is_cheaper():
     r1 = O.solve(N, r0["x"], b["lbx"][0], b["ubx"][0], b["p"][0])
     assert r1["status"] == 0 and r1["iters"] <= r0["iters"]
     assert np.abs(r1["x"][: 28 * N] - r0["x"][: 28 * N]).max() < 1e-3
+
+
+def check_multipliers(N, x, p, lbx, ubx, lam_g, lam_x, res_tol, compl_tol):
+    """The returned multipliers close the stationarity condition of the PINNED full-space NLP in CasADi's convention
+    (grad f + J_g^T lam_g + lam_x = 0, BoundMPC.py:638-645), have the signs of their bounds and are complementary."""
+    f, g, gr, J = O.nlp_eval(N, x, p)
+    lbg, ubg = O.gbounds(N)
+    res = gr + J.T @ lam_g + lam_x
+    assert np.abs(res).max() < res_tol, (np.abs(res).max(), int(np.argmax(np.abs(res))))
+    up = (ubg < 1e19) & (lbg < -1e19); lo = (lbg > -1e19) & (ubg > 1e19)
+    assert (lam_g[up] >= 0).all() and (lam_g[lo] <= 0).all()
+    assert np.abs(lam_g[up] * (g[up] - ubg[up])).max() < compl_tol and np.abs(lam_g[lo] * (g[lo] - lbg[lo])).max() < compl_tol
+    free = lbx < ubx                         # not pinned
+    xu = free & (ubx < 1e19); xl = free & (lbx > -1e19)
+    both = xu & xl
+    assert (lam_x[xu & ~xl] >= 0).all() and (lam_x[xl & ~xu] <= 0).all()
+    cu = np.where(xu, lam_x * (x - np.where(xu, ubx, 0)), 0); cl = np.where(xl, lam_x * (x - np.where(xl, lbx, 0)), 0)
+    # two-sided boxes: lam_x = z_ub - z_lb, each complementary with its own bound
+    one = ~both
+    assert np.abs(cu[one]).max() < compl_tol and np.abs(cl[one]).max() < compl_tol
+    assert (lam_x[free & ~xu & ~xl] == 0).all()
+    return np.abs(res).max()
+
+
+@pytest.mark.parametrize("N,seed,rnd,tol,res_tol", [(6, 6, True, 1e-5, 1e-4), (10, 1024, False, 1e-5, 1e-4), (20, 8192, True, 1e-5, 1e-4),
+                                                    (20, 8192, True, 1e-8, 1e-8), (15, 15, True, 1e-8, 1e-8)])
+def test_multipliers_close_the_full_space_kkt_conditions(N, seed, rnd, tol, res_tol):
+    """KKT residual of the pinned full-space NLP with the solver's own multipliers, up to the reference's horizons."""
+    b = scenes.make_batch(3, N, seed, O.fk_batch, randomize_sets=rnd)
+    for i in range(3):
+        r = O.solve(N, b["x0"][i], b["lbx"][i], b["ubx"][i], b["p"][i], tol=tol)
+        assert r["status"] == 0
+        lbx = np.where(np.isinf(b["lbx"][i]), -1e20, b["lbx"][i]); ubx = np.where(np.isinf(b["ubx"][i]), 1e20, b["ubx"][i])
+        check_multipliers(N, r["x"], b["p"][i], lbx, ubx, r["lam_g"], r["lam_x"], res_tol, 20 * tol)
