@@ -3,6 +3,8 @@ import socket
 import sys
 
 import pytest
+import torch  # noqa: F401  -- BEFORE libboundmpc_hip.so is loaded: torch brings its own HIP runtime, and the GPU tests
+#                              that hand torch tensors to the C ABI need both to share the one that was loaded first
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -225,3 +225,42 @@ def test_device_loop_tracks_reference_trace_with_hip_solver(golden_dir):
     assert dp_max < 1e-3 and dq_max < 5e-3, (dp_max, dq_max)
     assert row[L["phi"]] >= row[L["phi_max"]] - 0.001
     assert abs(np.mean(iters) - g["iters"].mean()) < 1.0
+
+
+def test_device_collision_sets_match_the_reference_finder(golden_dir):
+    """a10 / f2 on the MI355X: bmpc_loop_k_colpairs + the greedy selection of bmpc_loop_k_prepare against the REFERENCE's own
+    finder on its example scene (tests/golden/colsets.npz: 56 (q0, qf) pairs x 6 collision points x 12 boxes)."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.robot_model import RobotModel
+    from boundplanner_amd.solver import HipBoundMPC
+    from test_collision_sets import expected_set_params
+    from test_device_loop import _rollout_state
+    g = np.load(os.path.join(golden_dir, "colsets.npz"))
+    N, R = 8, g["q0"].shape[0]
+    params = _params(N)
+    be = HipBoundMPC(N, max_batch=R)
+    robot = RobotModel(be.fk)
+    loop = DeviceLoop(be, R)
+    loop.set_obstacles(*scenes.boxes_to_sets(g["boxes"]))
+    for r in range(R):
+        mpc, _, p_lie = _rollout_state(loop.lay, params, robot, g["q0"][r], g["qf"][r])
+        loop.set_rollout(r, mpc, g["q0"][r], np.zeros(7), np.zeros(7), np.zeros(7), g["qf"][r], np.zeros(6), p_lie)
+    loop.upload()
+    loop.prepare()
+    p = loop.problem()[3]
+    worst = 0.0
+    for r in range(R):
+        a_ref, b_ref, b_ok = expected_set_params(g, r)
+        worst = max(worst, np.abs(p[r, 515:785] - a_ref).max(), np.abs(p[r, 785:875] - b_ref)[b_ok].max())
+    assert worst < 1e-6, worst
+    assert (loop.download()["dead"] == 0).all()
+    # a scene that needs 20 halfspaces around one collision point: the rollout is frozen (the reference's normalizer prints
+    # an error and leaves the set ragged, util_functions.py:126-134)
+    loop2 = DeviceLoop(be, 1)
+    loop2.set_obstacles(*scenes.boxes_to_sets(g["shell_boxes"]))
+    mpc, _, p_lie = _rollout_state(loop2.lay, params, robot, g["shell_q"][0], g["shell_q"][0])
+    loop2.set_rollout(0, mpc, g["shell_q"][0], np.zeros(7), np.zeros(7), np.zeros(7), g["shell_q"][0], np.zeros(6), p_lie)
+    loop2.upload()
+    loop2.prepare()
+    assert loop2.download()["dead"][0] == 2.0
