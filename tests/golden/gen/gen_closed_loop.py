@@ -37,9 +37,6 @@ from bound_planner.BoundMPC.BoundMPC import BoundMPC as RefMPC  # noqa: E402
 from bound_planner.utils import get_default_params, integrate_joint  # noqa: E402
 from bound_planner.utils.util_functions import Params  # noqa: E402
 
-N = 10
-
-
 class FakeRobot:
     """Numeric kinematics with the reference RobotModel's method names."""
     col_joint_sizes = [0.09, 0.12, 0.09, 0.10, 0.07, 0.09, 0.075]
@@ -81,14 +78,24 @@ class DM:
 class OracleSolver:
     """CasADi-function-like wrapper of the CPU oracle; records every call."""
 
-    def __init__(self, n):
+    def __init__(self, n, fail_calls=()):
         self.n = n
         self.calls = []
         self._stats = {}
+        self.fail_calls = set(fail_calls)      # indices of calls that come back as a failed, infeasible solve
 
     def __call__(self, x0, lbx, ubx, lbg, ubg, p):
         x0, lbx, ubx, p = (np.asarray(a, float).reshape(-1) for a in (x0, lbx, ubx, p))
-        r = O.solve(self.n, x0, lbx, ubx, p)
+        fail = len(self.calls) in self.fail_calls
+        r = O.solve(self.n, x0, lbx, ubx, p, max_iter=2 if fail else 100)
+        if fail:
+            # an interrupted solve whose iterate violates a dynamics row by 1e-2 (what Maximum_Iterations_Exceeded /
+            # Infeasible_Problem_Detected returns look like to BoundMPC.py:613-617)
+            r["status"] = 1
+            r["g"] = r["g"].copy(); r["g"][3] += 1e-2
+        lb, ub = O.gbounds(self.n)
+        viol = -np.sum(r["g"][r["g"] < lb - 1e-6]) + np.sum(r["g"][r["g"] > ub + 1e-6])      # BoundMPC.py:613-615
+        r["viol"] = float(viol)
         self._stats = {"iter_count": r["iters"], "success": r["status"] == 0,
                        "return_status": "Solve_Succeeded" if r["status"] == 0 else "Maximum_Iterations_Exceeded"}
         self.calls.append(dict(x0=x0.copy(), lbx=lbx.copy(), ubx=ubx.copy(), p=p.copy(), x=r["x"].copy(), g=r["g"].copy(),
@@ -165,23 +172,56 @@ def box_set(lo, hi):
     return a, b
 
 
-def main():
+ERB = np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180
+
+
+def scenario(name, p0):
+    """Via paths of the committed traces (positions relative to the start pose p0, rotations relative to its orientation)."""
+    R0 = R.from_rotvec(p0[3:]).as_matrix()
+    rot = lambda *e: R0 @ R.from_euler("xyz", list(e), degrees=True).as_matrix()
+    big = [box_set([-0.3, -1.0, 0.05], [0.9, 0.4, 1.0])]
+    if name in ("base", "fail"):
+        # three via points, rotation about two axes, two large box sets (phi_max = 0.57 < 1: the w_phi rescale of Q10 is live)
+        dp = [[0, 0, 0], [0.05, -0.25, 0.10], [0.15, -0.45, -0.05]]
+        rots = [R0, rot(20, 0, 10), rot(20, 25, 10)]
+        sets = [box_set([-0.2, -0.6, 0.2], [0.8, 0.3, 0.9]), box_set([-0.1, -0.9, 0.1], [0.9, 0.0, 0.8])]
+        return dict(N=10, dp=dp, rots=rots, sets=sets, steps=70, fail_calls=(9, 10, 21) if name == "fail" else ())
+    if name == "n15":
+        # the reference's default horizon, five via points: three set switches, the 4-segment window of ReferencePath
+        # slides, phi_max = 1.18 > 1 (no w_phi rescale, Q10); the first 60 steps are recorded
+        dp = [[0, 0, 0], [0.05, -0.25, 0.10], [0.15, -0.45, -0.05], [0.30, -0.45, 0.15], [0.30, 0.05, 0.30]]
+        rots = [R0, rot(20, 0, 10), rot(20, 25, 10), rot(0, 25, -10), rot(0, 0, 0)]
+        return dict(N=15, dp=dp, rots=rots, sets=big * 4, steps=60, fail_calls=())
+    if name == "patch":
+        # the end-effector orientation passes through a half turn: its rotation vector (|.| = 2.09 at the start) flips
+        # sign on the way, and the warm start's integrated omega is re-based (Q11, BoundMPC.py:423-428)
+        dp = [[0, 0, 0], [0.05, -0.20, 0.05], [0.10, -0.40, 0.0]]
+        rots = [R0, rot(0, 0, 55), rot(0, 0, 110)]
+        return dict(N=10, dp=dp, rots=rots, sets=big * 2, steps=50, fail_calls=())
+    raise KeyError(name)
+
+
+def main(name):
     base = get_default_params()
-    params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
     robot = FakeRobot()
-    solver = OracleSolver(N)
     q0 = np.array([0, 0, 0, -np.pi / 2, 0, np.pi / 2, 0.0])
     p0 = robot.fk(q0)
+    sc = scenario(name, p0)
+    N = sc["N"]
+    params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    solver = OracleSolver(N, sc["fail_calls"])
     # start-up problem of MPCNode.reset (MPCNode.py:44-80) + the warm-up step of the example
     mpc = make_ref_mpc([p0[:3]] * 2, [R.from_rotvec(p0[3:]).as_matrix()] * 2, [np.array([1.0, 0, 0])],
-                       [np.array([1.0, 0, 0])], [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180],
-                       [np.zeros((15, 3))], [np.ones(15)], p0, params, solver, robot)
+                       [np.array([1.0, 0, 0])], [ERB.copy()], [np.zeros((15, 3))], [np.ones(15)], p0, params, solver, robot)
     st = dict(q=q0.copy(), qf=q0.copy(), dq=np.zeros(7), ddq=np.zeros(7), jerk=np.zeros(7), p_lie=p0.copy(), v=np.zeros(6))
     trace = []
 
     def node_step():
         st["p_lie"], _, _ = robot.forward_kinematics(st["q"], st["dq"])
         rec = {"in_" + k: np.copy(v) for k, v in st.items()}
+        patched = 0
+        if mpc.prev_solution is not None:       # the condition of BoundMPC.py:423
+            patched = int(np.linalg.norm(st["p_lie"][3:] - np.asarray(mpc.prev_solution)[31 * N:34 * N:N]) > 1.5)
         traj, ref_data, err_data, _, iters = mpc.step(st["q"], st["dq"], st["ddq"], st["p_lie"], st["v"], st["jerk"], st["qf"])
         new = integrate_joint(robot, traj["dddq"], st["q"], st["dq"], st["ddq"], mpc.dt)
         st["q"], st["dq"], st["ddq"], st["p_lie"], st["v"] = new[0], new[1], new[2], new[3], new[4]
@@ -189,11 +229,13 @@ def main():
         st["jerk"] = traj["dddq"][:, 1]
         c = solver.calls[-1]
         rec.update({"call_" + k: c[k] for k in ("x0", "lbx", "ubx", "p", "x", "g")})
-        rec.update(iters=c["iters"], status=c["status"], viol=c["viol"])
-        rec.update({"traj_" + k: np.array(traj[k]) for k in ("p", "v", "q", "dq", "ddq", "dddq", "phi", "dphi")})
+        rec.update(iters=c["iters"], status=c["status"], viol=c["viol"], patched=patched)
+        # failed steps shift the outputs by error_count columns (Q12): pad to the full width
+        pad = lambda a: np.concatenate((np.asarray(a, float), np.full(np.asarray(a).shape[:-1] + (N - np.asarray(a).shape[-1],), np.nan)), axis=-1)
+        rec.update({"traj_" + k: pad(traj[k]) for k in ("p", "v", "q", "dq", "ddq", "dddq", "phi", "dphi")})
+        rec.update(traj_cols=np.asarray(traj["dddq"]).shape[-1])
         rec.update(ref_p1=np.array(ref_data["p"][1]), ref_p0=np.array(ref_data["p"][0]),
-                   err_e_p1=np.array(err_data["e_p"][1]), err_e_r1=np.array(err_data["e_r"][1]),
-                   err_e_r_par=np.array(err_data["e_r_par"][:len(traj["phi"]) + 1], float))
+                   err_e_p1=np.array(err_data["e_p"][1]), err_e_r1=np.array(err_data["e_r"][1]))
         rec.update(split_idxs=np.array(mpc.split_idxs), switch=int(mpc.switch), pr_ref=np.copy(mpc.pr_ref),
                    iw_ref=np.copy(mpc.iw_ref), phi_current=mpc.phi_current.copy(), dphi_current=mpc.dphi_current.copy(),
                    phi_max=mpc.phi_max.copy(), slacks0=mpc.slacks0.copy(), error_count=mpc.error_count,
@@ -202,16 +244,13 @@ def main():
         trace.append(rec)
 
     node_step()       # warm-up on the trivial path
-    # plan-then-track reference: three via points, rotation about two axes, two large box sets
-    R0 = R.from_rotvec(p0[3:]).as_matrix()
-    p_via = [p0[:3].copy(), p0[:3] + np.array([0.05, -0.25, 0.10]), p0[:3] + np.array([0.15, -0.45, -0.05])]
-    r_via = [R0, R0 @ R.from_euler("xyz", [20, 0, 10], degrees=True).as_matrix(),
-             R0 @ R.from_euler("xyz", [20, 25, 10], degrees=True).as_matrix()]
-    bp1 = [np.array([0.0, 0, 1]), np.array([0.0, 0, 1])]
-    br1 = [np.array([0.0, 0, 1]), np.array([0.0, 0, 1])]
-    e_r_bound = [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(2)]
-    s0, s1 = box_set([-0.2, -0.6, 0.2], [0.8, 0.3, 0.9]), box_set([-0.1, -0.9, 0.1], [0.9, 0.0, 0.8])
-    a_sets, b_sets = [s0[0], s1[0]], [s0[1], s1[1]]
+    p_via = [p0[:3] + np.array(d, float) for d in sc["dp"]]
+    r_via = [np.array(r) for r in sc["rots"]]
+    ns = len(p_via) - 1
+    bp1 = [np.array([0.0, 0, 1]) for _ in range(ns)]
+    br1 = [np.array([0.0, 0, 1]) for _ in range(ns)]
+    e_r_bound = [ERB.copy() for _ in range(ns)]
+    a_sets, b_sets = [s[0] for s in sc["sets"]], [s[1] for s in sc["sets"]]
     via = dict(p_via=np.array(p_via), r_via=np.array(r_via), bp1=np.array(bp1), br1=np.array(br1),
                e_r_bound=np.array(e_r_bound), a_sets=np.array(a_sets), b_sets=np.array(b_sets))
     # MPCNode.update_reference (MPCNode.py:82-104)
@@ -219,21 +258,24 @@ def main():
                p0=np.copy(st["p_lie"]), params=params)
     st["qf"] = st["q"].copy()
     n_update = len(trace)
-    for _ in range(70):
+    for _ in range(sc["steps"]):
         if mpc.phi_current[0] >= mpc.phi_max[0] - 0.001:
             break
         node_step()
     keys = sorted(trace[0].keys())
-    out = {k: np.array([t[k] for t in trace]) for k in keys if k != "err_e_r_par"}
+    out = {k: np.array([t[k] for t in trace]) for k in keys}
     out["n_update"] = n_update
     out["N"] = N
     out["weights"] = params.weights
     out.update({"via_" + k: v for k, v in via.items()})
-    np.savez_compressed(os.path.join(OUT, "closed_loop.npz"), **out)
-    print("closed_loop.npz written:", len(trace), "steps; final phi", mpc.phi_current, "/", mpc.phi_max,
-          "iters", [t["iters"] for t in trace], "switches at", [i for i, t in enumerate(trace) if t["switch"]],
-          "sectors", [int(t["sector"]) for t in trace][-1])
+    fname = "closed_loop.npz" if name == "base" else f"closed_loop_{name}.npz"
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "written:", len(trace), "steps; final phi", mpc.phi_current, "/", mpc.phi_max,
+          "iters", [int(t["iters"]) for t in trace], "switches at", [i for i, t in enumerate(trace) if t["switch"]],
+          "final sector", int(trace[-1]["sector"]), "failed steps", [i for i, t in enumerate(trace) if t["error_count"]],
+          "omega re-based at", [i for i, t in enumerate(trace) if t["patched"]])
 
 
 if __name__ == "__main__":
-    main()
+    for nm in (sys.argv[1:] or ["base", "n15", "fail", "patch"]):
+        main(nm)

@@ -52,17 +52,31 @@ class ReplaySolver:
         return dict(self._stats)
 
 
+TRACES = ["closed_loop.npz",          # N=10, 3 via points, one set switch with via-point adaptation, ends at the path end
+          "closed_loop_n15.npz",      # the reference's default horizon N=15, 5 via points: three switches, the 4-segment window of
+                                      # ReferencePath slides, phi_max > 1 (no w_phi rescale, Q10); first 60 steps
+          "closed_loop_fail.npz",     # three failed solves (two of them consecutive, across the set switch): fallback to the
+                                      # previous solution, outputs shifted by error_count columns (Q12)
+          "closed_loop_patch.npz"]    # orientation through a half turn: the rotation vector flips, the warm start's integrated
+                                      # omega is re-based (Q11)
+
+
 @pytest.fixture(scope="module")
 def golden(golden_dir):
     return np.load(os.path.join(golden_dir, "closed_loop.npz"))
+
+
+@pytest.fixture(scope="module", params=TRACES)
+def trace(request, golden_dir):
+    return np.load(os.path.join(golden_dir, request.param))
 
 
 def _fk(q, dq=None):
     return O.fk_batch(q, dq)
 
 
-def test_closed_loop_replay_matches_reference(golden):
-    g = golden
+def test_closed_loop_replay_matches_reference(trace):
+    g = trace
     N = int(g["N"])
     base = get_default_params()
     assert np.array_equal(base.weights, g["weights"])
@@ -81,7 +95,10 @@ def test_closed_loop_replay_matches_reference(golden):
             assert np.abs(getattr(node, key) - g["in_" + key][k]).max() < 1e-9, (k, key)
         traj = node.step()
         for key in ("p", "v", "q", "dq", "ddq", "dddq", "phi", "dphi"):
-            assert np.abs(traj[key] - g["traj_" + key][k]).max() < 1e-9, (k, key)
+            mine = np.asarray(traj[key])
+            ref = g["traj_" + key][k][..., :mine.shape[-1]]          # failed steps return fewer columns (Q12)
+            assert np.isfinite(ref).all() and not np.isfinite(g["traj_" + key][k][..., mine.shape[-1]:]).any(), (k, key)
+            assert np.abs(mine - ref).max() < 1e-9, (k, key)
         m = node.mpc
         assert list(m.split_idxs) == list(g["split_idxs"][k]), k
         assert int(m.switch) == int(g["switch"][k]) and m.error_count == int(g["error_count"][k]), k
@@ -93,9 +110,9 @@ def test_closed_loop_replay_matches_reference(golden):
             assert np.abs(np.asarray(mine) - g[key][k]).max() < 1e-9, (k, key)
         for key in ("q", "dq", "ddq", "jerk", "v", "qf", "p_lie"):
             assert np.abs(getattr(node, key) - g["out_" + key][k]).max() < 1e-9, (k, key)
-    # the scenario exercises a set switch with via-point adaptation and ends at the path end
-    assert g["switch"].sum() >= 1 and g["sector"][-1] == 1
-    assert node.mpc.phi_current[0] >= node.mpc.phi_max[0] - 0.001
+    # every scenario exercises a set switch with via-point adaptation
+    assert g["switch"].sum() >= 1 and g["sector"][-1] >= 1
+    assert (node.mpc.phi_current[0] >= node.mpc.phi_max[0] - 0.001) == (g["phi_current"][-1][0] >= g["phi_max"][-1][0] - 0.001)
     print("max |argument - reference argument| over the run:", solver.maxdiff)
 
 
@@ -120,7 +137,7 @@ def test_closed_loop_hip_tracks_reference_trace(golden):
                                   [e.copy() for e in g["via_e_r_bound"]], [a.copy() for a in g["via_a_sets"]],
                                   [b.copy() for b in g["via_b_sets"]], [])
         traj = node.step()
-        dmax = max(dmax, np.abs(traj["p"] - g["traj_p"][k]).max())
+        dmax = max(dmax, np.abs(traj["p"] - g["traj_p"][k][:, :traj["p"].shape[1]]).max())
         assert list(node.mpc.split_idxs) == list(g["split_idxs"][k]), k
         assert node.mpc.error_count == 0
     assert dmax < 1e-3, dmax      # task-space trajectories over 37 closed-loop steps

@@ -16,14 +16,15 @@ def _params(N):
     return Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
 
 
-def test_kernels_replay_the_reference_trace(golden_dir):
+@pytest.mark.parametrize("fixture", ["closed_loop.npz", "closed_loop_n15.npz", "closed_loop_fail.npz", "closed_loop_patch.npz"])
+def test_kernels_replay_the_reference_trace(golden_dir, fixture):
     import oracle_lib as O
     from boundplanner_amd.device_loop import DeviceLoop, state_view
     from boundplanner_amd.mpc_node import MPCNode
     from boundplanner_amd.robot_model import RobotModel
     from boundplanner_amd.solver import HipBoundMPC
     from test_closed_loop import ReplaySolver
-    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     N = int(g["N"])
     params = _params(N)
     be = HipBoundMPC(N)
@@ -73,7 +74,8 @@ def test_kernels_replay_the_reference_trace(golden_dir):
                            ("qf", "out_qf"), ("p_lie", "out_p_lie")):
                 assert np.abs(V[f][r] - np.asarray(g[key][k]).reshape(-1)).max() < 1e-9, (k, r, f)
             assert abs(log[r, loop.LOG["phi"]] - g["phi_current"][k][0]) < 1e-9
-    assert (V["phi_current"][:, 0] >= V["phi_max"][:, 0] - 0.001).all()
+    assert ((V["phi_current"][:, 0] >= V["phi_max"][:, 0] - 0.001) == (g["phi_current"][-1][0] >= g["phi_max"][-1][0] - 0.001)).all()
+    assert (V["error_count"][:, 0] == int(g["error_count"][-1])).all()
 
 
 def _scenario(be, R, N, seed):
