@@ -6,6 +6,7 @@ solver raises.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -41,6 +42,13 @@ def load_library():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        # PyTorch-ROCm wheels bundle their own HIP runtime.  If this library (linked against the system ROCm) is loaded
+        # first, a later `import torch` in the same process finds "No HIP GPUs" (measured on ROCm 7.2 + torch 2.10+rocm7.0);
+        # the other order works and both then share one runtime.  So when torch is installed it is imported first.
+        if "torch" not in sys.modules and not os.environ.get("BMPC_NO_TORCH_PRELOAD"):
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         lib.bmpc_last_error.restype = ctypes.c_char_p
         lib.bmpc_last_error.argtypes = [ctypes.c_void_p]
@@ -53,6 +61,8 @@ def load_library():
         lib.bmpc_solve_dev_async.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10
         lib.bmpc_multipliers_dev.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.bmpc_wait.argtypes = [ctypes.c_void_p]
+        lib.bmpc_stream.restype = ctypes.c_void_p
+        lib.bmpc_stream.argtypes = [ctypes.c_void_p]
         lib.bmpc_active.argtypes = [ctypes.c_void_p]
         lib.bmpc_fk.argtypes = [ctypes.c_void_p, ctypes.c_int] + [_dp] * 7
         lib.bmpc_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]

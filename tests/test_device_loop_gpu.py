@@ -266,3 +266,77 @@ def test_device_collision_sets_match_the_reference_finder(golden_dir):
     loop2.upload()
     loop2.prepare()
     assert loop2.download()["dead"][0] == 2.0
+
+
+def _config4_loop(be, q_start, fs, fg, params, rows):
+    """configs[4] rollouts `rows` on the device: start-up solve on the trivial path, then the 2-via-point plan to the goal
+    pose with the fixed workspace box as EE set."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.batch_node import BatchMPCNode
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.params import normalize_set_size
+    seed_objs = BatchMPCNode(be, q_start[rows], params)
+    loop = DeviceLoop(be, len(rows))
+    for i in range(len(rows)):
+        loop.set_rollout(i, seed_objs.mpcs[i], seed_objs.q[i], seed_objs.dq[i], seed_objs.ddq[i], seed_objs.jerk[i], seed_objs.qf[i],
+                         seed_objs.v[i], seed_objs.p_lie[i])
+    loop.upload()
+    loop.run(1, log=False)
+    V = loop.download()
+    a_ee, b_ee = scenes._box_set([-1.0, -1.0, 0.0], [1.0, 1.0, 1.2])
+    for i, r in enumerate(rows):
+        sets = normalize_set_size([[a_ee, b_ee]], 15)
+        loop.replan(i, seed_objs.mpcs[i], [V["p_lie"][i][:3].copy(), fg["ee_pos"][r].copy()], [fs["ee_rot"][r].copy(), fg["ee_rot"][r].copy()],
+                    [np.array([0.0, 0, 1])], [np.array([0.0, 0, 1])], [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180],
+                    [sets[0][0]], [sets[0][1]])
+    loop.upload()
+    return loop
+
+
+def test_config4_closed_loop_full_size():
+    """BASELINE configs[4] at its full width (4096 rollouts, N=30, warm start as the reference, SURVEY 8(d) generator, seed
+    4096) through the device-resident loop: (1) every accepted step passes the reference's acceptance test; (2) a
+    rollout's trajectory does not depend on the batch it is stepped in (the first 512 rollouts alone, bitwise);
+    (3) who reaches the path end (1024 rollouts, 110 steps).  The SURVEY generator draws goals from U(0.5 q_lim) and fixes the
+    end-effector set to the workspace box [-1,-1,0]-[1,1,1.2]; the iiwa reaches z = 1.43 there, so 49 % of the goal poses
+    lie OUTSIDE the set the end effector must stay in.  Those rollouts stop at the box (their last solve is a KKT point with
+    the set rows active: tools/closed_loop_device.py --diagnose, profiles/r02_closed_loop_diag.json) -- a property of the
+    synthetic scene, not a solver stall: rollouts whose goal is inside the box reach it."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.params import Q_LIM_LOWER, Q_LIM_UPPER
+    from boundplanner_amd.solver import HipBoundMPC
+    N, R, steps = 30, 4096, 30
+    params = _params(N)
+    be = HipBoundMPC(N, max_batch=R)
+    rng = np.random.default_rng(4096)
+    q_start, q_goal = scenes.sample_start_goal(rng, be.fk, R)
+    fs, fg = be.fk(q_start), be.fk(q_goal)
+    loop = _config4_loop(be, q_start, fs, fg, params, np.arange(R))
+    log = loop.run(steps)                                   # [steps][R][logw]
+    L = loop.LOG
+    it, st, viol, err, dead = (log[:, :, L[k]] for k in ("iters", "status", "viol", "error_count", "dead"))
+    accepted = (err == 0) & (dead == 0)
+    assert ((st[accepted] == 0) | (viol[accepted] < 1e-4)).all()
+    assert (err > 0).mean() < 0.01 and dead[-1].sum() <= 8
+    assert it[0].mean() > it[10:].mean()                     # the warm start pays: later steps are cheaper than the first
+    print(f"configs[4], 4096 rollouts x {steps} steps: mean iterations {it.mean():.1f} (first step {it[0].mean():.1f}), failed steps "
+          f"{(err > 0).mean():.4f}, frozen rollouts {int(dead[-1].sum())}")
+    # (2) sub-run
+    sub = _config4_loop(be, q_start, fs, fg, params, np.arange(512))
+    log2 = sub.run(12)
+    for k in ("q", "p_lie", "phi", "iters", "status"):
+        assert np.array_equal(log2[:, :, L[k]], log[:12, :512, L[k]]), k
+    # (3) path end: the 1024 rollouts behind the first 512, long enough for the slow ones
+    rows = np.arange(512, 1536)
+    lg = _config4_loop(be, q_start, fs, fg, params, rows).run(110, log=True)[-1]
+    reached = lg[:, L["phi"]] >= lg[:, L["phi_max"]] - 0.001
+    pg = fg["ee_pos"][rows]
+    inside = (np.abs(pg[:, :2]) < 0.98).all(axis=1) & (pg[:, 2] < 1.18) & (pg[:, 2] > 0.02)
+    far_out = pg[:, 2] > 1.25
+    q_end = lg[:, L["q"]]
+    at_limit = (np.minimum(q_end - Q_LIM_LOWER, Q_LIM_UPPER - q_end) < 2e-3).any(axis=1)
+    ok = inside & ~at_limit & (lg[:, L["dead"]] == 0)
+    print(f"  after 110 steps: at the path end {reached.mean():.3f}; goals inside the workspace box {inside.mean():.3f} -> at the end "
+          f"{reached[ok].mean():.3f} (not at a joint limit); goals above z = 1.25 ({far_out.mean():.3f}) -> at the end {reached[far_out].mean():.3f}")
+    # observed: 1.000 of the goals inside the box, 0.16 of the goals above z = 1.25 (the set rows are soft: pslack)
+    assert reached[ok].mean() > 0.99 and reached[far_out].mean() < 0.3

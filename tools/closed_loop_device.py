@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seed", type=int, default=4096)
     ap.add_argument("--scene", choices=["free", "example"], default="free", help="free: configs[4] (no obstacles); example: the 12 "
                     "boxes of the reference's example scene, starts scattered around its start configuration, its goal pose")
+    ap.add_argument("--diagnose", default=None, help="write a JSON with the classification of the rollouts that did not reach the path end")
     ap.add_argument("--groups", type=int, default=3, help="rollout groups stepped concurrently (own solver handle and stream "
                     "each): the straggler tail of one group's solve overlaps the bulk of another's")
     args = ap.parse_args()
@@ -79,6 +80,7 @@ def main():
 
     L = loop.LOG
     iters, fails, reached_at = [], [], np.full(R, -1)
+    hist = []                  # per step: phi, q, error_count, iters, status (for --diagnose)
     ms_total = ms_solve = 0.0
     t0 = time.perf_counter()
     done = 0
@@ -97,6 +99,9 @@ def main():
             log = np.concatenate(parts, axis=1)
         ms_total += max(l.ms_total for l in loops); ms_solve += max(l.ms_solve for l in loops)
         iters.append(log[:, :, L["iters"]]); fails.append(log[:, :, L["error_count"]] > 0)
+        if args.diagnose:
+            hist.append(np.concatenate((log[:, :, [L["phi"], L["phi_max"], L["error_count"], L["iters"], L["status"], L["viol"], L["dead"]]],
+                                        log[:, :, L["q"]]), axis=2))
         at_end = log[:, :, L["phi"]] >= log[:, :, L["phi_max"]] - 0.001
         for s in range(n):
             reached_at[(reached_at < 0) & at_end[s]] = done + s + 1
@@ -119,6 +124,69 @@ def main():
         "reached_end_frac": float((reached_at > 0).mean()),
         "steps_to_end_median": float(np.median(reached_at[reached_at > 0])) if (reached_at > 0).any() else None,
     }
+    if args.diagnose:
+        from boundplanner_amd.params import Q_LIM_LOWER, Q_LIM_UPPER
+        H = np.concatenate(hist)                   # [steps][R][7 + 7]
+        phi, phimax, err, its, stat, viol, deadv, q = H[:, :, 0], H[:, :, 1], H[:, :, 2], H[:, :, 3], H[:, :, 4], H[:, :, 5], H[:, :, 6], H[:, :, 7:]
+        stuck = ~(reached_at > 0)
+        last = min(50, H.shape[0] - 1)
+        prog = phi[-1] - phi[-1 - last]                                        # progress over the last 50 steps
+        at_limit = (np.minimum(q[-1] - Q_LIM_LOWER, Q_LIM_UPPER - q[-1]) < 2e-3).any(axis=1)
+        failing = (err[-last:] > 0).mean(axis=0) > 0.2
+        not_conv = (stat[-last:] != 0).mean(axis=0) > 0.2
+        frac_left = 1.0 - phi[-1] / np.maximum(phimax[-1], 1e-9)
+        cls = np.full(R, "reached", dtype=object)
+        cls[stuck] = "stalled_other"
+        cls[stuck & (prog > 2e-3)] = "still_moving"
+        cls[stuck & (prog <= 2e-3) & at_limit] = "stalled_at_joint_limit"
+        cls[stuck & (prog <= 2e-3) & ~at_limit & (failing | not_conv)] = "stalled_solver_failing"
+        cls[deadv[-1] != 0] = "dead"
+        diag = {"rollouts": R, "steps": int(H.shape[0]), "classes": {c: int((cls == c).sum()) for c in sorted(set(cls))},
+                "stuck_frac_left_quantiles": [float(x) for x in np.quantile(frac_left[stuck], [0.1, 0.5, 0.9])] if stuck.any() else None,
+                "stuck_mean_iters_last50": float(its[-last:, stuck].mean()) if stuck.any() else None,
+                "reached_mean_iters_last50": float(its[-last:, ~stuck].mean()),
+                "stuck_not_converged_frac_last50": float((stat[-last:, stuck] != 0).mean()) if stuck.any() else None,
+                "phi_decrease_events": int((np.diff(phi, axis=0) < -1e-6).sum()), "phi_decrease_max": float(-np.diff(phi, axis=0).min()),
+                "accepted_viol_max": float(viol[(err == 0) & (deadv == 0)].max()),
+                "examples": {c: [int(i) for i in np.nonzero(cls == c)[0][:5]] for c in sorted(set(cls)) if c != "reached"}}
+        # nearest joint limit of the stalled-at-limit rollouts: which joints
+        if (cls == "stalled_at_joint_limit").any():
+            sel = cls == "stalled_at_joint_limit"
+            marg = np.minimum(q[-1][sel] - Q_LIM_LOWER, Q_LIM_UPPER - q[-1][sel])
+            diag["limit_joint_hist"] = [int(x) for x in np.bincount(marg.argmin(axis=1), minlength=7)]
+        # what holds the stalled rollouts back: the multipliers of their last solve (is it a KKT point? which rows are active?)
+        if G == 1 and stuck.any():
+            import torch
+            n_w, n_g = be.n_w, be.n_g
+            dev = torch.device("cuda", 0)
+            lg = torch.empty((R, n_g), dtype=torch.float64, device=dev); lx = torch.empty((R, n_w), dtype=torch.float64, device=dev)
+            be.multipliers_dev(R, lg.data_ptr(), lx.data_ptr())
+            lg, lx = lg.cpu().numpy(), lx.cpu().numpy()
+            sol = loop.solution()
+            x0_, lbx_, ubx_, p_ = loop.problem()
+            sel = np.nonzero((cls == "stalled_other") & (sol["status"] == 0))[0]
+            g0 = 35 * (N - 1)
+            rows = lg[:, g0:g0 + 112 * (N - 1)].reshape(R, N - 1, 112)
+            groups = {"ee_set": rows[:, :, 0:15], "rot_bounds": rows[:, :, 15:21], "collision_sets": rows[:, :, 21:111], "phi_cap": rows[:, :, 111:112]}
+            act = {k: np.abs(v).reshape(R, -1).max(axis=1) for k, v in groups.items()}
+            act["terminal_rows"] = np.abs(lg[:, g0 + 112 * (N - 1):]).max(axis=1)
+            for nm, blk in (("q_bounds", 0), ("dq_bounds", 1), ("ddq_bounds", 2), ("u_bounds", 3)):
+                act[nm] = np.abs(lx[:, blk * 7 * N:(blk + 1) * 7 * N].reshape(R, 7, N)[:, :, 1:]).reshape(R, -1).max(axis=1)
+            thr = 1e-2
+            diag["stalled_other_active_rows_frac"] = {k: float((v[sel] > thr).mean()) for k, v in act.items()}
+            diag["reached_active_rows_frac"] = {k: float((v[~stuck] > thr).mean()) for k, v in act.items()}
+            diag["stalled_other_multiplier_median"] = {k: float(np.median(v[sel])) for k, v in act.items()}
+            # stationarity of the pinned full-space NLP with these multipliers on a few stalled rollouts (oracle = checker)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            res = []
+            for i in sel[:6]:
+                _, _, gr, J = O.nlp_eval(N, sol["x"][i], p_[i])
+                res.append(float(np.abs(gr + J.T @ lg[i] + lx[i]).max()))
+            diag["stalled_other_kkt_stationarity_residual"] = res
+            diag["stalled_other_final_speed_max"] = float(np.abs(sol["x"][sel][:, 7 * N + 1:14 * N:N]).max())
+        json.dump(diag, open(args.diagnose, "w"), indent=1)
+        print(json.dumps(diag), file=sys.stderr)
     print(json.dumps(out))
 
 
