@@ -64,12 +64,12 @@ struct InitVisitor {
         th += fabs(h + t); ls += log(t);
         if (!valid) return;
         size_t o = (size_t)s * A->NP + pi;
-        A->t_t[o] = t; A->z[o] = 1.0; A->dzr[o] = 0.0;
+        A->t[o] = t; A->t_t[o] = t; A->z[o] = 1.0; A->dzr[o] = 0.0;
     }
     BMPC_INL void skip(int s) {
         if (!valid) return;
         size_t o = (size_t)s * A->NP + pi;
-        A->t_t[o] = 1.0; A->z[o] = 0.0; A->dzr[o] = 0.0;
+        A->t[o] = 1.0; A->t_t[o] = 1.0; A->z[o] = 0.0; A->dzr[o] = 0.0;
     }
     BMPC_INL void diag(int s, int, double, double h) { set(s, h); }
     BMPC_INL void zdiag(int s, int, double, double h) { set(s, h); }
@@ -124,7 +124,7 @@ BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
     stage_point(A, pg, iw0, k, dc, S);
     if (m.valid)
         BMPC_UNROLL
-        for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
+        for (int i = 0; i < NZ; i++) { A.zeta[(size_t)i * A.NP + m.pi] = S.zeta[i]; A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i]; }
     InitVisitor v{&A, m.pi, m.valid, 0.0, 0.0};
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, v);
     if (m.valid)
@@ -188,7 +188,7 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
     }
     BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
         size_t o = (size_t)s * A->NP + pi;
-        double t = A->t[o];          // read-only here: k_accept made t, z current (loads can run ahead)
+        double t = A->t[o];          // read-only here: the accepted trial was made current by k_rowtrial (loads can run ahead)
         zz = A->z[o];
         r1 = 1.0 / t; sg = zz * r1; r0 = sg * (h + t);
         double c = t * zz;
@@ -980,30 +980,77 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par)
 // These carry every load-modify-store on the row arrays (t, z, dt, dz_row): little register state, so
 // they run at full occupancy and hide the HBM latency that a thread-per-pair kernel cannot.
 // A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 3 * 256 doubles.
+// They also run the per-instance line-search logic: the pairs of an instance are lanes of one workgroup.
 // ------------------------------------------------------------------------------------------
 constexpr int ROW_GROUPS = 4;
 
-// k_accept: the accepted trial becomes the iterate: zeta = zeta_t, t = t_t, z += alpha_dual * dz_row
-BMPC_DEV void k_accept_body(const PipeArgs& A, int wave, int tid) {
-    const int count = A.L.cnt[0], N = A.N;
-    if (wave * ipw_of(N) >= count) return;
-    const int lane = tid & 63, g = tid >> 6;
-    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
-    if (!m.valid) return;
-    const double ad = A.st[m.b].ad;
-    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
-        size_t o = (size_t)s * A.NP + m.pi;
-        double z = A.z[o];
-        if (z > 0.0) {
-            A.t[o] = A.t_t[o];
-            if (ad != 0.0) A.z[o] = z + ad * A.dzr[o];
-        }
+// line-search start of one instance (fraction-to-boundary step lengths, merit derivative) from the per-pair partials of
+// k_step / k_rowstep, summed in pair order (fixed order -> reproducible)
+BMPC_INL void ls0_instance(const PipeArgs& A, int b) {
+    const int N = A.N;
+    GST st = A.st + b;
+    GCD P = A.part + pair_of(A, b, 1);
+    double ap = 1.0, ad = 1.0, dbar = 0, dphif = 0;
+    for (int k = 0; k < N - 1; k++) {
+        ap = fmin(ap, P[PT_AP * A.NP + k]); ad = fmin(ad, P[PT_AD * A.NP + k]);
+        dbar += P[PT_DBAR * A.NP + k]; dphif += P[PT_DPHIF * A.NP + k];
     }
-    for (int i = g; i < NZ; i += ROW_GROUPS) A.zeta[(size_t)i * A.NP + m.pi] = A.zeta_t[(size_t)i * A.NP + m.pi];
+    st->ap = ap; st->ad = ad;
+    st->D = dphif + dbar;
+    st->phi0 = st->f0 - st->mu * st->ls0;
+    if (st->it == 0) { st->theta_max = 1e4 * fmax(1.0, st->th0); st->theta_min = 1e-4 * fmax(1.0, st->th0); }
+    if (st->mu != st->filt_mu) { st->nfilt = 0; st->filt_mu = st->mu; }
+    st->alpha = ap; st->bt = 0; st->armijo = 0;
+    st->state = ST_TRIAL;
+    int pos = BMPC_ATOMIC_INC(A.L.cnt + 2);
+    A.L.trial[pos] = b;
 }
 
-// k_rowstep: dt = c - t (c from k_step), dz_row = (mu - t z - z dt) / t, fraction-to-boundary step
-// lengths and the barrier part of the merit derivative, reduced over the pair in slot-group order
+// filter acceptance test of one instance's trial point (Waechter & Biegler 2006, Sec. 2.3) from the per-pair partials of
+// k_trial / k_rowtrial; returns true when the trial becomes the iterate
+BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
+    const int N = A.N;
+    GST st = A.st + b;
+    GCD P = A.part + pair_of(A, b, 1);
+    double f1 = 0, th1 = 0, ls1 = 0;
+    for (int k = 0; k < N - 1; k++) { f1 += P[PT_F1 * A.NP + k]; th1 += P[PT_TH1 * A.NP + k]; ls1 += P[PT_LS1 * A.NP + k]; }
+    const double mu = st->mu, th0 = st->th0, D = st->D, phi0 = st->phi0, alpha = st->alpha;
+    double phi1 = f1 - mu * ls1;
+    bool acc = (th1 <= st->theta_max);
+    for (int j = 0; acc && j < st->nfilt; j++)
+        if (th1 >= st->filt_th[j] && phi1 >= st->filt_phi[j]) acc = false;
+    bool armijo_case = false;
+    if (acc) {
+        bool sw = (th0 <= st->theta_min) && (D < 0) && (alpha * pow(-D, 2.3) > pow(th0, 1.1));
+        if (sw) { acc = (phi1 <= phi0 + 1e-4 * alpha * D + 1e-12 * fabs(phi0)); armijo_case = acc; }
+        else acc = (th1 <= (1 - 1e-5) * th0) || (phi1 <= phi0 - 1e-5 * th0);
+    }
+    if (acc || st->bt >= 9) {
+        if (!armijo_case) {
+            const int MAXF = 8;
+            int nf = st->nfilt;
+            if (nf == MAXF) { for (int j = 0; j + 1 < MAXF; j++) { st->filt_th[j] = st->filt_th[j + 1]; st->filt_phi[j] = st->filt_phi[j + 1]; } nf--; }
+            st->filt_th[nf] = (1 - 1e-5) * th0;
+            st->filt_phi[nf] = phi0 - 1e-5 * th0;
+            st->nfilt = nf + 1;
+        }
+        st->f0 = f1; st->th0 = th1; st->ls0 = ls1;      // merit pieces of the accepted point
+        st->it += 1;
+        st->hess_mode = (A.o.hess == 2 && st->err_prev < A.o.hess_switch) ? 1 : 0;
+        st->state = ST_EVAL;
+        int pos = BMPC_ATOMIC_INC(A.L.cnt + 3);
+        A.L.eval_next[pos] = b;
+        return true;
+    }
+    st->alpha = 0.5 * alpha; st->bt += 1;
+    int pos = BMPC_ATOMIC_INC(A.L.cnt + 4);
+    A.L.trial_next[pos] = b;
+    return false;
+}
+
+// k_rowstep: dt = c - t (c from k_step), dz_row = (mu - t z - z dt) / t, fraction-to-boundary step lengths and the
+// barrier part of the merit derivative, reduced over the pair in slot-group order; then, the pairs of an instance
+// being lanes of this workgroup, the line-search start of every instance in it (what a kernel of its own did before)
 BMPC_DEV void k_rowstep_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
     const int count = A.L.cnt[1], N = A.N;
     if (wave * ipw_of(N) >= count) return;
@@ -1031,10 +1078,14 @@ BMPC_DEV void k_rowstep_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
         GD P = A.part + m.pi;
         P[PT_AP * A.NP] = (rp > 0) ? tau / rp : 1.0; P[PT_AD * A.NP] = (rd > 0) ? tau / rd : 1.0; P[PT_DBAR * A.NP] = db;
     }
+    BMPC_FENCE_SYNC();                              // the partials of every pair of the instance are visible
+    if (g == 0 && m.valid && m.k == 1) ls0_instance(A, m.b);
 }
 
-// k_rowtrial: t_t = t + alpha dt (in place over the h values k_trial left there), theta += |h + t_t|,
-// sum log t_t, reduced over the pair in slot-group order and added to k_trial's partials
+// k_rowtrial: t_t = t + alpha dt (in place over the h values k_trial left there), theta += |h + t_t|, sum log t_t,
+// reduced over the pair in slot-group order and added to k_trial's partials; then, per instance of this workgroup, the
+// filter acceptance test, and for an accepted trial the copy that makes it the iterate: t = t_t, z += alpha_dual dz_row,
+// zeta = zeta_t (rows still hot in L2; these were two more kernels and a cold re-read before)
 BMPC_DEV void k_rowtrial_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
     const int count = A.L.cnt[2], N = A.N;
     if (wave * ipw_of(N) >= count) return;
@@ -1058,6 +1109,21 @@ BMPC_DEV void k_rowtrial_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
         GD P = A.part + m.pi;
         P[PT_TH1 * A.NP] += a; P[PT_LS1 * A.NP] = b;
     }
+    if (tid < IPW_MAX) lds[512 + tid] = 0.0;       // per-instance verdicts
+    BMPC_FENCE_SYNC();
+    if (g == 0 && m.valid && m.k == 1 && ls_instance(A, m.b)) lds[512 + m.li] = 1.0;
+    BMPC_FENCE_SYNC();
+    if (!m.valid || lds[512 + m.li] == 0.0) return;
+    const double ad = A.st[m.b].ad;
+    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
+        size_t o = (size_t)s * A.NP + m.pi;
+        double z = A.z[o];
+        if (z > 0.0) {
+            A.t[o] = A.t_t[o];
+            if (ad != 0.0) A.z[o] = z + ad * A.dzr[o];
+        }
+    }
+    for (int i = g; i < NZ; i += ROW_GROUPS) A.zeta[(size_t)i * A.NP + m.pi] = A.zeta_t[(size_t)i * A.NP + m.pi];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -50,19 +50,16 @@ __global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
 }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 // streaming row kernels: 64 pairs x 4 slot groups per workgroup
-__global__ __launch_bounds__(256) void bmpc_k_accept(PipeArgsH H) { k_accept_body(DV(H), blockIdx.x, threadIdx.x); }
 __global__ __launch_bounds__(256) void bmpc_k_rowstep(PipeArgsH H) {
     __shared__ double lds[768];
     k_rowstep_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(256) void bmpc_k_rowtrial(PipeArgsH H) {
-    __shared__ double lds[512];
+    __shared__ double lds[512 + 8];
     k_rowtrial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
-__global__ __launch_bounds__(64) void bmpc_k_ls0(PipeArgsH H) { k_ls0_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
-__global__ __launch_bounds__(64) void bmpc_k_ls(PipeArgsH H) { k_ls_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_mult(PipeArgsH H) { k_mult_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
@@ -87,19 +84,16 @@ extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st) 
 
 // one super-step for at most n_act active instances; swaps the double-buffered lists in *A
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st) {
-    const int nw = waves_for(A->N, n_act), ni = (n_act + 63) / 64;
-    LAUNCH(bmpc_k_accept, nw, 256);
+    const int nw = waves_for(A->N, n_act);
     LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
     LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH(bmpc_k_rowstep, nw, 256);
-    LAUNCH(bmpc_k_ls0, ni, 64);
+    LAUNCH(bmpc_k_rowstep, nw, 256);      // + line-search start per instance
     LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH(bmpc_k_rowtrial, nw, 256);
-    LAUNCH(bmpc_k_ls, ni, 64);
+    LAUNCH(bmpc_k_rowtrial, nw, 256);     // + filter test per instance, accepted trials become the iterate
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
     t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;

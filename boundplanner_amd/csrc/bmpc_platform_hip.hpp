@@ -7,6 +7,8 @@
 #define BMPC_DEV __device__
 #define BMPC_INL __device__ __forceinline__
 #define BMPC_SYNC() __syncthreads()
+// barrier after which the GLOBAL-memory writes of the workgroup's threads are visible to each other
+#define BMPC_FENCE_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 #define BMPC_LANE() ((int)threadIdx.x)
 #define BMPC_BLOCK() ((int)blockIdx.x)
 #define BMPC_NBLOCKS() ((int)gridDim.x)

@@ -875,69 +875,6 @@ BMPC_DEV void k_init_fin_body(const PipeArgs& A, int b) {
     st->f0 = f1; st->th0 = th1; st->ls0 = ls1;
 }
 
-// after k_step: fraction-to-boundary step lengths, merit derivative, line-search start
-BMPC_DEV void k_ls0_body(const PipeArgs& A, int i) {
-    if (i >= A.L.cnt[1]) return;
-    const int b = A.L.step[i], N = A.N;
-    GST st = A.st + b;
-    GCD P = A.part + pair_of(A, b, 1);
-    double ap = 1.0, ad = 1.0, dbar = 0, dphif = 0;
-    for (int k = 0; k < N - 1; k++) {
-        ap = fmin(ap, P[PT_AP * A.NP + k]); ad = fmin(ad, P[PT_AD * A.NP + k]);
-        dbar += P[PT_DBAR * A.NP + k]; dphif += P[PT_DPHIF * A.NP + k];
-    }
-    st->ap = ap; st->ad = ad;
-    st->D = dphif + dbar;
-    st->phi0 = st->f0 - st->mu * st->ls0;
-    if (st->it == 0) { st->theta_max = 1e4 * fmax(1.0, st->th0); st->theta_min = 1e-4 * fmax(1.0, st->th0); }
-    if (st->mu != st->filt_mu) { st->nfilt = 0; st->filt_mu = st->mu; }
-    st->alpha = ap; st->bt = 0; st->armijo = 0;
-    st->state = ST_TRIAL;
-    int pos = BMPC_ATOMIC_INC(A.L.cnt + 2);
-    A.L.trial[pos] = b;
-}
-
-// after k_trial: filter acceptance test
-BMPC_DEV void k_ls_body(const PipeArgs& A, int i) {
-    if (i >= A.L.cnt[2]) return;
-    const int b = A.L.trial[i], N = A.N;
-    GST st = A.st + b;
-    GCD P = A.part + pair_of(A, b, 1);
-    double f1 = 0, th1 = 0, ls1 = 0;
-    for (int k = 0; k < N - 1; k++) { f1 += P[PT_F1 * A.NP + k]; th1 += P[PT_TH1 * A.NP + k]; ls1 += P[PT_LS1 * A.NP + k]; }
-    const double mu = st->mu, th0 = st->th0, D = st->D, phi0 = st->phi0, alpha = st->alpha;
-    double phi1 = f1 - mu * ls1;
-    bool acc = (th1 <= st->theta_max);
-    for (int j = 0; acc && j < st->nfilt; j++)
-        if (th1 >= st->filt_th[j] && phi1 >= st->filt_phi[j]) acc = false;
-    bool armijo_case = false;
-    if (acc) {
-        bool sw = (th0 <= st->theta_min) && (D < 0) && (alpha * pow(-D, 2.3) > pow(th0, 1.1));
-        if (sw) { acc = (phi1 <= phi0 + 1e-4 * alpha * D + 1e-12 * fabs(phi0)); armijo_case = acc; }
-        else acc = (th1 <= (1 - 1e-5) * th0) || (phi1 <= phi0 - 1e-5 * th0);
-    }
-    if (acc || st->bt >= 9) {
-        if (!armijo_case) {
-            const int MAXF = 8;
-            int nf = st->nfilt;
-            if (nf == MAXF) { for (int j = 0; j + 1 < MAXF; j++) { st->filt_th[j] = st->filt_th[j + 1]; st->filt_phi[j] = st->filt_phi[j + 1]; } nf--; }
-            st->filt_th[nf] = (1 - 1e-5) * th0;
-            st->filt_phi[nf] = phi0 - 1e-5 * th0;
-            st->nfilt = nf + 1;
-        }
-        st->f0 = f1; st->th0 = th1; st->ls0 = ls1;      // merit pieces of the accepted point
-        st->it += 1;
-        st->hess_mode = (A.o.hess == 2 && st->err_prev < A.o.hess_switch) ? 1 : 0;
-        st->state = ST_EVAL;
-        int pos = BMPC_ATOMIC_INC(A.L.cnt + 3);
-        A.L.eval_next[pos] = b;
-    } else {
-        st->alpha = 0.5 * alpha; st->bt += 1;
-        int pos = BMPC_ATOMIC_INC(A.L.cnt + 4);
-        A.L.trial_next[pos] = b;
-    }
-}
-
 // rotate the list counters between super-steps (one thread)
 BMPC_DEV void k_rotate_body(const PipeArgs& A) {
     GI c = A.L.cnt;

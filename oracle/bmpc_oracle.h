@@ -36,7 +36,7 @@ typedef struct {
     int max_iter;     /* BoundMPC.py:204 */
     int verbose;
     int hess;         /* 0 Gauss-Newton Hessian, 1 + second-order kinematic terms (default) */
-    int mu_strategy;  /* 0 LOQO adaptive, 1 monotone Fiacco-McCormick */
+    int mu_strategy;  /* 0 LOQO adaptive, 1 monotone Fiacco-McCormick (default), 2 / 3 probing (Mehrotra) rule */
     double hess_switch; /* hess==2: use second-order terms once the KKT error is below this */
     double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule (IPOPT names) */
 } bmpc_oracle_opts;

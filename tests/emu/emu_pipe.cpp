@@ -32,6 +32,7 @@ template <int NCH, int NT> static inline void bmpc_async_copy(const double* gsrc
 }
 #define BMPC_ASYNC_WAIT() do {} while (0)
 #define BMPC_SYNC() g_bar->arrive_and_wait()
+#define BMPC_FENCE_SYNC() g_bar->arrive_and_wait()
 #define BMPC_LANE() t_lane
 #define BMPC_NT 64
 #define BMPC_BLOCK() 0
@@ -98,7 +99,6 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         int nact = B - cnt[5];
         if (nact <= 0) break;
         if (verbose) printf("step %d: n_eval %d n_trial %d done %d\n", steps, cnt[0], cnt[2], cnt[5]);
-        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_accept_body(A, blk, l); }, 256);
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_points_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
@@ -106,10 +106,8 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_rowstep_body(A, blk, l, lds.data()); }, 256);
-        launch((cnt[1] + 63) / 64, [&](int blk, int l) { k_ls0_body(A, blk * 64 + l); });
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_rowtrial_body(A, blk, l, lds.data()); }, 256);
-        launch((cnt[2] + 63) / 64, [&](int blk, int l) { k_ls_body(A, blk * 64 + l); });
         k_rotate_body(A);
         std::swap(A.L.eval, A.L.eval_next);
         std::swap(A.L.trial, A.L.trial_next);
