@@ -32,7 +32,7 @@ HORIZON = 20
 BATCH_PER_GPU = 8192
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VEC_PEAK_TFLOPS = 78.6    # vector FP64 peak (spec); the binding resource of this kernel
-MAX_DISTINCT = 8               # distinct batches resident at once (231 MB each); longer runs cycle through them
+MAX_DISTINCT = 16              # distinct batches resident at once (231 MB each); longer runs cycle through them
 
 
 def alg_bytes_per_solve(N):
@@ -80,20 +80,24 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=HORIZON)
     ap.add_argument("--hess", type=int, default=None)
     ap.add_argument("--wpi", type=int, default=None, help="wavefronts per instance (1, 2, 4)")
     ap.add_argument("--bpc", type=int, default=None, help="resident workgroups per CU")
-    ap.add_argument("--depth", type=int, default=3, help="solver calls in flight (the straggler tail of one overlaps the bulk of "
-                    "the next); 1: one at a time")
-    ap.add_argument("--merge", type=int, default=2, help="batches handed to the solver per call (they are independent: "
-                    "a larger launch amortises the straggler tail over more bulk work)")
+    ap.add_argument("--depth", type=int, default=None, help="solver calls in flight (the straggler tail of one overlaps the bulk of "
+                    "the next); 1: one at a time.  Default 2 with --pool, 3 without")
+    ap.add_argument("--merge", type=int, default=2, help="--pool 0 only: batches handed to the solver per call (they are "
+                    "independent: a larger launch amortises the straggler tail over more bulk work)")
     ap.add_argument("--gate", type=float, default=1.0, help="start the next solver call when the others have < gate * their instances "
                     "active (1.0: at once)")
     ap.add_argument("--engine", type=int, default=None, help="0 pipeline (default), 1 persistent kernel")
+    ap.add_argument("--pool", type=int, default=16384, help="bmpc_opts.pool_slots: workspace slots of a solver handle.  > 0 (default): "
+                    "the timed batches are handed over in `depth` solver calls, each streaming its instances through the pool "
+                    "(a slot whose instance has finished takes the next one: one straggler tail per call, hidden behind the "
+                    "other call).  0: every call holds all its instances (`merge` batches), `depth` calls in flight")
     ap.add_argument("--same-batch", action="store_true", help="every step solves the seed-8192 batch (profiling passes)")
     ap.add_argument("--gen-workers", type=int, default=None, help="processes building problem instances (0: in this process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,9 +115,11 @@ def main():
 
     from boundplanner_amd import scenes
     N, B = args.horizon, args.batch
-    depth = max(1, min(args.depth, 4))
+    depth = max(1, min(args.depth if args.depth is not None else (2 if args.pool > 0 else 3), 4))
     M = max(1, min(args.merge, 4))
-    n_distinct = 1 if args.same_batch else min(args.steps + args.warmup, MAX_DISTINCT)
+    if args.pool > 0:
+        M = max(1, min((args.steps + depth - 1) // depth, MAX_DISTINCT))      # the timed batches in `depth` streaming calls
+    n_distinct = 1 if args.same_batch else min(max(args.steps + args.warmup, M), MAX_DISTINCT)
     n_distinct = M * ((n_distinct + M - 1) // M)
     # instance-building workers: forked BEFORE this process initialises the GPU; they never touch it
     pool = None
@@ -145,7 +151,9 @@ def main():
         kw["blocks_per_cu"] = args.bpc
     if args.engine is not None:
         kw["engine"] = args.engine
-    bes = [HipBoundMPC(N, device=local_rank, max_batch=M * B, **kw) for _ in range(depth)]
+    if args.pool > 0:
+        kw["pool_slots"] = args.pool
+    bes = [HipBoundMPC(N, device=local_rank, max_batch=min(M * B, args.pool) if args.pool > 0 else M * B, **kw) for _ in range(depth)]
     be = bes[0]
     n_w = be.n_w
     big = lambda a: np.nan_to_num(a, posinf=1e20, neginf=-1e20)
@@ -264,7 +272,7 @@ def main():
                    "batch_per_gpu": B, "horizon": N, "distinct_batches": n_distinct,
                    "sharding": "contiguous shards, no data-path collective, RCCL all-gather of x" if world > 1 else "single GPU",
                    "hess": int(be.opts.hess), "engine": int(be.opts.engine), "solver_handles_in_flight": depth,
-                   "batches_per_solver_call": M, "batches_in_flight": depth * M},
+                   "batches_per_solver_call": M, "batches_in_flight": depth * M, "pool_slots": args.pool},
         "solver": {"iters_mean": mean_it, "iters_p50": float(np.median(it_np)), "iters_p99": float(np.percentile(it_np, 99)),
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
                    "accepted_frac": float(ok.mean()), "gen_s": t_gen, "stats_of": "the step-0 batch solved alone"},

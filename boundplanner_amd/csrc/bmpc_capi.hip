@@ -22,9 +22,9 @@ extern "C" hipError_t bmpc_launch_solve_nt256(const KernelArgs* A, int nblocks, 
 extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
                                      double* ee_rot, double* col_pts, double* jac, double* dvdq, hipStream_t st);
 
-extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, int n0, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_retire(const PipeArgsH* A, int n_max, int refill, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st);
-extern "C" hipError_t bmpc_pipe_launch_out(const PipeArgsH* A, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_mult(const PipeArgsH* A, hipStream_t st);
 extern "C" void bmpc_pipe_build_table(int* tbl);
 extern "C" size_t bmpc_pipe_state_bytes(void);
@@ -41,7 +41,7 @@ struct bmpc_handle {
     int pipe_cap = 0;
     double* d_pipe = nullptr;      // one slab: SoA iterate/row arrays, stage records, gains, partials
     void* d_pipe_st = nullptr;     // InstState[cap]
-    int* d_pipe_lists = nullptr;   // 5 lists of cap ints + 8 counters
+    int* d_pipe_lists = nullptr;   // 7 lists + the slot -> row map of cap ints each + NCNT counters
     int* d_pipe_tbl = nullptr;     // scatter table of the stage record
     int* h_cnt = nullptr;          // pinned host copy of the counters
     int last_steps = 0;
@@ -81,7 +81,7 @@ static int pipe_ensure(bmpc_handle* h, int B);
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
     o->hess = 2; o->hess_switch = 0.1; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->max_batch = 0; o->blocks_per_cu = 0; o->waves_per_instance = 1; o->engine = 0;
+    o->max_batch = 0; o->blocks_per_cu = 0; o->waves_per_instance = 1; o->engine = 0; o->pool_slots = 0;
 }
 
 extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
@@ -90,6 +90,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     if (o->N < 3 || o->N > 64 || o->nr_segs != 4 || !(o->dt > 0)) return 1;
     if (o->waves_per_instance != 1 && o->waves_per_instance != 2 && o->waves_per_instance != 4) return 1;
     if (o->engine != 0 && o->engine != 1) return 1;
+    if (o->pool_slots < 0 || (o->pool_slots > 0 && o->pool_slots < 64)) return 1;
     bmpc_handle* h = new bmpc_handle();
     h->o = *o;
     h->n_w = 44 * o->N + 6;
@@ -119,7 +120,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
         bmpc_pipe_build_table(tbl.data());
         HIPCHK(h, hipMalloc((void**)&h->d_pipe_tbl, tbl.size() * sizeof(int)));
         HIPCHK(h, hipMemcpy(h->d_pipe_tbl, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(h, hipHostMalloc((void**)&h->h_cnt, 8 * sizeof(int)));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_cnt, NCNT * sizeof(int)));
     }
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
@@ -195,9 +196,13 @@ extern "C" int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg) {
 // ------------------------------------------------------------------------------------------
 // pipeline engine: workspace + launch sequence
 // ------------------------------------------------------------------------------------------
+// workspace for `B` slots; a handle created with pool_slots > 0 never holds more than that many (larger batches stream
+// through the pool, bmpc_opts.pool_slots)
 static int pipe_ensure(bmpc_handle* h, int B) {
+    if (h->o.pool_slots > 0 && B > h->o.pool_slots) B = h->o.pool_slots;
     if (B <= h->pipe_cap) return 0;
     int cap = B > h->o.max_batch ? B : h->o.max_batch;
+    if (h->o.pool_slots > 0 && cap > h->o.pool_slots) cap = h->o.pool_slots;
     if (h->d_pipe) { (void)hipFree(h->d_pipe); h->d_pipe = nullptr; }
     if (h->d_pipe_st) { (void)hipFree(h->d_pipe_st); h->d_pipe_st = nullptr; }
     if (h->d_pipe_lists) { (void)hipFree(h->d_pipe_lists); h->d_pipe_lists = nullptr; }
@@ -206,7 +211,7 @@ static int pipe_ensure(bmpc_handle* h, int B) {
     const size_t n = (3 * (size_t)NZ + 5 * (size_t)NSLOT + NPART + HREC + KREC) * NP + (size_t)cap * NX;
     HIPCHK(h, hipMalloc((void**)&h->d_pipe, n * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_pipe_st, (size_t)cap * bmpc_pipe_state_bytes()));
-    HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (5 * (size_t)cap + 8) * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (8 * (size_t)cap + NCNT) * sizeof(int)));
     h->pipe_cap = cap;
     return 0;
 }
@@ -235,36 +240,53 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.st = (InstState*)h->d_pipe_st;
     int* L = h->d_pipe_lists;
     A.L.eval = L; A.L.step = L + cap; A.L.trial = L + 2 * (size_t)cap; A.L.eval_next = L + 3 * (size_t)cap;
-    A.L.trial_next = L + 4 * (size_t)cap; A.L.cnt = L + 5 * (size_t)cap;
+    A.L.trial_next = L + 4 * (size_t)cap; A.L.done = L + 5 * (size_t)cap; A.L.admit = L + 6 * (size_t)cap;
+    A.src = L + 7 * (size_t)cap; A.L.cnt = L + 8 * (size_t)cap;
     A.tbl = h->d_pipe_tbl;
     A.prof = h->d_prof;
     A.lam_g = nullptr; A.lam_x = nullptr;
     h->last_valid = false;
-    int cnt0[8] = {B, 0, 0, 0, 0, 0, 0, 0};
+    // The workspace is a pool of `cap` slots.  B <= cap: every instance has its slot (slot = row).  B > cap (a handle
+    // created with pool_slots): the rows stream through the pool -- a slot whose instance has finished is retired
+    // (outputs written) and takes the next row at the start of the following super-step, so the kernels keep working on
+    // ~cap instances until the input runs out and only ONE straggler tail is paid for the whole call.
+    const int n0 = B < cap ? B : cap;
+    const bool streaming = B > cap;
+    int cnt0[NCNT] = {0};
+    cnt0[0] = n0; cnt0[6] = n0; cnt0[9] = n0;
     HIPCHK(h, hipMemcpyAsync(A.L.cnt, cnt0, sizeof cnt0, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipEventRecord(h->ev0, st));
-    HIPCHK(h, bmpc_pipe_launch_init(&A, st));
-    // Every instance advances one stage of its own state machine per super-step; finished
-    // instances leave the work lists.  The host only needs the number still active to size the
-    // grids (an upper bound is enough) and to stop: read back every few super-steps.
-    int n_act = B, steps = 0;
+    HIPCHK(h, bmpc_pipe_launch_init(&A, n0, st));
+    // Every instance advances one stage of its own state machine per super-step; finished instances leave the work
+    // lists.  The host only needs upper bounds of the list lengths to size the grids, and the retired count to stop:
+    // read back every few super-steps.
+    int n_act = n0, steps = 0, retired = 0, next_row = n0;
     h->n_active.store(B);
-    const int max_steps = 12 * (h->o.max_iter + 2);
-    while (n_act > 0 && steps < max_steps) {
-        int burst = steps < 8 ? 8 : 4;
-        for (int i = 0; i < burst; i++, steps++) HIPCHK(h, bmpc_pipe_launch_step(&A, n_act, st));
-        HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    const long max_steps = 12L * (h->o.max_iter + 2) * ((B + cap - 1) / cap + 1);
+    while (retired < B && steps < max_steps) {
+        const int burst = steps < 8 ? 8 : 4;
+        // while input rows are left (as far as the host knows: next_row only grows), finished instances make room before
+        // every super-step; afterwards they are retired once per burst
+        const bool rows_left = streaming && next_row < B;
+        for (int i = 0; i < burst; i++, steps++) {
+            if (rows_left && i > 0) HIPCHK(h, bmpc_pipe_launch_retire(&A, cap, 1, st));
+            HIPCHK(h, bmpc_pipe_launch_step(&A, rows_left ? cap : n_act, st));
+        }
+        HIPCHK(h, bmpc_pipe_launch_retire(&A, rows_left ? cap : n_act, rows_left ? 1 : 0, st));
+        HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
-        n_act = B - h->h_cnt[5];
-        h->n_active.store(n_act);
+        retired = h->h_cnt[7];
+        next_row = h->h_cnt[6] < B ? h->h_cnt[6] : B;
+        n_act = next_row - retired;
+        if (streaming && next_row < B) n_act = cap;
+        h->n_active.store(B - retired);
     }
     h->last_steps = steps;
-    HIPCHK(h, bmpc_pipe_launch_out(&A, st));
     HIPCHK(h, hipEventRecord(h->ev1, st));
-    // the outputs are complete and the per-handle workspace is free when the call returns: a following call on another
-    // stream must not start k_init on the workspace k_out is still reading (the loop above synchronised anyway)
+    // the outputs are complete and the per-handle workspace is free when the call returns (the loop above synchronised)
     HIPCHK(h, hipStreamSynchronize(st));
-    h->last_args = A; h->last_valid = true;
+    if (retired < B) { h->err = "pipeline did not drain (internal error)"; return 3; }
+    h->last_args = A; h->last_valid = !streaming;      // multipliers need every instance's final iterate in its slot
     return 0;
 }
 

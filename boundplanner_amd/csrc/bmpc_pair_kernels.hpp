@@ -79,16 +79,18 @@ struct InitVisitor {
     template <int C> BMPC_INL void point_end() {}
 };
 
+// over the admit list: slots that just received an instance
 BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
-    const int count = A.B, N = A.N;
+    const int count = A.L.cnt[9], N = A.N;
     if (wave * ipw_of(N) >= count) return;
-    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    PairMap m = pair_map(A, A.L.admit, count, wave, lane);
     const int k = m.k, n_w = 44 * N + 6;
     const DynC dc = make_dync(A.o.dt);
-    GCD x0 = A.x0 + (size_t)m.b * n_w;
-    GCD lbx = A.lbx + (size_t)m.b * n_w;
-    GCD ubx = A.ubx + (size_t)m.b * n_w;
-    PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds_par);
+    const size_t row = (size_t)A.src[m.b];
+    GCD x0 = A.x0 + row * n_w;
+    GCD lbx = A.lbx + row * n_w;
+    GCD ubx = A.ubx + row * n_w;
+    PGP pg = stage_params(A, A.L.admit, count, wave, lane, m, lds_par);
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
@@ -584,8 +586,8 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)m.b * n_w;
-    GCD ubx = A.ubx + (size_t)m.b * n_w;
+    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
+    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
     PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds + EM_DOUBLES + 8);
     const double ad = A.st[m.b].ad;
     double iw0[3];
@@ -853,8 +855,8 @@ BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)m.b * n_w;
-    GCD ubx = A.ubx + (size_t)m.b * n_w;
+    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
+    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
     PGP pg = stage_params(A, A.L.step, count, wave, lane, m, lds_par);
     PGP wts = pg + P_W;
     const double mu = A.st[m.b].mu;
@@ -937,8 +939,8 @@ BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par)
     const int k = m.k, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)m.b * n_w;
-    GCD ubx = A.ubx + (size_t)m.b * n_w;
+    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
+    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
     PGP pg = stage_params(A, A.L.trial, count, wave, lane, m, lds_par);
     const double alpha = A.st[m.b].alpha;
     double iw0[3];
@@ -1154,33 +1156,25 @@ struct OutVisitor {
 };
 
 BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
-    const int count = A.B, N = A.N;
+    const int count = A.L.cnt[8], N = A.N;          // the done list: instances that finished since the last retirement
     if (wave * ipw_of(N) >= count) return;
-    // all instances, in order: list-free mapping (a null list means instance = entry index)
-    PairMap m;
-    {
-        const int S_ = N - 1, ipw = ipw_of(N);
-        int li = lane / S_, kk = lane - li * S_;
-        int e = wave * ipw + li;
-        m.valid = (li < ipw) && (e < count);
-        if (!m.valid) { e = wave * ipw; kk = 0; li = 0; }
-        m.b = e; m.k = kk + 1; m.li = li; m.pi = pair_of(A, m.b, m.k);
-    }
-    PGP pg = stage_params(A, (GCI)nullptr, count, wave, lane, m, lds_par);
+    PairMap m = pair_map(A, A.L.done, count, wave, lane);
+    PGP pg = stage_params(A, A.L.done, count, wave, lane, m, lds_par);
     if (!m.valid) return;
-    const int b = m.b, k = m.k, n_w = 44 * N + 6;
+    const int k = m.k, n_w = 44 * N + 6;
+    const size_t b = (size_t)A.src[m.b];            // output row of the instance
     const bool term = (k == N - 1);
     const size_t pi = m.pi;
     const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)b * n_w;
-    GCD ubx = A.ubx + (size_t)b * n_w;
+    GCD lbx = A.lbx + b * n_w;
+    GCD ubx = A.ubx + b * n_w;
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     StagePoint S;
     load_zeta(A.zeta_t, A.NP, pi, S.zeta);     // the last evaluated point of the instance
     stage_point(A, pg, iw0, k, dc, S);
-    GD x = A.x + (size_t)b * n_w;
+    GD x = A.x + b * n_w;
     BMPC_UNROLL
     for (int j = 0; j < 7; j++) {
         x[j * N + k] = S.y[Z_Q + j]; x[7 * N + j * N + k] = S.y[Z_DQ + j];
@@ -1204,7 +1198,7 @@ BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
         BMPC_UNROLL
         for (int i = 0; i < 6; i++) x[40 * N + i] = S.y[Z_D + i];
     // violation as BoundMPC.py:613-615 (g rows only, 1e-6 dead band) and the g vector
-    GD g = A.g ? A.g + (size_t)b * (147 * (N - 1) + 21) : nullptr;
+    GD g = A.g ? A.g + b * (147 * (N - 1) + 21) : nullptr;
     OutVisitor V;
     V.viol = 0; V.gi = g ? g + 35 * (N - 1) + 112 * (k - 1) : nullptr; V.pg = pg; V.C = &S.C; V.y = S.y; V.term = term;
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
@@ -1321,12 +1315,13 @@ BMPC_DEV void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
     }
     PGP pg = stage_params(A, (GCI)nullptr, count, wave, lane, m, lds_par);
     if (!m.valid) return;
-    const int b = m.b, k = m.k, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
+    const int k = m.k, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
+    const size_t b = (size_t)A.src[m.b];
     const bool term = (k == N - 1);
     const size_t pi = m.pi;
     const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)b * n_w;
-    GCD ubx = A.ubx + (size_t)b * n_w;
+    GCD lbx = A.lbx + b * n_w;
+    GCD ubx = A.ubx + b * n_w;
     PGP wts = pg + P_W;
     double iw0[3];
     BMPC_UNROLL
@@ -1337,13 +1332,13 @@ BMPC_DEV void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
     double G[6][7], g12[12];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);
     cost_grad12(pg, S.C, term, g12);
-    GD lx = A.lam_x + (size_t)b * n_w;
+    GD lx = A.lam_x + b * n_w;
     // bound multipliers of this stage's columns start from zero (p and v are unbounded)
     BMPC_UNROLL
     for (int f = 0; f < 40; f++) lx[(size_t)f * N + k] = 0.0;
     MultVisitor V;
     V.A = &A; V.pi = pi; V.N = N; V.k = k;
-    V.lg = A.lam_g + (size_t)b * n_g + 35 * (N - 1) + 112 * (k - 1);
+    V.lg = A.lam_g + b * n_g + 35 * (N - 1) + 112 * (k - 1);
     V.lx = lx;
     V.sPS = 0; V.sRS = 0; V.z1[0] = 0; V.z1[1] = 0;
     BMPC_UNROLL

@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void bmpc_k_rowtrial(PipeArgsH H) {
     k_rowtrial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
+__global__ __launch_bounds__(64) void bmpc_k_admit(PipeArgsH H) { k_admit_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
+__global__ void bmpc_k_pool_reset(PipeArgsH H, int done_too) { if (threadIdx.x == 0 && blockIdx.x == 0) k_pool_reset_body(DV(H), done_too != 0); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
@@ -75,10 +77,26 @@ __global__ __launch_bounds__(64) void bmpc_k_fin(PipeArgsH H) { k_fin_body(DV(H)
         if ((nb) > 0) hipLaunchKernelGGL(kern, dim3(nb), dim3(nt), (lds_doubles) * sizeof(double), st, *A); \
     } while (0)
 
-extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, hipStream_t st) {
-    LAUNCH(bmpc_k_init_inst, (A->B + 63) / 64, 64);
-    LAUNCH_DYN(bmpc_k_init, waves_for(A->N, A->B), 64, pair_lds_doubles(A->N, false));
-    LAUNCH(bmpc_k_init_fin, (A->B + 63) / 64, 64);
+// first fill of the pool: n0 = min(B, slots) slots take the first n0 input rows (cnt[0] = cnt[6] = cnt[9] = n0 set by the host)
+extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, int n0, hipStream_t st) {
+    LAUNCH(bmpc_k_init_inst, (n0 + 63) / 64, 64);
+    LAUNCH_DYN(bmpc_k_init, waves_for(A->N, n0), 64, pair_lds_doubles(A->N, false));
+    LAUNCH(bmpc_k_init_fin, (n0 + 63) / 64, 64);
+    hipLaunchKernelGGL(bmpc_k_pool_reset, dim3(1), dim3(64), 0, st, *A, 0);
+    return hipGetLastError();
+}
+
+// retirement of the instances that finished (at most n_max): outputs in the reference layout, then -- while input rows are
+// left -- their slots take the next rows and are initialised.  A solve of B <= slots instances never refills.
+extern "C" hipError_t bmpc_pipe_launch_retire(const PipeArgsH* A, int n_max, int refill, hipStream_t st) {
+    LAUNCH_DYN(bmpc_k_out, waves_for(A->N, n_max), 64, pair_lds_doubles(A->N, false));
+    LAUNCH(bmpc_k_fin, (n_max + 63) / 64, 64);
+    LAUNCH(bmpc_k_admit, (n_max + 63) / 64, 64);
+    if (refill) {
+        LAUNCH_DYN(bmpc_k_init, waves_for(A->N, n_max), 64, pair_lds_doubles(A->N, false));
+        LAUNCH(bmpc_k_init_fin, (n_max + 63) / 64, 64);
+    }
+    hipLaunchKernelGGL(bmpc_k_pool_reset, dim3(1), dim3(64), 0, st, *A, 1);
     return hipGetLastError();
 }
 
@@ -97,12 +115,6 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
     t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;
-    return hipGetLastError();
-}
-
-extern "C" hipError_t bmpc_pipe_launch_out(const PipeArgsH* A, hipStream_t st) {
-    LAUNCH_DYN(bmpc_k_out, waves_for(A->N, A->B), 64, pair_lds_doubles(A->N, false));
-    LAUNCH(bmpc_k_fin, (A->B + 63) / 64, 64);
     return hipGetLastError();
 }
 

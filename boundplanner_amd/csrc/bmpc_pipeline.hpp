@@ -91,10 +91,13 @@ template <> struct PtrT<1> {
     typedef BMPC_AS1 struct InstState* S; typedef GRC RC;
 };
 
-template <int DEV> struct ListsT {           // work lists (instance ids) with their counters
+template <int DEV> struct ListsT {           // work lists (slot ids) with their counters
     typename PtrT<DEV>::I eval, step, trial, eval_next, trial_next;
-    typename PtrT<DEV>::I cnt;   // [0] n_eval [1] n_step [2] n_trial [3] n_eval_next [4] n_trial_next [5] n_done
+    typename PtrT<DEV>::I done, admit;   // slots whose instance finished (to retire) / slots that got a new instance (to initialise)
+    typename PtrT<DEV>::I cnt;   // [0] n_eval [1] n_step [2] n_trial [3] n_eval_next [4] n_trial_next [5] finished (cumulative)
+                                 // [6] next input row to admit [7] retired (cumulative) [8] n_done [9] n_admit
 };
+constexpr int NCNT = 12;
 
 template <int DEV> struct PipeArgsT {
     typedef PtrT<DEV> PT;
@@ -112,7 +115,9 @@ template <int DEV> struct PipeArgsT {
     typename PT::D krec;                 // [pairs][KREC]
     typename PT::D dx1;                  // [B][32] step of x_1 (k_ric -> k_fwd)
     typename PT::D part;                 // [NPART][NP]
-    typename PT::S st;                   // [B]
+    typename PT::S st;                   // [slots]
+    typename PT::I src;                  // [slots] input / output row of the instance in the slot (streaming: B rows
+                                         // pass through fewer slots, a slot is refilled when its instance has retired)
     ListsT<DEV> L;
     typename PT::CI tbl;                 // scatter table of the stage record (3 ints per field)
     typename PT::D prof;                 // diagnostic builds (-DBMPC_PROFILE): phase cycle sums, else unused
@@ -154,7 +159,7 @@ BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int 
     for (int li = 0; li < ipw; li++) {
         const int e = wave * ipw + li;
         if (e < count) {
-            GCD src = A.p + (size_t)(list ? list[e] : e) * NPAR;
+            GCD src = A.p + (size_t)A.src[list ? list[e] : e] * NPAR;
             for (int i = lane; i < NPAR; i += 64) lds_par[li * NPAR + i] = src[i];
         }
     }

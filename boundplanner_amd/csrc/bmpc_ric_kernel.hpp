@@ -764,7 +764,7 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
     const int N = A.N, n_w = 44 * N + 6;
     const SolverOpts& o = A.o;
     InstState* st = A.st + b;
-    const double* lbx = A.lbx + (size_t)b * n_w;
+    const double* lbx = A.lbx + (size_t)A.src[b] * n_w;
     // pinned part of x_1 and its defect
     if (lane == 0) {
         double x1fix[24];
@@ -844,6 +844,8 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
         if (status >= 0) {
             st->state = ST_DONE; st->status = status; st->fk = RL(R_park)[8];
             BMPC_ATOMIC_INC(A.L.cnt + 5);
+            int pos = BMPC_ATOMIC_INC(A.L.cnt + 8);      // to be retired (outputs written, slot refilled)
+            A.L.done[pos] = b;
         } else {
             if (tries == 0) hreg = (hreg < 1e-8) ? 0.0 : hreg / 3;
             st->hreg = hreg; st->mu = mu; st->tries = tries; st->state = ST_STEP;
@@ -856,23 +858,52 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
 // ------------------------------------------------------------------------------------------
 // per-instance control kernels (one thread per list entry)
 // ------------------------------------------------------------------------------------------
-BMPC_DEV void k_init_inst_body(const PipeArgs& A, int i) {
-    if (i >= A.B) return;
-    GST st = A.st + i;
+BMPC_INL void inst_reset(const PipeArgs& A, int slot) {
+    GST st = A.st + slot;
     st->state = ST_EVAL; st->it = 0; st->status = 1; st->nfilt = 0; st->hess_mode = 0; st->bt = 0; st->armijo = 0; st->tries = 0;
     st->mu = A.o.mu_init; st->alpha = 0; st->ad = 0; st->ap = 0; st->hreg = 0; st->err_prev = 1e300; st->filt_mu = -1;
     st->theta_max = 1e300; st->theta_min = 0; st->fk = 0;
-    A.L.eval[i] = i;
 }
 
-// after k_init: merit pieces (f, theta, sum log t) of the initial point
-BMPC_DEV void k_init_fin_body(const PipeArgs& A, int b) {
-    if (b >= A.B) return;
+// first fill of the pool: slot i takes input row i (host sets cnt[0] = cnt[9] = cnt[6] = number of slots filled)
+BMPC_DEV void k_init_inst_body(const PipeArgs& A, int i) {
+    if (i >= A.L.cnt[9]) return;
+    A.src[i] = i;
+    inst_reset(A, i);
+    A.L.eval[i] = i; A.L.admit[i] = i;
+}
+
+// retirement: every slot of the done list (its outputs have just been written by k_out / k_fin) takes the next input
+// row, if there is one, and joins the eval and admit lists (k_init then builds its first iterate)
+BMPC_DEV void k_admit_body(const PipeArgs& A, int e) {
+    if (e >= A.L.cnt[8]) return;
+    const int slot = A.L.done[e];
+    BMPC_ATOMIC_INC(A.L.cnt + 7);
+    const int row = BMPC_ATOMIC_INC(A.L.cnt + 6);
+    if (row >= A.B) return;                        // no input left: the slot stays empty
+    A.src[slot] = row;
+    inst_reset(A, slot);
+    int pos = BMPC_ATOMIC_INC(A.L.cnt + 9);
+    A.L.admit[pos] = slot;
+    pos = BMPC_ATOMIC_INC(A.L.cnt + 0);
+    A.L.eval[pos] = slot;
+}
+
+// after k_init: merit pieces (f, theta, sum log t) of the initial point (admit list)
+BMPC_DEV void k_init_fin_body(const PipeArgs& A, int e) {
+    if (e >= A.L.cnt[9]) return;
+    const int b = A.L.admit[e];
     GST st = A.st + b;
     GCD P = A.part + pair_of(A, b, 1);
     double f1 = 0, th1 = 0, ls1 = 0;
     for (int k = 0; k < A.N - 1; k++) { f1 += P[PT_F1 * A.NP + k]; th1 += P[PT_TH1 * A.NP + k]; ls1 += P[PT_LS1 * A.NP + k]; }
     st->f0 = f1; st->th0 = th1; st->ls0 = ls1;
+}
+
+// the done and admit lists have been consumed
+BMPC_DEV void k_pool_reset_body(const PipeArgs& A, bool done_too) {
+    if (done_too) A.L.cnt[8] = 0;
+    A.L.cnt[9] = 0;
 }
 
 // rotate the list counters between super-steps (one thread)
@@ -881,17 +912,19 @@ BMPC_DEV void k_rotate_body(const PipeArgs& A) {
     c[0] = c[3]; c[3] = 0; c[1] = 0; c[2] = c[4]; c[4] = 0;
 }
 
-// per-instance outputs after k_out
-BMPC_DEV void k_fin_body(const PipeArgs& A, int b) {
-    if (b >= A.B) return;
+// per-instance outputs after k_out (done list)
+BMPC_DEV void k_fin_body(const PipeArgs& A, int e) {
+    if (e >= A.L.cnt[8]) return;
+    const int b = A.L.done[e];
     const GST st = A.st + b;
     GCD P = A.part + pair_of(A, b, 1);
     double v = 0;
     for (int k = 0; k < A.N - 1; k++) v += P[PT_F1 * A.NP + k];
-    A.viol[b] = v;
-    A.f[b] = st->fk;
-    A.iters[b] = st->it;
-    A.status[b] = st->status;
+    const int row = A.src[b];
+    A.viol[row] = v;
+    A.f[row] = st->fk;
+    A.iters[row] = st->it;
+    A.status[row] = st->status;
 }
 
 // adjoint sweep of the multiplier recovery (see k_mult): one thread per instance, backwards over the stages
@@ -899,8 +932,8 @@ BMPC_DEV void k_mult_sweep_body(const PipeArgs& A, int b) {
     if (b >= A.B) return;
     const int N = A.N, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
     const double dt = A.o.dt;
-    GD lg = A.lam_g + (size_t)b * n_g;
-    GD lx = A.lam_x + (size_t)b * n_w;
+    GD lg = A.lam_g + (size_t)A.src[b] * n_g;
+    GD lx = A.lam_x + (size_t)A.src[b] * n_w;
     double lq[7], ldq[7], lddq[7], lprot[3] = {0, 0, 0}, lrs = 0, lps = 0;
     for (int j = 0; j < 7; j++) { lq[j] = 0; ldq[j] = 0; lddq[j] = 0; }
     for (int k = N - 1; k >= 1; k--) {

@@ -22,7 +22,7 @@ class BmpcOpts(ctypes.Structure):
                 ("hess", ctypes.c_int), ("hess_switch", ctypes.c_double), ("mu_init", ctypes.c_double),
                 ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
                 ("max_batch", ctypes.c_int), ("blocks_per_cu", ctypes.c_int), ("waves_per_instance", ctypes.c_int),
-                ("engine", ctypes.c_int)]
+                ("engine", ctypes.c_int), ("pool_slots", ctypes.c_int)]
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",

@@ -41,6 +41,10 @@ typedef struct {
     int waves_per_instance; /* engine 1 only: 1, 2 or 4 wavefronts sharing one LDS image */
     int engine;         /* 0 (default) batch-synchronous pipeline: thread-per-(instance,stage) evaluation kernels +
                            wavefront-per-instance LDS Riccati kernel; 1 persistent one-wavefront-per-instance kernel */
+    int pool_slots;     /* engine 0: 0 (default) = every instance of a call has its own workspace slot; > 0 = the workspace
+                           holds this many instances and a call with more of them STREAMS them through it: a slot whose
+                           instance has finished takes the next one, so a long call keeps the GPU on ~pool_slots instances
+                           and pays a single straggler tail.  Results do not depend on it (bitwise). */
 } bmpc_opts;
 
 void bmpc_default_opts(bmpc_opts* o, int N);

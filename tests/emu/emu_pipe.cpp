@@ -66,7 +66,7 @@ template <class F> static void launch(int nblocks, F body, int nt = 64) {
 extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int hess, double hess_switch, double mu_init,
                               double kappa_mu, double theta_mu, double kappa_eps, int B, const double* x0,
                               const double* lbx, const double* ubx, const double* p, double* x, double* g, double* f,
-                              int* iters, int* status, double* viol, int verbose, double* lam_g, double* lam_x) {
+                              int* iters, int* status, double* viol, int verbose, double* lam_g, double* lam_x, int slots) {
     RobotConst rc;
     fill_robot_const(rc);
     PipeArgs A;   // emulation: BMPC_AS1 is empty, host and device views coincide
@@ -75,30 +75,42 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     A.rc = &rc;
     A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.p = p;
     A.x = x; A.f = f; A.viol = viol; A.g = g; A.iters = iters; A.status = status;
-    const size_t NP = ((size_t)B * (N - 1) + 63) / 64 * 64 + 64;
+    const int cap = (slots > 0 && slots < B) ? slots : B;       // pool of `cap` slots: B > cap streams through it
+    const size_t NP = ((size_t)cap * (N - 1) + 63) / 64 * 64 + 64;
     A.NP = NP;
     std::vector<double> zeta(NZ * NP), zeta_t(NZ * NP), dz(NZ * NP), t(NSLOT * NP, 1.0), t_t(NSLOT * NP, 1.0),
-        z(NSLOT * NP), dtv(NSLOT * NP), dzr(NSLOT * NP), hrec(NP * HREC), krec(NP * KREC), part(NPART * NP), dx1v((size_t)B * NX);
-    std::vector<InstState> st(B);
-    std::vector<int> l_eval(B), l_step(B), l_trial(B), l_evn(B), l_trn(B), cnt(8, 0), tbl(3 * HREC);
+        z(NSLOT * NP), dtv(NSLOT * NP), dzr(NSLOT * NP), hrec(NP * HREC), krec(NP * KREC), part(NPART * NP), dx1v((size_t)cap * NX);
+    std::vector<InstState> st(cap);
+    std::vector<int> l_eval(cap), l_step(cap), l_trial(cap), l_evn(cap), l_trn(cap), l_done(cap), l_admit(cap), srcv(cap), cnt(NCNT, 0), tbl(3 * HREC);
     build_scatter_table(tbl.data());
     A.zeta = zeta.data(); A.zeta_t = zeta_t.data(); A.dz = dz.data();
     A.t = t.data(); A.t_t = t_t.data(); A.z = z.data(); A.dt = dtv.data(); A.dzr = dzr.data();
     A.hrec = hrec.data(); A.krec = krec.data(); A.dx1 = dx1v.data(); A.part = part.data(); A.st = st.data();
     A.L.eval = l_eval.data(); A.L.step = l_step.data(); A.L.trial = l_trial.data();
     A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
+    A.L.done = l_done.data(); A.L.admit = l_admit.data(); A.src = srcv.data();
     A.tbl = tbl.data();
     std::vector<double> lds(std::max<size_t>(pair_lds_doubles(N, true), RIC_LDS_DOUBLES) + 64);
-    const int nb_inst = (B + 63) / 64, nw = waves_for(N, B);
-    cnt[0] = B;
+    const int n0 = cap;
+    const int nb_inst = (cap + 63) / 64, nw = waves_for(N, cap);
+    cnt[0] = n0; cnt[6] = n0; cnt[9] = n0;
     launch(nb_inst, [&](int blk, int l) { k_init_inst_body(A, blk * 64 + l); });
     launch(nw, [&](int blk, int l) { k_init_body(A, blk, l, lds.data()); });
     launch(nb_inst, [&](int blk, int l) { k_init_fin_body(A, blk * 64 + l); });
+    k_pool_reset_body(A, false);
+    auto retire = [&]() {        // bmpc_pipe_launch_retire
+        launch(waves_for(N, cnt[8]), [&](int blk, int l) { k_out_body(A, blk, l, lds.data()); });
+        launch((cnt[8] + 63) / 64, [&](int blk, int l) { k_fin_body(A, blk * 64 + l); });
+        launch((cnt[8] + 63) / 64, [&](int blk, int l) { k_admit_body(A, blk * 64 + l); });
+        launch(waves_for(N, cnt[9]), [&](int blk, int l) { k_init_body(A, blk, l, lds.data()); });
+        launch((cnt[9] + 63) / 64, [&](int blk, int l) { k_init_fin_body(A, blk * 64 + l); });
+        k_pool_reset_body(A, true);
+    };
     int steps = 0;
-    for (; steps < 12 * (max_iter + 2); steps++) {
-        int nact = B - cnt[5];
-        if (nact <= 0) break;
-        if (verbose) printf("step %d: n_eval %d n_trial %d done %d\n", steps, cnt[0], cnt[2], cnt[5]);
+    for (; steps < 12 * (max_iter + 2) * ((B + cap - 1) / cap + 1); steps++) {
+        retire();
+        if (cnt[7] >= B) break;
+        if (verbose) printf("step %d: n_eval %d n_trial %d finished %d retired %d next row %d\n", steps, cnt[0], cnt[2], cnt[5], cnt[7], cnt[6]);
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_points_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
@@ -111,13 +123,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         k_rotate_body(A);
         std::swap(A.L.eval, A.L.eval_next);
         std::swap(A.L.trial, A.L.trial_next);
-        if (verbose > 1)
-            for (int b = 0; b < B; b++)
-                printf("  inst %d: state %d it %d mu %.3e alpha %.3e err_prev %.3e hm %d hreg %.1e\n", b, st[b].state, st[b].it,
-                       st[b].mu, st[b].alpha, st[b].err_prev, st[b].hess_mode, st[b].hreg);
     }
-    launch(nw, [&](int blk, int l) { k_out_body(A, blk, l, lds.data()); });
-    launch(nb_inst, [&](int blk, int l) { k_fin_body(A, blk * 64 + l); });
     if (lam_g && lam_x) {
         A.lam_g = lam_g; A.lam_x = lam_x;
         launch(nw, [&](int blk, int l) { k_mult_body(A, blk, l, lds.data()); });

@@ -22,7 +22,7 @@ def build(force=False):
 
 
 def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, hess=2, hess_switch=0.1, mu_init=0.1,
-                kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, want_g=False, verbose=0, want_lam=False):
+                kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, want_g=False, verbose=0, want_lam=False, slots=0):
     build()
     lib = ctypes.CDLL(LIB)
     n_w, n_g = 44 * N + 6, 147 * (N - 1) + 21
@@ -37,5 +37,5 @@ def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, hess=2, hess
     D = ctypes.c_double
     steps = lib.emu_pipe_solve(N, D(dt), D(tol), max_iter, hess, D(hess_switch), D(mu_init), D(kappa_mu), D(theta_mu),
                                D(kappa_eps), B, P(x0), P(lbx), P(ubx), P(p), P(x), P(g), P(f),
-                               it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), P(viol), verbose, P(lam_g), P(lam_x))
+                               it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), P(viol), verbose, P(lam_g), P(lam_x), slots)
     return dict(x=x, g=g, f=f, iters=it, status=st, viol=viol, steps=steps, lam_g=lam_g, lam_x=lam_x)

@@ -28,3 +28,15 @@ def test_emulated_pipeline_matches_oracle():
         assert np.abs(r["lam_g"][i] - rs["lam_g"]).max() < 1e-6 and np.abs(r["lam_x"][i] - rs["lam_x"]).max() < 1e-6
         _, _, gr, J = O.nlp_eval(N, r["x"][i], batch["p"][i])
         assert np.abs(gr + J.T @ r["lam_g"][i] + r["lam_x"][i]).max() < 1e-4
+
+
+def test_emulated_pool_streams_more_instances_than_slots():
+    """bmpc_opts.pool_slots: 7 instances through a pool of 3 slots (a slot whose instance has finished is retired and takes
+    the next input row) return bitwise what they return with a slot each."""
+    N, B = 6, 7
+    batch = scenes.make_batch(B, N, 9, O.fk_batch, randomize_sets=True)
+    full = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    pool = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True, slots=3)
+    for k in ("x", "g", "f", "iters", "status", "viol"):
+        assert np.array_equal(full[k], pool[k]), k
+    assert (full["status"] == 0).all() and len(set(full["iters"].tolist())) > 1      # they finish at different times

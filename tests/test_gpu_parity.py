@@ -310,6 +310,28 @@ def test_multipliers(backends, N, seed, rnd, tol, res_tol):
         be.multipliers_dev(B + 1, lg.data_ptr(), lx.data_ptr())       # no solve of that size on the handle
 
 
+def test_pool_streams_a_batch_through_fewer_slots(backends):
+    """bmpc_opts.pool_slots: 3000 instances through a pool of 512 / 1000 slots (a slot whose instance has finished is
+    retired and takes the next input row) return bitwise what they return with a slot each; multipliers, which need
+    every final iterate in the workspace, are refused for a streamed call."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N, B = 10, 3000
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 1024, be.fk, randomize_sets=True)
+    full = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    for slots in (512, 1000):
+        pool = HipBoundMPC(N, pool_slots=slots)
+        r = pool.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+        for k in ("x", "g", "f", "iters", "status", "viol"):
+            assert np.array_equal(full[k], r[k]), (slots, k)
+        with pytest.raises(RuntimeError):
+            pool.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_lam=True)
+        small = pool.solve_batch(batch["x0"][:300], batch["lbx"][:300], batch["ubx"][:300], batch["p"][:300], want_lam=True)
+        assert np.array_equal(small["x"], full["x"][:300]) and np.isfinite(small["lam_g"]).all()
+        pool.close()
+
+
 def test_hip_matches_committed_slsqp_solutions(backends, golden_dir):
     """SURVEY 8(c) bridge (ii) on the product path: the HIP solve (through the C ABI) of the committed
     N=10 instances lands on the solutions an independent SLSQP run found (tests/golden/gen/gen_slsqp.py)."""
