@@ -23,7 +23,11 @@ extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* 
                                      double* ee_rot, double* col_pts, double* jac, double* dvdq, hipStream_t st);
 
 extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, int n0, hipStream_t st);
-extern "C" hipError_t bmpc_pipe_launch_retire(const PipeArgsH* A, int n_max, int refill, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_retire_out(const PipeArgsH* A, int n_max, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_max, int refill, hipStream_t st);
+// closed loop: called between the two halves of a retirement with the list of slots whose instances have just retired
+// (device pointers: list, its length); enqueues the caller's post-processing / next-problem kernels on the stream
+typedef int (*bmpc_retire_hook)(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream);
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_mult(const PipeArgsH* A, hipStream_t st);
 extern "C" void bmpc_pipe_build_table(int* tbl);
@@ -218,7 +222,8 @@ static int pipe_ensure(bmpc_handle* h, int B) {
 
 static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
                       const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
-                      double* d_viol, hipStream_t st) {
+                      double* d_viol, hipStream_t st, bmpc_retire_hook hook = nullptr, void* hook_ctx = nullptr,
+                      const int* d_cont = nullptr) {
     int rc = pipe_ensure(h, B);
     if (rc) return rc;
     const int N = h->o.N, cap = h->pipe_cap;
@@ -245,13 +250,21 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.tbl = h->d_pipe_tbl;
     A.prof = h->d_prof;
     A.lam_g = nullptr; A.lam_x = nullptr;
+    A.cont = d_cont;
     h->last_valid = false;
+    if (hook && B > cap) { h->err = "closed-loop solve: more rollouts than workspace slots"; return 1; }
+    auto retire = [&](int n_max, int refill) -> int {
+        HIPCHK(h, bmpc_pipe_launch_retire_out(&A, n_max, st));
+        if (hook) { if (int r = hook(hook_ctx, A.L.done, A.L.cnt + 8, n_max, (void*)st)) { h->err = "retire hook failed"; return r; } }
+        HIPCHK(h, bmpc_pipe_launch_retire_admit(&A, n_max, refill, st));
+        return 0;
+    };
     // The workspace is a pool of `cap` slots.  B <= cap: every instance has its slot (slot = row).  B > cap (a handle
     // created with pool_slots): the rows stream through the pool -- a slot whose instance has finished is retired
     // (outputs written) and takes the next row at the start of the following super-step, so the kernels keep working on
     // ~cap instances until the input runs out and only ONE straggler tail is paid for the whole call.
     const int n0 = B < cap ? B : cap;
-    const bool streaming = B > cap;
+    const bool streaming = B > cap || hook != nullptr;      // slots are refilled (closed loop: with the same row's next problem)
     int cnt0[NCNT] = {0};
     cnt0[0] = n0; cnt0[6] = n0; cnt0[9] = n0;
     HIPCHK(h, hipMemcpyAsync(A.L.cnt, cnt0, sizeof cnt0, hipMemcpyHostToDevice, st));
@@ -262,23 +275,23 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     // read back every few super-steps.
     int n_act = n0, steps = 0, retired = 0, next_row = n0;
     h->n_active.store(B);
-    const long max_steps = 12L * (h->o.max_iter + 2) * ((B + cap - 1) / cap + 1);
+    const long max_steps = hook ? (1L << 40) : 12L * (h->o.max_iter + 2) * ((B + cap - 1) / cap + 1);
     while (retired < B && steps < max_steps) {
         const int burst = steps < 8 ? 8 : 4;
         // while input rows are left (as far as the host knows: next_row only grows), finished instances make room before
         // every super-step; afterwards they are retired once per burst
-        const bool rows_left = streaming && next_row < B;
+        const bool rows_left = streaming && (hook ? retired < B : next_row < B);
         for (int i = 0; i < burst; i++, steps++) {
-            if (rows_left && i > 0) HIPCHK(h, bmpc_pipe_launch_retire(&A, cap, 1, st));
+            if (rows_left && i > 0) { if (int r = retire(cap, 1)) return r; }
             HIPCHK(h, bmpc_pipe_launch_step(&A, rows_left ? cap : n_act, st));
         }
-        HIPCHK(h, bmpc_pipe_launch_retire(&A, rows_left ? cap : n_act, rows_left ? 1 : 0, st));
+        if (int r = retire(rows_left ? cap : n_act, rows_left ? 1 : 0)) return r;
         HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         retired = h->h_cnt[7];
         next_row = h->h_cnt[6] < B ? h->h_cnt[6] : B;
         n_act = next_row - retired;
-        if (streaming && next_row < B) n_act = cap;
+        if (streaming && (hook ? retired < B : next_row < B)) n_act = cap < B ? cap : B;
         h->n_active.store(B - retired);
     }
     h->last_steps = steps;
@@ -287,6 +300,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     HIPCHK(h, hipStreamSynchronize(st));
     if (retired < B) { h->err = "pipeline did not drain (internal error)"; return 3; }
     h->last_args = A; h->last_valid = !streaming;      // multipliers need every instance's final iterate in its slot
+    h->last_args.cont = nullptr;
     return 0;
 }
 
@@ -329,6 +343,19 @@ extern "C" int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const d
     if (B == 0) return 0;
     HIPCHK(h, hipSetDevice(h->o.device));
     return launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, (hipStream_t)stream);
+}
+
+// Closed loop without lock step (bmpc_loop_run_async): B rows, each a rollout whose successive problems are produced in
+// place by `hook`; a row is solved again while d_cont[row] != 0.  Internal to the library (bmpc_loop.hip).
+extern "C" int bmpc_solve_dev_hooked(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
+                                     const double* d_p, double* d_x, double* d_f, int* d_iters, int* d_status, double* d_viol,
+                                     void* stream, bmpc_retire_hook hook, void* hook_ctx, const int* d_cont) {
+    if (!h || B <= 0 || !hook || !d_cont) return 1;
+    if (h->o.engine != 0) { h->err = "bmpc_loop_run_async needs the pipeline engine"; return 1; }
+    int wrc = bmpc_wait(h);
+    if (wrc) return wrc;
+    HIPCHK(h, hipSetDevice(h->o.device));
+    return pipe_solve(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, nullptr, d_f, d_iters, d_status, d_viol, (hipStream_t)stream, hook, hook_ctx, d_cont);
 }
 
 // Asynchronous form of bmpc_solve_dev: returns at once; the data-dependent launch sequence is driven by

@@ -28,19 +28,28 @@ __global__ __launch_bounds__(256) void bmpc_loop_k_bounds(int R, int N, double* 
 
 // closest pairs collision-point segment <-> obstacle: one thread per (rollout, collision point), blockIdx.y = obstacle, so
 // that the obstacle's rows are wave-uniform (scalar loads)
-__global__ __launch_bounds__(64) void bmpc_loop_k_colpairs(int R, const RobotConst* rc, LoopScene sc, const double* S, double* colres) {
-    const int e = blockIdx.x * 64 + threadIdx.x, ob = blockIdx.y;
-    if (e >= R * 6) return;
-    const int r = e / 6, pt = e - 6 * r;
+// Every kernel below runs either over all R rollouts (list == nullptr) or over the rollouts of a device list of length
+// *n_list (bmpc_loop_run_async: the rollouts whose solve has just retired).
+#define LOOP_ROLLOUT(e, r)                                  \
+    int r = (e);                                            \
+    if (list) { if ((e) >= *n_list) return; r = list[e]; }  \
+    else if ((e) >= R) return;
+
+__global__ __launch_bounds__(64) void bmpc_loop_k_colpairs(int R, const RobotConst* rc, LoopScene sc, const double* S, double* colres,
+                                                           const int* list, const int* n_list) {
+    const int e6 = blockIdx.x * 64 + threadIdx.x, ob = blockIdx.y;
+    const int e = e6 / 6, pt = e6 - 6 * e;
+    LOOP_ROLLOUT(e, r)
     const double* s = S + (size_t)r * LS_SIZE;
     if (s[LS_dead] != 0.0) return;
-    loop_collision_pair(rc, sc, s, pt, ob, colres + ((size_t)e * sc.n_obs + ob) * LP_CRES);
+    loop_collision_pair(rc, sc, s, pt, ob, colres + (((size_t)r * 6 + pt) * sc.n_obs + ob) * LP_CRES);
 }
 
 __global__ __launch_bounds__(64) void bmpc_loop_k_prepare(int R, int N, const RobotConst* rc, double* S, const double* prev,
-                                                          double* p, double* lbx, double* ubx, LoopScene sc, const double* colres) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= R) return;
+                                                          double* p, double* lbx, double* ubx, LoopScene sc, const double* colres,
+                                                          const int* list, const int* n_list) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    LOOP_ROLLOUT(e, r)
     const size_t n_w = 44 * N + 6;
     double* s = S + (size_t)r * LS_SIZE;
     if (s[LS_dead] != 0.0) return;
@@ -48,22 +57,32 @@ __global__ __launch_bounds__(64) void bmpc_loop_k_prepare(int R, int N, const Ro
                  colres ? colres + (size_t)r * 6 * sc.n_obs * LP_CRES : nullptr);
 }
 
-__global__ __launch_bounds__(256) void bmpc_loop_k_x0(int R, int N, const double* S, const double* prev, double* x0) {
+__global__ __launch_bounds__(256) void bmpc_loop_k_x0(int R, int N, const double* S, const double* prev, double* x0,
+                                                      const int* list, const int* n_list) {
     const int n_w = 44 * N + 6;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (size_t)R * n_w) return;
-    const size_t r = e / n_w;
-    x0[e] = loop_x0_elem(N, S + r * LS_SIZE, prev + r * n_w, (int)(e - r * n_w));
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int e = (int)(idx / n_w), i = (int)(idx - (size_t)e * n_w);
+    LOOP_ROLLOUT(e, r)
+    x0[(size_t)r * n_w + i] = loop_x0_elem(N, S + (size_t)r * LS_SIZE, prev + (size_t)r * n_w, i);
 }
 
+// steps_left (bmpc_loop_run_async): per-rollout countdown; the log row of a rollout's step is (steps taken so far) * R + r,
+// cont[r] tells the solver whether the rollout has another problem coming
 __global__ __launch_bounds__(64) void bmpc_loop_k_finish(int R, int N, double dt, const RobotConst* rc, double* S, const double* x,
                                                          const double* prev, const int* status, const double* viol,
-                                                         const int* iters, double* log) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= R) return;
+                                                         const int* iters, double* log, const int* list, const int* n_list,
+                                                         int* steps_left, int* cont, int nsteps) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    LOOP_ROLLOUT(e, r)
     const size_t n_w = 44 * N + 6;
     double* s = S + (size_t)r * LS_SIZE;
     double* lg = log ? log + (size_t)r * LP_LOGW : nullptr;
+    if (steps_left) {
+        const int left = steps_left[r];
+        if (log) lg = log + ((size_t)(nsteps - left) * R + r) * LP_LOGW;
+        steps_left[r] = left - 1;
+        cont[r] = left - 1 > 0;
+    }
     if (s[LS_dead] != 0.0) {
         s[LS_accept] = 0.0;
         if (lg) { for (int i = 0; i < LP_LOGW; i++) lg[i] = 0.0; lg[4] = 1.0; }
@@ -73,11 +92,14 @@ __global__ __launch_bounds__(64) void bmpc_loop_k_finish(int R, int N, double dt
 }
 
 // prev_solution <- accepted solution (BoundMPC.py:643)
-__global__ __launch_bounds__(256) void bmpc_loop_k_keep(int R, int N, const double* S, const double* x, double* prev) {
+__global__ __launch_bounds__(256) void bmpc_loop_k_keep(int R, int N, const double* S, const double* x, double* prev,
+                                                        const int* list, const int* n_list) {
     const int n_w = 44 * N + 6;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (size_t)R * n_w) return;
-    if (S[(e / n_w) * LS_SIZE + LS_accept] != 0.0) prev[e] = x[e];
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int e = (int)(idx / n_w), i = (int)(idx - (size_t)e * n_w);
+    LOOP_ROLLOUT(e, r)
+    const size_t o = (size_t)r * n_w + i;
+    if (S[(size_t)r * LS_SIZE + LS_accept] != 0.0) prev[o] = x[o];
 }
 
 struct bmpc_loop {
@@ -92,6 +114,9 @@ struct bmpc_loop {
     double* d_scene = nullptr;     // A | b | AAt | V
     int* d_scene_i = nullptr;      // nrows | nv
     double* d_colres = nullptr;
+    int *d_steps_left = nullptr, *d_cont = nullptr;    // bmpc_loop_run_async
+    int async_nsteps = 0;
+    double* async_log = nullptr;
     size_t log_cap = 0;
     hipStream_t st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -123,6 +148,8 @@ extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
     if (L->d_scene) (void)hipFree(L->d_scene);
     if (L->d_scene_i) (void)hipFree(L->d_scene_i);
     if (L->d_colres) (void)hipFree(L->d_colres);
+    if (L->d_steps_left) (void)hipFree(L->d_steps_left);
+    if (L->d_cont) (void)hipFree(L->d_cont);
     if (L->e0) (void)hipEventDestroy(L->e0);
     if (L->e1) (void)hipEventDestroy(L->e1);
     if (L->h) bmpc_handle_release(L->h);     // a bmpc_destroy deferred because of this loop runs now
@@ -235,24 +262,28 @@ extern "C" int bmpc_loop_set_obstacles(bmpc_loop* L, int n_obs, const double* A,
     return 0;
 }
 
-static int launch_prepare(bmpc_loop* L) {
-    const size_t ne = (size_t)L->R * L->n_w;
+// n rollouts at most: all of them (list == nullptr, n == R) or those of a device list
+static int launch_prepare(bmpc_loop* L, hipStream_t st, int n, const int* list = nullptr, const int* n_list = nullptr) {
+    const size_t ne = (size_t)n * L->n_w;
     if (L->sc.n_obs > 0) {
-        hipLaunchKernelGGL(bmpc_loop_k_colpairs, dim3((L->R * 6 + 63) / 64, L->sc.n_obs), dim3(64), 0, L->st, L->R, L->d_rc, L->sc, L->d_S,
-                           L->d_colres);
+        hipLaunchKernelGGL(bmpc_loop_k_colpairs, dim3((n * 6 + 63) / 64, L->sc.n_obs), dim3(64), 0, st, L->R, L->d_rc, L->sc, L->d_S,
+                           L->d_colres, list, n_list);
     }
-    hipLaunchKernelGGL(bmpc_loop_k_prepare, dim3((L->R + 63) / 64), dim3(64), 0, L->st, L->R, L->N, L->d_rc, L->d_S, L->d_prev,
-                       L->d_p, L->d_lbx, L->d_ubx, L->sc, L->d_colres);
-    hipLaunchKernelGGL(bmpc_loop_k_x0, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, L->R, L->N, L->d_S, L->d_prev, L->d_x0);
+    hipLaunchKernelGGL(bmpc_loop_k_prepare, dim3((n + 63) / 64), dim3(64), 0, st, L->R, L->N, L->d_rc, L->d_S, L->d_prev,
+                       L->d_p, L->d_lbx, L->d_ubx, L->sc, L->d_colres, list, n_list);
+    hipLaunchKernelGGL(bmpc_loop_k_x0, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, L->R, L->N, L->d_S, L->d_prev, L->d_x0,
+                       list, n_list);
     LCHK(L, hipGetLastError());
     return 0;
 }
 
-static int launch_finish(bmpc_loop* L, double* d_log_rows) {
-    const size_t ne = (size_t)L->R * L->n_w;
-    hipLaunchKernelGGL(bmpc_loop_k_finish, dim3((L->R + 63) / 64), dim3(64), 0, L->st, L->R, L->N, L->dt, L->d_rc, L->d_S, L->d_x,
-                       L->d_prev, L->d_status, L->d_viol, L->d_iters, d_log_rows);
-    hipLaunchKernelGGL(bmpc_loop_k_keep, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, L->R, L->N, L->d_S, L->d_x, L->d_prev);
+static int launch_finish(bmpc_loop* L, hipStream_t st, int n, double* d_log_rows, const int* list = nullptr, const int* n_list = nullptr,
+                         int* steps_left = nullptr, int* cont = nullptr, int nsteps = 0) {
+    const size_t ne = (size_t)n * L->n_w;
+    hipLaunchKernelGGL(bmpc_loop_k_finish, dim3((n + 63) / 64), dim3(64), 0, st, L->R, L->N, L->dt, L->d_rc, L->d_S, L->d_x,
+                       L->d_prev, L->d_status, L->d_viol, L->d_iters, d_log_rows, list, n_list, steps_left, cont, nsteps);
+    hipLaunchKernelGGL(bmpc_loop_k_keep, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, L->R, L->N, L->d_S, L->d_x, L->d_prev,
+                       list, n_list);
     LCHK(L, hipGetLastError());
     return 0;
 }
@@ -276,7 +307,7 @@ static int do_solve(bmpc_loop* L) {
 extern "C" int bmpc_loop_prepare(bmpc_loop* L) {
     if (!L) return 1;
     LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
-    if (int rc = launch_prepare(L)) return rc;
+    if (int rc = launch_prepare(L, L->st, L->R)) return rc;
     LCHK(L, hipStreamSynchronize(L->st));
     return 0;
 }
@@ -287,7 +318,7 @@ extern "C" int bmpc_loop_finish(bmpc_loop* L, double* log) {
     if (!L) return 1;
     LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     if (log) { if (int rc = ensure_log(L, (size_t)L->R)) return rc; }
-    if (int rc = launch_finish(L, log ? L->d_log : nullptr)) return rc;
+    if (int rc = launch_finish(L, L->st, L->R, log ? L->d_log : nullptr)) return rc;
     LCHK(L, hipStreamSynchronize(L->st));
     if (log) LCHK(L, hipMemcpy(log, L->d_log, (size_t)L->R * LP_LOGW * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
@@ -300,11 +331,11 @@ extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_to
     double solve_s = 0.0;
     LCHK(L, hipEventRecord(L->e0, L->st));
     for (int s = 0; s < nsteps; s++) {
-        if (int rc = launch_prepare(L)) return rc;
+        if (int rc = launch_prepare(L, L->st, L->R)) return rc;
         auto t0 = std::chrono::steady_clock::now();
         if (int rc = do_solve(L)) return rc;
         solve_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (int rc = launch_finish(L, log ? L->d_log + (size_t)s * L->R * LP_LOGW : nullptr)) return rc;
+        if (int rc = launch_finish(L, L->st, L->R, log ? L->d_log + (size_t)s * L->R * LP_LOGW : nullptr)) return rc;
     }
     LCHK(L, hipEventRecord(L->e1, L->st));
     LCHK(L, hipStreamSynchronize(L->st));
@@ -312,6 +343,52 @@ extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_to
     LCHK(L, hipEventElapsedTime(&ms, L->e0, L->e1));
     if (ms_total) *ms_total = ms;
     if (ms_solve) *ms_solve = (float)(1e3 * solve_s);
+    if (log) LCHK(L, hipMemcpy(log, L->d_log, (size_t)nsteps * L->R * LP_LOGW * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- closed loop without lock step ---------------------------------------------------------------------------------------
+// The rollouts are independent, so nothing but convenience makes them wait for each other: here every rollout is a row of
+// ONE hooked solver call (bmpc_capi.hip).  When the solve of a rollout's current step retires, the hook below runs the
+// finish / keep / collision-pair / prepare / start-vector kernels for just those rollouts, and the solver re-admits the
+// slot with the rollout's next problem at the start of the following super-step.  The straggler tail is then paid once per
+// run instead of once per MPC step.  Per-rollout arithmetic does not depend on the schedule: the log equals bmpc_loop_run's.
+typedef int (*bmpc_retire_hook)(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream);
+extern "C" int bmpc_solve_dev_hooked(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
+                                     const double* d_p, double* d_x, double* d_f, int* d_iters, int* d_status, double* d_viol,
+                                     void* stream, bmpc_retire_hook hook, void* hook_ctx, const int* d_cont);
+
+static int loop_retire_hook(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream) {
+    bmpc_loop* L = (bmpc_loop*)ctx;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = launch_finish(L, st, n_max, L->async_log, d_done, d_n_done, L->d_steps_left, L->d_cont, L->async_nsteps)) return rc;
+    return launch_prepare(L, st, n_max, d_done, d_n_done);
+}
+
+extern "C" int bmpc_loop_run_async(bmpc_loop* L, int nsteps, double* log, float* ms_total) {
+    if (!L || nsteps <= 0) return 1;
+    LCHK(L, hipSetDevice(L->dev));
+    if (log) { if (int rc = ensure_log(L, (size_t)nsteps * L->R)) return rc; }
+    if (!L->d_steps_left) {
+        LCHK(L, hipMalloc((void**)&L->d_steps_left, (size_t)L->R * sizeof(int)));
+        LCHK(L, hipMalloc((void**)&L->d_cont, (size_t)L->R * sizeof(int)));
+    }
+    std::vector<int> left((size_t)L->R, nsteps);
+    LCHK(L, hipMemcpyAsync(L->d_steps_left, left.data(), left.size() * sizeof(int), hipMemcpyHostToDevice, L->st));
+    LCHK(L, hipMemsetAsync(L->d_cont, 0, (size_t)L->R * sizeof(int), L->st));
+    LCHK(L, hipStreamSynchronize(L->st));       // `left` goes out of scope below
+    L->async_nsteps = nsteps;
+    L->async_log = log ? L->d_log : nullptr;
+    LCHK(L, hipEventRecord(L->e0, L->st));
+    if (int rc = launch_prepare(L, L->st, L->R)) return rc;         // step 0 of every rollout
+    int rc = bmpc_solve_dev_hooked(L->h, L->R, L->d_x0, L->d_lbx, L->d_ubx, L->d_p, L->d_x, L->d_f, L->d_iters, L->d_status, L->d_viol,
+                                   (void*)L->st, loop_retire_hook, L, L->d_cont);
+    if (rc != 0) { L->err = std::string("bmpc_solve_dev_hooked: ") + bmpc_last_error(L->h); return rc; }
+    LCHK(L, hipEventRecord(L->e1, L->st));
+    LCHK(L, hipStreamSynchronize(L->st));
+    float ms = 0.f;
+    LCHK(L, hipEventElapsedTime(&ms, L->e0, L->e1));
+    if (ms_total) *ms_total = ms;
     if (log) LCHK(L, hipMemcpy(log, L->d_log, (size_t)nsteps * L->R * LP_LOGW * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }

@@ -86,11 +86,15 @@ extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, int n0, hipStrea
     return hipGetLastError();
 }
 
-// retirement of the instances that finished (at most n_max): outputs in the reference layout, then -- while input rows are
-// left -- their slots take the next rows and are initialised.  A solve of B <= slots instances never refills.
-extern "C" hipError_t bmpc_pipe_launch_retire(const PipeArgsH* A, int n_max, int refill, hipStream_t st) {
+// retirement of the instances that finished (at most n_max), first half: outputs in the reference layout
+extern "C" hipError_t bmpc_pipe_launch_retire_out(const PipeArgsH* A, int n_max, hipStream_t st) {
     LAUNCH_DYN(bmpc_k_out, waves_for(A->N, n_max), 64, pair_lds_doubles(A->N, false));
     LAUNCH(bmpc_k_fin, (n_max + 63) / 64, 64);
+    return hipGetLastError();
+}
+// second half: while input rows are left (or, closed loop, the row has its next problem ready) the slots are refilled and
+// initialised.  A solve of B <= slots instances without a retire hook never refills.
+extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_max, int refill, hipStream_t st) {
     LAUNCH(bmpc_k_admit, (n_max + 63) / 64, 64);
     if (refill) {
         LAUNCH_DYN(bmpc_k_init, waves_for(A->N, n_max), 64, pair_lds_doubles(A->N, false));

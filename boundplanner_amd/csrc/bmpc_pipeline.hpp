@@ -122,6 +122,8 @@ template <int DEV> struct PipeArgsT {
     typename PT::CI tbl;                 // scatter table of the stage record (3 ints per field)
     typename PT::D prof;                 // diagnostic builds (-DBMPC_PROFILE): phase cycle sums, else unused
     typename PT::D lam_g, lam_x;         // multiplier outputs of k_mult / k_mult_sweep ([B][n_g], [B][n_w]) or null
+    typename PT::CI cont;                // closed loop (bmpc_loop_run_async): [rows] 1 = the row has another problem ready (its slot
+                                         // is re-admitted with the same row when it retires), else null
 };
 typedef PipeArgsT<0> PipeArgsH;          // host view
 typedef PipeArgsT<1> PipeArgs;           // device view (same layout)

@@ -878,9 +878,17 @@ BMPC_DEV void k_init_inst_body(const PipeArgs& A, int i) {
 BMPC_DEV void k_admit_body(const PipeArgs& A, int e) {
     if (e >= A.L.cnt[8]) return;
     const int slot = A.L.done[e];
-    BMPC_ATOMIC_INC(A.L.cnt + 7);
-    const int row = BMPC_ATOMIC_INC(A.L.cnt + 6);
-    if (row >= A.B) return;                        // no input left: the slot stays empty
+    int row;
+    if (A.cont) {
+        // closed loop: the caller's retire hook has post-processed the solution of this row and, if the rollout goes on,
+        // prepared its next problem in place: the slot keeps its row
+        row = A.src[slot];
+        if (!A.cont[row]) { BMPC_ATOMIC_INC(A.L.cnt + 7); return; }
+    } else {
+        BMPC_ATOMIC_INC(A.L.cnt + 7);
+        row = BMPC_ATOMIC_INC(A.L.cnt + 6);
+        if (row >= A.B) return;                    // no input left: the slot stays empty
+    }
     A.src[slot] = row;
     inst_reset(A, slot);
     int pos = BMPC_ATOMIC_INC(A.L.cnt + 9);

@@ -192,6 +192,15 @@ class DeviceLoop:
         self.ms_total, self.ms_solve = mt.value, ms.value
         return out
 
+    def run_async(self, nsteps, log=True):
+        """The same `nsteps` MPC steps of every rollout without lock step: a rollout starts its next step as soon as its own
+        solve has retired (bmpc_loop_run_async).  Same log as run(), bitwise."""
+        out = np.zeros((nsteps, self.R, self.logw)) if log else None
+        mt = ctypes.c_float()
+        self._chk(self.lib.bmpc_loop_run_async(self._l, int(nsteps), self._P(out), ctypes.byref(mt)), "bmpc_loop_run_async")
+        self.ms_total, self.ms_solve = mt.value, mt.value
+        return out
+
     def prepare(self):
         self._chk(self.lib.bmpc_loop_prepare(self._l), "bmpc_loop_prepare")
 

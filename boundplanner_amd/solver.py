@@ -30,7 +30,7 @@ EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error"
            "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream",
            "bmpc_debug_phase_cycles",
            "bmpc_loop_state_doubles", "bmpc_loop_log_doubles", "bmpc_loop_field", "bmpc_loop_create", "bmpc_loop_destroy",
-           "bmpc_loop_last_error", "bmpc_loop_set_obstacles", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_prepare",
+           "bmpc_loop_last_error", "bmpc_loop_set_obstacles", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_run_async", "bmpc_loop_prepare",
            "bmpc_loop_solve", "bmpc_loop_finish", "bmpc_loop_problem", "bmpc_loop_solution", "bmpc_loop_set_solution"]
 
 _lib = None
@@ -75,6 +75,7 @@ def load_library():
         lib.bmpc_loop_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp]
         lib.bmpc_loop_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp]
         lib.bmpc_loop_run.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        lib.bmpc_loop_run_async.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_float)]
         lib.bmpc_loop_prepare.argtypes = [ctypes.c_void_p]
         lib.bmpc_loop_solve.argtypes = [ctypes.c_void_p]
         lib.bmpc_loop_finish.argtypes = [ctypes.c_void_p, _dp]

@@ -153,6 +153,10 @@ int bmpc_loop_download(bmpc_loop* l, int first, int count, double* state, double
  * viol, error_count, dead, phi, phi_max, split_idx[1], sector, switch, p_lie(6), q(7).
  * ms_total: HIP-event time of the whole run on the loop's stream; ms_solve: host time inside the solves */
 int bmpc_loop_run(bmpc_loop* l, int nsteps, double* log, float* ms_total, float* ms_solve);
+/* The same nsteps MPC steps of all rollouts WITHOUT lock step: the rollouts are independent, so each one starts its next
+ * step as soon as its own solve has retired (its workspace slot is re-admitted with the next problem, prepared on the
+ * device) instead of waiting for the slowest solve of the batch at every step.  Same log as bmpc_loop_run (bitwise). */
+int bmpc_loop_run_async(bmpc_loop* l, int nsteps, double* log, float* ms_total);
 /* the three phases of one step separately, and access to the solver arguments / solution (tests) */
 int bmpc_loop_prepare(bmpc_loop* l);
 int bmpc_loop_solve(bmpc_loop* l);

@@ -71,6 +71,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     fill_robot_const(rc);
     PipeArgs A;   // emulation: BMPC_AS1 is empty, host and device views coincide
     A.B = B; A.N = N;
+    A.lam_g = nullptr; A.lam_x = nullptr; A.cont = nullptr;
     A.o = SolverOpts{N, dt, tol, max_iter, hess, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps};
     A.rc = &rc;
     A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.p = p;

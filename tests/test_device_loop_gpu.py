@@ -340,3 +340,29 @@ def test_config4_closed_loop_full_size():
           f"{reached[ok].mean():.3f} (not at a joint limit); goals above z = 1.25 ({far_out.mean():.3f}) -> at the end {reached[far_out].mean():.3f}")
     # observed: 1.000 of the goals inside the box, 0.16 of the goals above z = 1.25 (the set rows are soft: pslack)
     assert reached[ok].mean() > 0.99 and reached[far_out].mean() < 0.3
+
+
+def test_async_closed_loop_equals_lock_step():
+    """bmpc_loop_run_async: rollouts that do not wait for each other (a rollout's slot of the solver pool is re-admitted
+    with its next problem as soon as its own solve has retired) produce, rollout by rollout and step by step, bitwise the
+    log of the lock-step loop -- with and without scene obstacles (collision sets on the device)."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N, R, steps = 10, 96, 14
+    params = _params(N)
+    be = HipBoundMPC(N, max_batch=R)
+    rng = np.random.default_rng(7)
+    q_start, q_goal = scenes.sample_start_goal(rng, be.fk, R)
+    fs, fg = be.fk(q_start), be.fk(q_goal)
+    boxes, _, _, _ = scenes.example_scene()
+    for obstacles in (None, scenes.boxes_to_sets(boxes[4:8])):
+        logs = []
+        for mode in ("run", "run_async"):
+            loop = _config4_loop(be, q_start, fs, fg, params, np.arange(R))
+            if obstacles is not None:
+                loop.set_obstacles(*obstacles)
+            logs.append(getattr(loop, mode)(steps))
+        assert np.isfinite(logs[0]).all()
+        L = loop.LOG
+        assert len(set(logs[0][:, :, L["iters"]].ravel().tolist())) > 3          # the solves do take different numbers of iterations
+        assert np.array_equal(logs[0], logs[1])

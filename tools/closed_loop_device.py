@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seed", type=int, default=4096)
     ap.add_argument("--scene", choices=["free", "example"], default="free", help="free: configs[4] (no obstacles); example: the 12 "
                     "boxes of the reference's example scene, starts scattered around its start configuration, its goal pose")
+    ap.add_argument("--async", dest="async_", action="store_true", help="rollouts do not wait for each other (bmpc_loop_run_async); one group")
     ap.add_argument("--diagnose", default=None, help="write a JSON with the classification of the rollouts that did not reach the path end")
     ap.add_argument("--groups", type=int, default=3, help="rollout groups stepped concurrently (own solver handle and stream "
                     "each): the straggler tail of one group's solve overlaps the bulk of another's")
@@ -40,7 +41,7 @@ def main():
     N, R = args.horizon, args.rollouts
     base = get_default_params()
     params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
-    G = max(1, args.groups)
+    G = 1 if args.async_ else max(1, args.groups)
     bounds = [R * g // G for g in range(G + 1)]
     bes = [HipBoundMPC(N, max_batch=bounds[g + 1] - bounds[g]) for g in range(G)]
     be = bes[0]
@@ -86,7 +87,9 @@ def main():
     done = 0
     while done < args.steps:
         n = min(args.chunk, args.steps - done)
-        if G == 1:
+        if args.async_:
+            log = loop.run_async(n)
+        elif G == 1:
             log = loop.run(n)
         else:       # one host thread per group; bmpc_loop_run releases the GIL for its whole duration
             import threading
@@ -114,7 +117,8 @@ def main():
     out = {
         "scene": args.scene,
         "config": f"BASELINE configs[4]: closed loop, {R} rollouts x {args.steps} steps, N={N}, fixed sets, warm start (reference Q11), "
-                  "device-resident loop (prepare kernel -> batched solve -> finish kernel)" + (f", {G} rollout groups in flight" if G > 1 else ""),
+                  "device-resident loop (prepare kernel -> batched solve -> finish kernel)" + (f", {G} rollout groups in flight" if G > 1 else "")
+                  + (", rollouts not in lock step (bmpc_loop_run_async)" if args.async_ else ""),
         "groups": G,
         "solves": int(R * args.steps), "wall_s": wall, "solves_per_s": R * args.steps / wall,
         "gpu_stream_ms_total": ms_total, "host_ms_inside_solves": ms_solve, "ms_per_step": 1e3 * wall / args.steps,
