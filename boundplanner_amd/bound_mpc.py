@@ -21,7 +21,8 @@ from .reference_path import ReferencePath
 
 class BoundMPC:
     def __init__(self, pos_points, rot_points, bp1, br1, e_r_bound, a_sets, b_sets, obstacles,
-                 p0=np.zeros(6), params=None, solver=None, robot_model=None):
+                 p0=np.zeros(6), params=None, solver=None, robot_model=None, robot=None):
+        self.robot = robot if robot is not None else getattr(robot_model, "robot", None)   # table of .robots, None = iiwa14
         self.N = params.n
         self.dt = params.dt
         self.nr_segs = params.nr_segs
@@ -130,7 +131,7 @@ class BoundMPC:
         if col_pts0 is None:
             col_pts0 = [self.robot_model.fk_pos_col(q0, i) for i in range(6)]
             col_ptsf = [self.robot_model.fk_pos_col(qf, i) for i in range(6)]
-        sizes = COL_JOINT_SIZES
+        sizes = COL_JOINT_SIZES if self.robot is None else self.robot["col_joint_sizes"]
         set_joints = []
         for i in range(6):
             a_c, b_c, _ = find_set_collision_avoidance(
@@ -147,7 +148,7 @@ class BoundMPC:
                              dp_normed_ref, bp1, bp2, br1, br2, e_r_bound, weights_current,
                              phi_max, v_1, v_2, v_3, self.qd, a_set, b_set, a_set_joints,
                              b_set_joints)
-        lbx, ubx = make_bounds(N, q0, dq0, ddq0, jerk_current, p0, v0)
+        lbx, ubx = make_bounds(N, q0, dq0, ddq0, jerk_current, p0, v0, robot=self.robot)
         aux = dict(e_r_bound=e_r_bound, jac_dtau_l=jac_dtau_l, jac_dtau_r=jac_dtau_r,
                    p_ref=p_ref, dp_normed_ref=dp_normed_ref, dp_ref=dp_ref,
                    phi_switch=phi_switch, bp1=bp1, bp2=bp2, br1=br1, br2=br2, v1=v_1, v2=v_2,

@@ -37,6 +37,7 @@ struct bmpc_handle {
     bmpc_opts o;
     int n_w, n_g, n_cu, nblocks_max;
     RobotConst* d_rc = nullptr;
+    bmpc_robot robot;              // host copy of the robot table behind d_rc
     double* d_ws = nullptr;
     int* d_counter = nullptr;
     double* d_prof = nullptr;   // diagnostic builds only
@@ -110,7 +111,8 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     int bpc = o->blocks_per_cu > 0 ? o->blocks_per_cu : 3;
     h->nblocks_max = h->n_cu * bpc;
     RobotConst rc;
-    fill_robot_const(rc);
+    robot_iiwa14(h->robot);
+    fill_robot_const(rc, h->robot);
     HIPCHK(h, hipMalloc((void**)&h->d_rc, sizeof(RobotConst)));
     HIPCHK(h, hipMemcpy(h->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
     h->ws_blocks = (size_t)h->nblocks_max;
@@ -172,6 +174,31 @@ extern "C" int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p) {
     if (n_w) *n_w = h->n_w;
     if (n_g) *n_g = h->n_g;
     if (n_p) *n_p = NPAR;
+    return 0;
+}
+
+extern "C" void bmpc_robot_iiwa14(bmpc_robot* r) { if (r) robot_iiwa14(*r); }
+extern "C" void bmpc_robot_gen3(bmpc_robot* r) { if (r) robot_gen3(*r); }
+
+extern "C" int bmpc_set_robot(bmpc_handle* h, const bmpc_robot* r) {
+    if (!h || !r) return 1;
+    int rc_ = bmpc_wait(h);
+    if (rc_) return rc_;
+    for (int i = 0; i < 7; i++)
+        if (!(r->q_lower[i] <= r->q_upper[i]) || !(r->dq_max[i] > 0) || !(r->col_joint_sizes[i] >= 0)) { h->err = "bmpc_set_robot: inconsistent limits"; return 1; }
+    if (!(r->ddq_max > 0) || !(r->u_max > 0)) { h->err = "bmpc_set_robot: inconsistent limits"; return 1; }
+    HIPCHK(h, hipSetDevice(h->o.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    RobotConst rc;
+    fill_robot_const(rc, *r);
+    HIPCHK(h, hipMemcpy(h->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
+    h->robot = *r;
+    h->last_valid = false;
+    return 0;
+}
+extern "C" int bmpc_get_robot(const bmpc_handle* h, bmpc_robot* r) {
+    if (!h || !r) return 1;
+    *r = h->robot;
     return 0;
 }
 

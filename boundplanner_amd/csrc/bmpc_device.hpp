@@ -57,12 +57,14 @@ struct SolverOpts {
     double hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps;
 };
 
-struct RobotConst {           // iiwa14 chain constants (iiwa.urdf), rotations precomputed on the host
+struct RobotConst {           // chain constants of the handle's robot (include/boundmpc.h bmpc_robot), rotations precomputed on the host
     double jxyz[7][3];
     double jrot[7][9];
     double ee_xyz[3];
     double ee_rot[9];
     double l4c_xyz[3];
+    // limits and collision-sphere radii: used by the device-resident loop (bounds rows, collision sets)
+    double q_lo[7], q_hi[7], dq_max[7], ddq_max, u_max, colsize[6];
 };
 
 typedef BMPC_AS1 double* GD;               // pointers into global memory (device code of the pipeline)

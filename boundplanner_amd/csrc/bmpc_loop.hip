@@ -19,11 +19,11 @@ using namespace bmpc;
 extern "C" void bmpc_handle_retain(bmpc_handle* h);
 extern "C" void bmpc_handle_release(bmpc_handle* h);
 
-__global__ __launch_bounds__(256) void bmpc_loop_k_bounds(int R, int N, double* lbx, double* ubx) {
+__global__ __launch_bounds__(256) void bmpc_loop_k_bounds(int R, int N, const RobotConst* rc, double* lbx, double* ubx) {
     const int n_w = 44 * N + 6;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (size_t)R * n_w) return;
-    loop_bound_const(N, (int)(e % n_w), lbx + e, ubx + e);
+    loop_bound_const(rc, N, (int)(e % n_w), lbx + e, ubx + e);
 }
 
 // closest pairs collision-point segment <-> obstacle: one thread per (rollout, collision point), blockIdx.y = obstacle, so
@@ -168,7 +168,9 @@ extern "C" int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out) {
     L->dev = o.device;
     LCHK(L, hipSetDevice(o.device));
     RobotConst rc;
-    fill_robot_const(rc);
+    bmpc_robot rob;
+    if (bmpc_get_robot(h, &rob) != 0) { L->err = "bmpc_get_robot failed"; return 1; }
+    fill_robot_const(rc, rob);                 // the loop works on the robot the handle has at this moment
     LCHK(L, hipMalloc((void**)&L->d_rc, sizeof(RobotConst)));
     LCHK(L, hipMemcpy(L->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
     const size_t nw = (size_t)R * L->n_w * sizeof(double);
@@ -190,7 +192,7 @@ extern "C" int bmpc_loop_create(bmpc_handle* h, int R, bmpc_loop** out) {
     LCHK(L, hipEventCreate(&L->e0));
     LCHK(L, hipEventCreate(&L->e1));
     const size_t ne = (size_t)R * L->n_w;
-    hipLaunchKernelGGL(bmpc_loop_k_bounds, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, R, L->N, L->d_lbx, L->d_ubx);
+    hipLaunchKernelGGL(bmpc_loop_k_bounds, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, L->st, R, L->N, L->d_rc, L->d_lbx, L->d_ubx);
     LCHK(L, hipGetLastError());
     LCHK(L, hipStreamSynchronize(L->st));
     return 0;

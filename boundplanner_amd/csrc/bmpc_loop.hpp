@@ -69,11 +69,7 @@ LP_FIELDS(X)
 #undef X
 constexpr int LS_SIZE = (ls_off(LF_COUNT) + 7) / 8 * 8;
 
-// robot limits (iiwa.urdf <limit>, RobotModel.py:44-54, BoundMPC.py:171-191)
-constexpr double LP_QLIM[7] = {2.9670597283903604, 2.0943951023931953, 2.9670597283903604, 2.0943951023931953,
-                               2.9670597283903604, 2.0943951023931953, 3.0543261909900763};
-constexpr double LP_DQLIM = 10.0, LP_DDQLIM = 5.0, LP_UMAX = 35.0;
-constexpr double LP_COLSIZE[6] = {0.09, 0.12, 0.09, 0.10, 0.07, 0.09};   // RobotModel.py:37 (index 6 unused)
+// robot limits and collision-sphere radii (URDF <limit>, RobotModel.py:37-54, BoundMPC.py:171-191): RobotConst
 
 // ---- SO(3) helpers (conventions of scipy.spatial.transform.Rotation, which the reference calls) ----
 BMPC_INL void lp_quat_to_mat(const double* q, double* R) {
@@ -542,7 +538,7 @@ BMPC_DEV void loop_prepare(const RobotConst* rc, int N, double* S, const double*
         }
         for (int c = 0; c < 3; c++)
             for (int r = 0; r < LP_ROWS; r++) p[P_ASETJ + 45 * j + LP_ROWS * c + r] = (r < n) ? a[r][c] : 0.0;
-        for (int r = 0; r < LP_ROWS; r++) p[P_BSETJ + 6 * r + j] = (r < n) ? b[r] - LP_COLSIZE[j] : 10.0;
+        for (int r = 0; r < LP_ROWS; r++) p[P_BSETJ + 6 * r + j] = (r < n) ? b[r] - rc->colsize[j] : 10.0;
     }
 
     // stage-0 pins (BoundMPC.py:544-580, Q7): x[0:-1:N] = value on the joint-major arrays
@@ -559,12 +555,12 @@ BMPC_DEV void loop_prepare(const RobotConst* rc, int N, double* S, const double*
 }
 
 // constant part of the bounds (BoundMPC.py:171-191, 544-589); infinities as +-1e20
-BMPC_INL void loop_bound_const(int N, int i, double* lo, double* hi) {
+BMPC_INL void loop_bound_const(const RobotConst* rc, int N, int i, double* lo, double* hi) {
     double l = 0.0, h = 1e20;
-    if (i < 7 * N) { h = LP_QLIM[i / N]; l = -h; }
-    else if (i < 14 * N) { h = LP_DQLIM; l = -h; }
-    else if (i < 21 * N) { h = LP_DDQLIM; l = -h; }
-    else if (i < 28 * N) { h = LP_UMAX; l = -h; }
+    if (i < 7 * N) { h = rc->q_hi[i / N]; l = rc->q_lo[i / N]; }
+    else if (i < 14 * N) { h = rc->dq_max[(i - 7 * N) / N]; l = -h; }
+    else if (i < 21 * N) { h = rc->ddq_max; l = -h; }
+    else if (i < 28 * N) { h = rc->u_max; l = -h; }
     else if (i < 40 * N) { h = 1e20; l = -1e20; }
     *lo = l; *hi = h;
 }

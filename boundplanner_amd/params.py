@@ -85,13 +85,20 @@ def pack_params(split_idxs, slacks0, iw_ref, dtau_init, dtau_init_par, dtau_init
     return out
 
 
-def make_bounds(N, q0, dq0, ddq0, jerk0, p0, v0):
-    """lbx/ubx of BoundMPC.py:544-589: limits, stage 0 pinned, slacks >= 0."""
+def make_bounds(N, q0, dq0, ddq0, jerk0, p0, v0, robot=None):
+    """lbx/ubx of BoundMPC.py:544-589: limits, stage 0 pinned, slacks >= 0.  robot: a table of boundplanner_amd.robots
+    (None = iiwa14); infinite joint limits (+-1e20 in a table) become +-inf like the reference's (RobotModel.py:46-48)."""
     inf = np.inf
-    lo = [np.repeat(Q_LIM_LOWER, N), np.repeat(-DQ_LIM, N), -DDQ_LIM * np.ones(7 * N),
-          -U_MAX * np.ones(7 * N), -inf * np.ones(6 * N), -inf * np.ones(6 * N)]
-    hi = [np.repeat(Q_LIM_UPPER, N), np.repeat(DQ_LIM, N), DDQ_LIM * np.ones(7 * N),
-          U_MAX * np.ones(7 * N), inf * np.ones(6 * N), inf * np.ones(6 * N)]
+    if robot is None:
+        ql, qh, dqm, ddqm, um = Q_LIM_LOWER, Q_LIM_UPPER, DQ_LIM, DDQ_LIM, U_MAX
+    else:
+        ql = np.where(np.asarray(robot["q_lower"], float) <= -1e19, -inf, np.asarray(robot["q_lower"], float))
+        qh = np.where(np.asarray(robot["q_upper"], float) >= 1e19, inf, np.asarray(robot["q_upper"], float))
+        dqm, ddqm, um = np.asarray(robot["dq_max"], float), robot["ddq_max"], robot["u_max"]
+    lo = [np.repeat(ql, N), np.repeat(-dqm, N), -ddqm * np.ones(7 * N),
+          -um * np.ones(7 * N), -inf * np.ones(6 * N), -inf * np.ones(6 * N)]
+    hi = [np.repeat(qh, N), np.repeat(dqm, N), ddqm * np.ones(7 * N),
+          um * np.ones(7 * N), inf * np.ones(6 * N), inf * np.ones(6 * N)]
     for arr_l, arr_h, val in zip(lo, hi, (q0, dq0, ddq0, jerk0, p0, v0)):
         arr_l[0:-1:N] = val      # Q7: x[0:-1:N] = value on joint-major arrays
         arr_h[0:-1:N] = val

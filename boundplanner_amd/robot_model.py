@@ -12,14 +12,23 @@ from .params import COL_JOINT_SIZES, DQ_LIM, Q_LIM_LOWER, Q_LIM_UPPER, U_MAX
 
 
 class RobotModel:
-    def __init__(self, fk_fn=None):
+    def __init__(self, fk_fn=None, robot=None):
+        """robot: table of boundplanner_amd.robots (None = iiwa14, RobotModel.py:10 USE_IIWA = True); `fk_fn` must have been
+        given the same table (HipBoundMPC(N, robot=...).fk)."""
         if fk_fn is None:
             from .solver import default_fk_fn  # raises loudly when the HIP library is missing
             fk_fn = default_fk_fn()
         self._fk = fk_fn
-        self.col_joint_sizes = list(COL_JOINT_SIZES)
-        self.q_lim_lower, self.q_lim_upper = Q_LIM_LOWER.copy(), Q_LIM_UPPER.copy()
-        self.dq_lim_lower, self.dq_lim_upper = -DQ_LIM.copy(), DQ_LIM.copy()
+        self.robot = robot
+        if robot is None:
+            self.col_joint_sizes = list(COL_JOINT_SIZES)
+            self.q_lim_lower, self.q_lim_upper = Q_LIM_LOWER.copy(), Q_LIM_UPPER.copy()
+            self.dq_lim_lower, self.dq_lim_upper = -DQ_LIM.copy(), DQ_LIM.copy()
+        else:
+            self.col_joint_sizes = list(robot["col_joint_sizes"])
+            ql, qh = np.asarray(robot["q_lower"], float), np.asarray(robot["q_upper"], float)
+            self.q_lim_lower, self.q_lim_upper = np.where(ql <= -1e19, -np.inf, ql), np.where(qh >= 1e19, np.inf, qh)
+            self.dq_lim_lower, self.dq_lim_upper = -np.asarray(robot["dq_max"], float), np.asarray(robot["dq_max"], float)
         self.tau_lim_lower = [-320, -320, -176, -176, -110, -40, -40]
         self.tau_lim_upper = [320, 320, 176, 176, 110, 40, 40]
         self.u_max, self.u_min = U_MAX, -U_MAX

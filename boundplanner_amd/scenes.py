@@ -29,14 +29,17 @@ def _rand_unit(rng):
     return v / np.linalg.norm(v)
 
 
-def sample_start_goal(rng, fk_batch, n):
+def sample_start_goal(rng, fk_batch, n, robot=None):
     """q_start, q_goal ~ U(0.5 q_lo, 0.5 q_hi); reject collision points below z=0.05 or
-    start/goal closer than 0.1 m."""
+    start/goal closer than 0.1 m.  robot: table of .robots (None = iiwa14); unlimited joints are drawn from +-pi/2."""
+    lo, hi = Q_LIM_LOWER, Q_LIM_UPPER
+    if robot is not None:
+        lo = np.maximum(np.asarray(robot["q_lower"], float), -np.pi); hi = np.minimum(np.asarray(robot["q_upper"], float), np.pi)
     qs, qg = [], []
     while len(qs) < n:
         m = max(64, 2 * (n - len(qs)))
-        a = rng.uniform(0.5 * Q_LIM_LOWER, 0.5 * Q_LIM_UPPER, size=(m, 7))
-        b = rng.uniform(0.5 * Q_LIM_LOWER, 0.5 * Q_LIM_UPPER, size=(m, 7))
+        a = rng.uniform(0.5 * lo, 0.5 * hi, size=(m, 7))
+        b = rng.uniform(0.5 * lo, 0.5 * hi, size=(m, 7))
         fa, fb = fk_batch(a), fk_batch(b)
         ok = (fa["col_pts"][:, :, 2].min(axis=1) >= 0.05) & (fb["col_pts"][:, :, 2].min(axis=1) >= 0.05)
         ok &= (fa["ee_pos"][:, 2] >= 0.05) & (fb["ee_pos"][:, 2] >= 0.05)
@@ -55,13 +58,13 @@ def _build_instance(args):
     """Deterministic part of one instance (no random draws, no kinematics calls): the reference's seeding sequence
     BoundMPC() -> update() -> step() preparation on a 2-via-point path.  Runs in a worker process when make_batch is
     given a pool.  Returns (x0, lbx, ubx, p, mpc)."""
-    N, dt, q0, p0, p1, rot0, rot1, col0, a_ee, b_ee, aj_extra, bj_extra, keep_mpc = args
+    N, dt, q0, p0, p1, rot0, rot1, col0, a_ee, b_ee, aj_extra, bj_extra, keep_mpc, robot = args
     base = get_default_params()
     prm = Params(n=N, dt=dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
     sets = normalize_set_size([[a_ee, b_ee]], 15)
     mpc = BoundMPC([p0[:3].copy(), p0[:3].copy()], [rot0.copy(), rot0.copy()],
                    [np.array([1.0, 0.0, 0.0])], [np.array([1.0, 0.0, 0.0])], [_ERB.copy()],
-                   [np.zeros((15, 3))], [np.ones(15)], [], p0=p0, params=prm)
+                   [np.zeros((15, 3))], [np.ones(15)], [], p0=p0, params=prm, robot=robot)
     mpc.update([p0[:3].copy(), p1.copy()], [rot0.copy(), rot1.copy()],
                [np.array([0.0, 0.0, 1.0])], [np.array([0.0, 0.0, 1.0])], [_ERB.copy()],
                [sets[0][0]], [sets[0][1]], [], np.zeros(6), p0=p0, params=prm)
@@ -80,14 +83,15 @@ def _build_instance(args):
     return w0, lbx, ubx, p, (mpc if keep_mpc else None)
 
 
-def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1, pool=None):
+def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1, pool=None, robot=None):
     """Returns dict with x0, lbx, ubx, p ([B, n] float64, row-major per instance) + the state
     needed to drive closed loops.  All random draws happen here, in instance order, from one PCG64 stream; the
     per-instance host construction (1.3 ms of Python each) is deterministic given the draws and is mapped over
     `pool` (a multiprocessing pool of processes that never touch the GPU) when one is given -- same result, and
     `mpcs` is then not returned."""
     rng = np.random.default_rng(seed)
-    q_start, q_goal = sample_start_goal(rng, fk_batch, B)
+    sizes = COL_JOINT_SIZES if robot is None else robot["col_joint_sizes"]
+    q_start, q_goal = sample_start_goal(rng, fk_batch, B, robot)
     fs, fg = fk_batch(q_start), fk_batch(q_goal)
     n_w = 44 * N + 6
     out = {k: np.zeros((B, n_w)) for k in ("x0", "lbx", "ubx")}
@@ -117,10 +121,10 @@ def make_batch(B, N, seed, fk_batch, randomize_sets=False, dt=0.1, pool=None):
                 for r in range(k):
                     a = _rand_unit(rng)
                     ra[r] = a
-                    rb[r] = a @ col0[i] + rng.uniform(0.05, 0.4) - COL_JOINT_SIZES[i]
+                    rb[r] = a @ col0[i] + rng.uniform(0.05, 0.4) - sizes[i]
                 aj_extra.append(ra); bj_extra.append(rb)
         jobs.append((N, dt, q_start[b], p0, p1, fs["ee_rot"][b], fg["ee_rot"][b], col0, a_ee, b_ee, aj_extra, bj_extra,
-                     pool is None))
+                     pool is None, robot))
     res = map(_build_instance, jobs) if pool is None else pool.imap(_build_instance, jobs, chunksize=64)
     mpcs = []
     for b, (w0, lbx, ubx, p, mpc) in enumerate(res):

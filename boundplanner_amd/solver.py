@@ -27,7 +27,7 @@ class BmpcOpts(ctypes.Structure):
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
            "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_solve_dev_async", "bmpc_multipliers_dev", "bmpc_wait", "bmpc_active", "bmpc_fk",
-           "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream",
+           "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream", "bmpc_robot_iiwa14", "bmpc_robot_gen3", "bmpc_set_robot", "bmpc_get_robot",
            "bmpc_debug_phase_cycles",
            "bmpc_loop_state_doubles", "bmpc_loop_log_doubles", "bmpc_loop_field", "bmpc_loop_create", "bmpc_loop_destroy",
            "bmpc_loop_last_error", "bmpc_loop_set_obstacles", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_run_async", "bmpc_loop_prepare",
@@ -61,6 +61,8 @@ def load_library():
         lib.bmpc_solve_dev_async.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10
         lib.bmpc_multipliers_dev.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.bmpc_wait.argtypes = [ctypes.c_void_p]
+        lib.bmpc_set_robot.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.bmpc_get_robot.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.bmpc_stream.restype = ctypes.c_void_p
         lib.bmpc_stream.argtypes = [ctypes.c_void_p]
         lib.bmpc_active.argtypes = [ctypes.c_void_p]
@@ -93,7 +95,8 @@ def _P(a):
 class HipBoundMPC:
     """Owner of one C handle: batched solves + batched kinematics on one MI355X."""
 
-    def __init__(self, N, dt=0.1, tol=1e-5, max_iter=100, device=0, **kw):
+    def __init__(self, N, dt=0.1, tol=1e-5, max_iter=100, device=0, robot=None, **kw):
+        """robot: None (iiwa14), "iiwa14", "gen3" or a table of boundplanner_amd.robots"""
         lib = load_library()
         o = BmpcOpts()
         lib.bmpc_default_opts(ctypes.byref(o), N)
@@ -111,6 +114,18 @@ class HipBoundMPC:
         self.n_w, self.n_g, self.n_p = nw.value, ng.value, npar.value
         self.lbg, self.ubg = np.zeros(self.n_g), np.zeros(self.n_g)
         lib.bmpc_gbounds(self._h, _P(self.lbg), _P(self.ubg))
+        from . import robots
+        self.robot = robots.IIWA14
+        if robot is not None:
+            self.set_robot(robot)
+
+    def set_robot(self, robot):
+        """Kinematic table, limits and collision-sphere radii of the handle (bmpc_set_robot)."""
+        from . import robots
+        table = {"iiwa14": robots.IIWA14, "gen3": robots.GEN3}[robot] if isinstance(robot, str) else robot
+        r = robots.to_struct(table)
+        self._chk(self.lib.bmpc_set_robot(self._h, ctypes.byref(r)), "bmpc_set_robot")
+        self.robot = table
 
     def close(self):
         if getattr(self, "_h", None):

@@ -49,6 +49,22 @@ typedef struct {
 
 void bmpc_default_opts(bmpc_opts* o, int N);
 
+/* Kinematic table of a 7-joint serial arm in the frame conventions of RobotModel.py:15-54: revolute joints about their
+ * local z axes with the URDF <origin xyz rpy> of joint_1..joint_7 (fixed rotation R = Rz(yaw) Ry(pitch) Rx(roll)), the fixed
+ * joints to end_effector_link and link4_col_link (child of joint_4's link), URDF limits, BoundMPC.py:171-191 acceleration /
+ * jerk limits and the collision-sphere radii col_joint_sizes (RobotModel.py:37-40).  The six collision points are the
+ * origins of joint_3..joint_7 and link4_col_link (RobotModel.py:27-35).  Infinite joint limits: +-1e20. */
+typedef struct {
+    double joint_xyz[7][3], joint_rpy[7][3];
+    double ee_xyz[3], ee_rpy[3];
+    double link4_col_xyz[3];
+    double q_lower[7], q_upper[7], dq_max[7];
+    double ddq_max, u_max;
+    double col_joint_sizes[7];
+} bmpc_robot;
+void bmpc_robot_iiwa14(bmpc_robot* r);   /* RobotModel/iiwa.urdf (USE_IIWA = True, the default; RobotModel.py:10) */
+void bmpc_robot_gen3(bmpc_robot* r);     /* RobotModel/gen3_arm.urdf (USE_IIWA = False): Kinova Gen3, joints 1/3/5/7 unlimited */
+
 /* replaces setup_optimization_problem(...) + nlpsol construction (BoundMPC.py:240-246) */
 int bmpc_create(const bmpc_opts* o, bmpc_handle** h);
 void bmpc_destroy(bmpc_handle* h);
@@ -59,6 +75,10 @@ int bmpc_dims(const bmpc_handle* h, int* n_w, int* n_g, int* n_p);
 
 /* the handle's own HIP stream (a hipStream_t): the one bmpc_solve, bmpc_solve_dev_async and the device loop run on */
 void* bmpc_stream(bmpc_handle* h);
+
+/* Robot of the handle (default: iiwa14).  bmpc_set_robot must precede the solves / device loops that are to use it. */
+int bmpc_set_robot(bmpc_handle* h, const bmpc_robot* r);
+int bmpc_get_robot(const bmpc_handle* h, bmpc_robot* r);
 
 /* the options the handle was created with */
 int bmpc_get_opts(const bmpc_handle* h, bmpc_opts* o);

@@ -13,15 +13,34 @@
 #define PI_1 3.141592653589793
 
 /* joint_1..joint_7 <origin xyz rpy> (iiwa.urdf:25,40,55,70,85,107,122) */
-static const double JXYZ[7][3] = {{0, 0, 0.1525}, {0, 0, 0.2075}, {0, 0.2325, 0}, {0, 0, 0.1875},
+static double JXYZ[7][3] = {{0, 0, 0.1525}, {0, 0, 0.2075}, {0, 0.2325, 0}, {0, 0, 0.1875},
                                   {0, 0.2125, 0}, {0, 0, 0.1875}, {0, 0.0796, 0}};
-static const double JRPY[7][3] = {{0, 0, 0},        {PI_2, 0, PI_1}, {PI_2, 0, PI_1}, {PI_2, 0, 0},
+static double JRPY[7][3] = {{0, 0, 0},        {PI_2, 0, PI_1}, {PI_2, 0, PI_1}, {PI_2, 0, 0},
                                   {-PI_2, PI_1, 0}, {PI_2, 0, 0},    {-PI_2, PI_1, 0}};
 /* joint_ee (iiwa.urdf:137): rpy is literally -1.575 (not -pi/2) */
-static const double EE_XYZ[3] = {0, 0, 0.21};
-static const double EE_RPY[3] = {0, -1.575, -1.575};
+static double EE_XYZ[3] = {0, 0, 0.21};
+static double EE_RPY[3] = {0, -1.575, -1.575};
 /* link4_col (iiwa.urdf:91) */
-static const double L4C_XYZ[3] = {0, 0.3, 0};
+static double L4C_XYZ[3] = {0, 0.3, 0};
+
+/* another 7-joint arm with the same frame conventions (the reference's USE_IIWA = False branch, RobotModel.py:10-48: the
+ * Kinova Gen3 of gen3_arm.urdf): process-wide, set before solving; NULL restores the iiwa14 */
+void bmpc_oracle_set_robot(const double* joint_xyz21, const double* joint_rpy21, const double* ee_xyz, const double* ee_rpy,
+                           const double* link4_col_xyz) {
+    static const double X0[7][3] = {{0, 0, 0.1525}, {0, 0, 0.2075}, {0, 0.2325, 0}, {0, 0, 0.1875}, {0, 0.2125, 0}, {0, 0, 0.1875}, {0, 0.0796, 0}};
+    static const double R0[7][3] = {{0, 0, 0}, {PI_2, 0, PI_1}, {PI_2, 0, PI_1}, {PI_2, 0, 0}, {-PI_2, PI_1, 0}, {PI_2, 0, 0}, {-PI_2, PI_1, 0}};
+    static const double E0[3] = {0, 0, 0.21}, ER0[3] = {0, -1.575, -1.575}, L0[3] = {0, 0.3, 0};
+    for (int i = 0; i < 7; i++)
+        for (int a = 0; a < 3; a++) {
+            JXYZ[i][a] = joint_xyz21 ? joint_xyz21[3 * i + a] : X0[i][a];
+            JRPY[i][a] = joint_rpy21 ? joint_rpy21[3 * i + a] : R0[i][a];
+        }
+    for (int a = 0; a < 3; a++) {
+        EE_XYZ[a] = joint_xyz21 ? ee_xyz[a] : E0[a];
+        EE_RPY[a] = joint_xyz21 ? ee_rpy[a] : ER0[a];
+        L4C_XYZ[a] = joint_xyz21 ? link4_col_xyz[a] : L0[a];
+    }
+}
 
 const int BMPC_COL_NJ[6] = {2, 3, 4, 5, 6, 4};
 

@@ -52,6 +52,11 @@ void bmpc_oracle_dims(int N, int* n_w, int* n_g, int* n_p);
 void bmpc_oracle_fk(const double* q, const double* dq, double* ee_pos, double* ee_rot,
                     double* col_pts, double* jac, double* dvdq);
 
+/* Kinematic table of another 7-joint arm (RobotModel.py:10-48, USE_IIWA = False: gen3_arm.urdf): joint <origin xyz> [7][3] and
+ * <origin rpy> [7][3], the fixed joints to end_effector_link and link4_col_link.  Process-wide; NULL restores the iiwa14. */
+void bmpc_oracle_set_robot(const double* joint_xyz21, const double* joint_rpy21, const double* ee_xyz, const double* ee_rpy,
+                           const double* link4_col_xyz);
+
 /* Full-space NLP functions in the reference's layout (casadi_ocp_formulation.py:89-101,
  * 383-417).  Any output pointer may be NULL.  jac_g is dense row-major n_g x n_w. */
 int bmpc_oracle_eval(int N, double dt, const double* w, const double* p, double* f, double* g,

@@ -32,7 +32,7 @@ extern "C" void emu_loop_prepare(int N, double* S, const double* prev, double* x
     RobotConst rc;
     fill_robot_const(rc);
     const int n_w = 44 * N + 6;
-    for (int i = 0; i < n_w; i++) loop_bound_const(N, i, lbx + i, ubx + i);
+    for (int i = 0; i < n_w; i++) loop_bound_const(&rc, N, i, lbx + i, ubx + i);
     loop_prepare(&rc, N, S, prev, p, lbx, ubx);
     for (int i = 0; i < n_w; i++) x0[i] = loop_x0_elem(N, S, prev, i);
 }
@@ -57,7 +57,7 @@ extern "C" void emu_loop_prepare_obs(int N, double* S, const double* prev, doubl
     LoopScene sc{n_obs, A, b, AAt.data(), nrows, V, nv, box.data(), is_box.data()};
     for (int pt = 0; pt < 6; pt++)
         for (int ob = 0; ob < n_obs; ob++) loop_collision_pair(&rc, sc, S, pt, ob, colres.data() + (size_t)(pt * n_obs + ob) * LP_CRES);
-    for (int i = 0; i < n_w; i++) loop_bound_const(N, i, lbx + i, ubx + i);
+    for (int i = 0; i < n_w; i++) loop_bound_const(&rc, N, i, lbx + i, ubx + i);
     loop_prepare(&rc, N, S, prev, p, lbx, ubx, &sc, colres.data());
     for (int i = 0; i < n_w; i++) x0[i] = loop_x0_elem(N, S, prev, i);
 }

@@ -36,6 +36,16 @@ def lib():
     return _lib
 
 
+def set_robot(table=None):
+    """table: boundplanner_amd.robots table (dict) or None for the iiwa14 -- process-wide."""
+    if table is None:
+        lib().bmpc_oracle_set_robot(None, None, None, None, None)
+        return
+    a = lambda k: np.ascontiguousarray(table[k], float)
+    xyz, rpy, ee, eer, l4 = a("joint_xyz"), a("joint_rpy"), a("ee_xyz"), a("ee_rpy"), a("link4_col_xyz")
+    lib().bmpc_oracle_set_robot(_P(xyz), _P(rpy), _P(ee), _P(eer), _P(l4))
+
+
 def fk_batch(q, dq=None):
     q = np.ascontiguousarray(q, float).reshape(-1, 7)
     dq = np.zeros_like(q) if dq is None else np.ascontiguousarray(dq, float).reshape(-1, 7)

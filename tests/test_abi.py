@@ -11,7 +11,7 @@ def test_exports_match_header():
     import __graft_entry__ as ge
     ge.build()
     hdr = open(os.path.join(ROOT, "include", "boundmpc.h")).read()
-    declared = set(re.findall(r"\b(bmpc_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(bmpc_[a-z0-9_]+)\s*\(", hdr))
     lib = solver.load_library()
     for name in declared:
         assert hasattr(lib, name), name
