@@ -106,7 +106,20 @@ class OracleSolver:
         return self._stats
 
 
-def make_ref_mpc(pos_points, rot_points, bp1, br1, e_r_bound, a_sets, b_sets, p0, params, solver, robot):
+def reference_finder(boxes):
+    """The reference's own ConvexSetFinder on box obstacles, its qpOASES slot filled by an exact QP solver (gen_colsets.py)."""
+    from bound_planner.BoundPlanner.ConvexSetFinder import ConvexSetFinder
+    from bound_planner.utils import normalize_set_size
+    from boundplanner_amd import scenes
+    from gen_colsets import ExactQP
+    sets, pts = scenes.boxes_to_sets(boxes)
+    obs_sets = normalize_set_size([[a.copy(), b.copy()] for a, b in sets], 15)
+    f = ConvexSetFinder(obs_sets, pts, np.array([1.0, 0.38, 1.0]), np.array([-0.14, -1.0, 0.0]))
+    f.projl_solver = ExactQP()
+    return f
+
+
+def make_ref_mpc(pos_points, rot_points, bp1, br1, e_r_bound, a_sets, b_sets, p0, params, solver, robot, finder=None):
     """A reference BoundMPC object with the state its __init__ sets up (BoundMPC.py:28-265), minus the
     CasADi/IPOPT solver build, the Pinocchio model and the planner's cvxpy/cdd machinery."""
     from bound_planner.ReferencePath import ReferencePath
@@ -160,8 +173,9 @@ def make_ref_mpc(pos_points, rot_points, bp1, br1, e_r_bound, a_sets, b_sets, p0
     m.solver = solver
     lb, ub = O.gbounds(m.N)
     m.lbg, m.ubg = lb, ub
-    finder = types.SimpleNamespace(find_set_collision_avoidance=lambda pl, pf, limit_space=True, e_max=0.7:
-                                   find_set_collision_avoidance([], [], np.asarray(pl), np.asarray(pf), e_max=e_max))
+    if finder is None:
+        finder = types.SimpleNamespace(find_set_collision_avoidance=lambda pl, pf, limit_space=True, e_max=0.7:
+                                       find_set_collision_avoidance([], [], np.asarray(pl), np.asarray(pf), e_max=e_max))
     m.planner = types.SimpleNamespace(set_finder=finder, add_obstacle_reps=lambda *a, **k: None)
     return m
 
@@ -198,6 +212,16 @@ def scenario(name, p0):
         dp = [[0, 0, 0], [0.05, -0.20, 0.05], [0.10, -0.40, 0.0]]
         rots = [R0, rot(0, 0, 55), rot(0, 0, 110)]
         return dict(N=10, dp=dp, rots=rots, sets=big * 2, steps=50, fail_calls=())
+    if name == "scene":
+        # BASELINE configs[0]: the reference's example scene (boundplanner_with_mpc_example.py:19-100: start configuration, goal
+        # position, workspace, 12 box obstacles), its default horizon; the per-step collision sets come from the reference's
+        # own ConvexSetFinder (a10 inside the loop).  The via path is hand-authored (the plan phase is not built).
+        from boundplanner_amd import scenes
+        boxes, _, goal_p, _ = scenes.example_scene()
+        dp = [[0, 0, 0], [0.05, -0.25, 0.10], (goal_p - p0[:3]).tolist()]
+        rots = [R0, rot(20, 0, 10), rot(20, 25, 10)]
+        ws = [box_set([-0.14, -1.0, 0.0], [1.0, 0.38, 1.0])]
+        return dict(N=15, dp=dp, rots=rots, sets=ws * 2, steps=45, fail_calls=(), boxes=boxes)
     raise KeyError(name)
 
 
@@ -210,9 +234,10 @@ def main(name):
     N = sc["N"]
     params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
     solver = OracleSolver(N, sc["fail_calls"])
+    finder = reference_finder(sc["boxes"]) if "boxes" in sc else None
     # start-up problem of MPCNode.reset (MPCNode.py:44-80) + the warm-up step of the example
     mpc = make_ref_mpc([p0[:3]] * 2, [R.from_rotvec(p0[3:]).as_matrix()] * 2, [np.array([1.0, 0, 0])],
-                       [np.array([1.0, 0, 0])], [ERB.copy()], [np.zeros((15, 3))], [np.ones(15)], p0, params, solver, robot)
+                       [np.array([1.0, 0, 0])], [ERB.copy()], [np.zeros((15, 3))], [np.ones(15)], p0, params, solver, robot, finder)
     st = dict(q=q0.copy(), qf=q0.copy(), dq=np.zeros(7), ddq=np.zeros(7), jerk=np.zeros(7), p_lie=p0.copy(), v=np.zeros(6))
     trace = []
 
@@ -268,6 +293,8 @@ def main(name):
     out["N"] = N
     out["weights"] = params.weights
     out.update({"via_" + k: v for k, v in via.items()})
+    if "boxes" in sc:
+        out["boxes"] = sc["boxes"]
     fname = "closed_loop.npz" if name == "base" else f"closed_loop_{name}.npz"
     np.savez_compressed(os.path.join(OUT, fname), **out)
     print(fname, "written:", len(trace), "steps; final phi", mpc.phi_current, "/", mpc.phi_max,
@@ -277,5 +304,6 @@ def main(name):
 
 
 if __name__ == "__main__":
-    for nm in (sys.argv[1:] or ["base", "n15", "fail", "patch"]):
+    sys.path.insert(0, HERE)
+    for nm in (sys.argv[1:] or ["base", "n15", "fail", "patch", "scene"]):
         main(nm)

@@ -31,7 +31,8 @@ def test_so3_helpers_match_scipy():
         assert np.abs(e - R.from_matrix(M).as_euler("zyx")).max() < 1e-12
 
 
-@pytest.mark.parametrize("fixture", ["closed_loop.npz", "closed_loop_n15.npz", "closed_loop_fail.npz", "closed_loop_patch.npz"])
+@pytest.mark.parametrize("fixture", ["closed_loop.npz", "closed_loop_n15.npz", "closed_loop_fail.npz", "closed_loop_patch.npz",
+                                     "closed_loop_scene.npz"])
 def test_replay_of_the_reference_trace(golden_dir, fixture):
     """(scenarios: see tests/test_closed_loop.py TRACES)"""
     g = np.load(os.path.join(golden_dir, fixture))
@@ -40,6 +41,11 @@ def test_replay_of_the_reference_trace(golden_dir, fixture):
     params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
     lay = E.layout()
     shadow = MPCNode(g["in_q"][0], RobotModel(O.fk_batch), lambda n, dt: ReplaySolver(g, tol=1e-9), params=params)
+    obs = None
+    if "boxes" in g.files:          # scene obstacles: per-step collision sets on the "device" (a10 / f2 inside the loop)
+        from boundplanner_amd import scenes
+        obs = scenes.boxes_to_sets(g["boxes"])
+        shadow.mpc.set_obstacle_sets(*obs)
     n_w = 44 * N + 6
     prev = np.zeros(n_w)
     pack = lambda: pack_state(lay, shadow.mpc, shadow.q, shadow.dq, shadow.ddq, shadow.jerk, shadow.qf, shadow.v, shadow.p_lie)
@@ -62,11 +68,12 @@ def test_replay_of_the_reference_trace(golden_dir, fixture):
                 if f != "has_prev":
                     state_view(lay, S)[f][:] = val
             state_view(lay, S)["has_prev"][:] = keep["has_prev"]
-        x0, lbx, ubx, p = E.prepare(N, S, prev)
+        x0, lbx, ubx, p = E.prepare(N, S, prev) if obs is None else E.prepare_obs(N, S, prev, *obs)
         for name, mine in (("x0", x0), ("lbx", lbx), ("ubx", ubx), ("p", p)):
             d = np.abs(mine - big(g["call_" + name][k])).max()
             worst[name] = max(worst.get(name, 0.0), d)
-            assert d < 1e-9, (k, name, d, np.argmax(np.abs(mine - big(g["call_" + name][k]))))
+            # (collision-set rows with obstacles: closest-pair search resolved to ~1e-7 on both sides)
+            assert d < (2e-6 if (obs is not None and name == "p") else 1e-9), (k, name, d, np.argmax(np.abs(mine - big(g["call_" + name][k]))))
         E.finish(N, params.dt, S, g["call_x"][k], prev, int(g["status"][k]), float(g["viol"][k]), int(g["iters"][k]))
         shadow.step()                                   # keeps the host mirror in lock step for the re-plan
         V = state_view(lay, S)

@@ -16,7 +16,8 @@ def _params(N):
     return Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
 
 
-@pytest.mark.parametrize("fixture", ["closed_loop.npz", "closed_loop_n15.npz", "closed_loop_fail.npz", "closed_loop_patch.npz"])
+@pytest.mark.parametrize("fixture", ["closed_loop.npz", "closed_loop_n15.npz", "closed_loop_fail.npz", "closed_loop_patch.npz",
+                                     "closed_loop_scene.npz"])
 def test_kernels_replay_the_reference_trace(golden_dir, fixture):
     import oracle_lib as O
     from boundplanner_amd.device_loop import DeviceLoop, state_view
@@ -31,6 +32,12 @@ def test_kernels_replay_the_reference_trace(golden_dir, fixture):
     R = 3                                     # identical rollouts: the result may not depend on the batch slot
     loop = DeviceLoop(be, R)
     shadow = MPCNode(g["in_q"][0], RobotModel(O.fk_batch), lambda n, dt: ReplaySolver(g, tol=1e-9), params=params)
+    has_obs = "boxes" in g.files
+    if has_obs:                     # BASELINE configs[0] scene: collision sets per step by bmpc_loop_k_colpairs + prepare
+        from boundplanner_amd import scenes
+        obs = scenes.boxes_to_sets(g["boxes"])
+        shadow.mpc.set_obstacle_sets(*obs)
+        loop.set_obstacles(*obs)
     for r in range(R):
         loop.set_rollout(r, shadow.mpc, shadow.q, shadow.dq, shadow.ddq, shadow.jerk, shadow.qf, shadow.v, shadow.p_lie)
     loop.upload()
@@ -60,7 +67,7 @@ def test_kernels_replay_the_reference_trace(golden_dir, fixture):
         for r in range(R):
             for name, mine in (("x0", x0), ("lbx", lbx), ("ubx", ubx), ("p", p)):
                 d = np.abs(mine[r] - big(g["call_" + name][k])).max()
-                assert d < 1e-9, (k, r, name, d)
+                assert d < (2e-6 if (has_obs and name == "p") else 1e-9), (k, r, name, d)
         loop.set_solution(np.tile(g["call_x"][k], (R, 1)), np.full(R, int(g["iters"][k])), np.full(R, int(g["status"][k])),
                           np.full(R, float(g["viol"][k])))
         log = loop.finish()
@@ -192,20 +199,26 @@ def test_device_loop_with_obstacles_tracks_host_loop():
     assert (log[:, loop.LOG["dead"]] == 0).all()
 
 
-def test_device_loop_tracks_reference_trace_with_hip_solver(golden_dir):
+@pytest.mark.parametrize("fixture", ["closed_loop.npz", "closed_loop_scene.npz"])
+def test_device_loop_tracks_reference_trace_with_hip_solver(golden_dir, fixture):
     """The reference's closed-loop scenario end to end on the device (prepare kernel -> HIP solve -> finish kernel):
     same switching step, same number of steps to the path end, states within the stated solver tolerance of the
-    golden trace (which was produced by the reference's host code with the CPU oracle in the solver slot)."""
+    golden trace (which was produced by the reference's host code with the CPU oracle in the solver slot).
+    closed_loop_scene.npz = BASELINE configs[0]: the reference's example scene (start, goal, workspace, 12 box obstacles,
+    N=15), per-step collision sets on the device against the reference's own ConvexSetFinder in the trace."""
     import oracle_lib as O
     from boundplanner_amd.device_loop import DeviceLoop
     from boundplanner_amd.mpc_node import MPCNode
     from boundplanner_amd.robot_model import RobotModel
     from boundplanner_amd.solver import HipBoundMPC
-    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     N = int(g["N"])
     params = _params(N)
     be = HipBoundMPC(N)
     loop = DeviceLoop(be, 1)
+    if "boxes" in g.files:
+        from boundplanner_amd import scenes
+        loop.set_obstacles(*scenes.boxes_to_sets(g["boxes"]))
     seed = MPCNode(g["in_q"][0], RobotModel(be.fk), lambda n, dt: None, params=params)   # host construction only
     loop.set_rollout(0, seed.mpc, seed.q, seed.dq, seed.ddq, seed.jerk, seed.qf, seed.v, seed.p_lie)
     loop.upload()
