@@ -1,7 +1,7 @@
 """Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
 
 Run in the build container only (needs /root/reference):
-    python tests/golden/gen/gen_golden.py [kin] [nlp6] [nlp10] [nlp20]
+    python tests/golden/gen/gen_golden.py [kin] [nlp6] [nlp10] [nlp15] [nlp20] [nlp30]
 
 * kin.npz      : outputs of the reference's serialized CasADi kinematics (RobotModel/*.ca)
                  at 32 joint configurations (+ d(J dq)/dq by complex step through jacobian.ca).
@@ -104,12 +104,16 @@ def gen_nlp_dir(N, npts, ndir, seed):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["kin", "nlp6", "nlp10", "nlp20"]
+    what = sys.argv[1:] or ["kin", "nlp6", "nlp10", "nlp15", "nlp20", "nlp30"]
     if "kin" in what:
         gen_kin()
     if "nlp6" in what:
         gen_nlp_full(6, 5, 6)
     if "nlp10" in what:
         gen_nlp_dir(10, 8, 3, 10)
+    if "nlp15" in what:
+        gen_nlp_dir(15, 6, 2, 15)        # the reference's default horizon (util_functions.py:49)
     if "nlp20" in what:
         gen_nlp_dir(20, 8, 3, 20)
+    if "nlp30" in what:
+        gen_nlp_dir(30, 4, 2, 30)        # BASELINE configs[4]

@@ -19,7 +19,7 @@ def test_full_jacobian_N6(golden_dir):
         assert np.abs(J - g["jac_g"][i]).max() < 1e-12
 
 
-@pytest.mark.parametrize("N", [10, 20])
+@pytest.mark.parametrize("N", [10, 15, 20, 30])       # 15 = the reference's default horizon, 30 = BASELINE configs[4]
 def test_directional_derivatives(golden_dir, N):
     g = np.load(os.path.join(golden_dir, f"nlp_N{N}.npz"))
     for i in range(g["w"].shape[0]):
