@@ -67,6 +67,7 @@ struct bmpc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
+    std::atomic<bool> busy{false}; // a solve is running on this handle (a handle serves one host thread at a time)
     std::atomic<int> n_loops{0};   // device loops borrowing this handle (bmpc_loop_create / bmpc_loop_destroy)
     bool destroy_pending = false;  // bmpc_destroy called while loops were alive: the last loop frees the handle
     std::string err;
@@ -82,6 +83,16 @@ struct bmpc_handle {
     } while (0)
 
 static int pipe_ensure(bmpc_handle* h, int B);
+
+// one solve at a time per handle: a second host thread entering gets an error instead of a corrupted workspace
+struct BusyGuard {
+    bmpc_handle* h; bool ok;
+    explicit BusyGuard(bmpc_handle* h_) : h(h_) { bool f = false; ok = h->busy.compare_exchange_strong(f, true); }
+    ~BusyGuard() { if (ok) h->busy.store(false); }
+};
+#define BUSY_OR_FAIL(h, what)                                                                                   \
+    BusyGuard busy_guard_(h);                                                                                   \
+    if (!busy_guard_.ok) return 4;       /* (h->err belongs to the thread that owns the handle: not touched) */
 
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
@@ -368,6 +379,7 @@ extern "C" int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const d
     int wrc = bmpc_wait(h);        // an asynchronous solve in flight owns the workspace
     if (wrc) return wrc;
     if (B == 0) return 0;
+    BUSY_OR_FAIL(h, "bmpc_solve_dev");
     HIPCHK(h, hipSetDevice(h->o.device));
     return launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, (hipStream_t)stream);
 }
@@ -381,6 +393,7 @@ extern "C" int bmpc_solve_dev_hooked(bmpc_handle* h, int B, const double* d_x0, 
     if (h->o.engine != 0) { h->err = "bmpc_loop_run_async needs the pipeline engine"; return 1; }
     int wrc = bmpc_wait(h);
     if (wrc) return wrc;
+    BUSY_OR_FAIL(h, "bmpc_loop_run_async");
     HIPCHK(h, hipSetDevice(h->o.device));
     return pipe_solve(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, nullptr, d_f, d_iters, d_status, d_viol, (hipStream_t)stream, hook, hook_ctx, d_cont);
 }
@@ -411,12 +424,16 @@ extern "C" int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, c
     int rc = bmpc_wait(h);
     if (rc) return rc;
     if (B == 0) return 0;
+    { bool f = false; if (!h->busy.compare_exchange_strong(f, true)) return 4; }
     h->n_active.store(B);
-    h->worker = std::thread([=]() {
-        if (hipSetDevice(h->o.device) != hipSuccess) { h->err = "hipSetDevice failed in the worker"; h->worker_rc = 2; return; }
-        int r = launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, h->stream);
+    h->worker = std::thread([=]() {      // the worker owns the handle until it is done (bmpc_wait joins it)
+        int r = 0;
+        if (hipSetDevice(h->o.device) != hipSuccess) { h->err = "hipSetDevice failed in the worker"; r = 2; }
+        if (r == 0) r = launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, h->stream);
         if (r == 0 && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed in the worker"; r = 2; }
         h->worker_rc = r;
+        if (r != 0) h->n_active.store(0);        // a failed solve is not "active" for ever; bmpc_wait reports the code
+        h->busy.store(false);
     });
     return 0;
 }
@@ -471,6 +488,7 @@ extern "C" int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double*
     if (B == 0) return 0;
     int rc = bmpc_wait(h);         // an asynchronous solve in flight owns the workspace
     if (rc) return rc;
+    BUSY_OR_FAIL(h, "bmpc_solve");
     HIPCHK(h, hipSetDevice(h->o.device));
     rc = ensure_cap(h, B, g != nullptr);
     if (rc) return rc;

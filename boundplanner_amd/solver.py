@@ -139,6 +139,8 @@ class HipBoundMPC:
             pass
 
     def _chk(self, rc, what):
+        if rc == 4:
+            raise RuntimeError(f"{what} refused: the handle is in use by another thread (one handle per host thread)")
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self.lib.bmpc_last_error(self._h).decode()}")
 

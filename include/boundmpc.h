@@ -15,7 +15,8 @@
  *
  * Plain C, plain pointers and sizes; no torch/HIP types in the signatures (the `_dev` entry
  * takes a hipStream_t as void*).  A handle is not thread-safe; use one per host thread/stream.
- * Return value: 0 on success, nonzero on API misuse or a HIP error (see bmpc_last_error).
+ * Return value: 0 on success, nonzero on API misuse or a HIP error (see bmpc_last_error); 4 = the handle is busy with a
+ * solve started from another host thread (nothing was done).
  */
 #ifndef BOUNDMPC_H
 #define BOUNDMPC_H

@@ -479,3 +479,34 @@ def test_two_handles_from_two_host_threads():
     for t in th: t.join()
     for i in range(2):
         assert np.array_equal(par[i]["x"], seq[i]["x"]) and np.array_equal(par[i]["status"], seq[i]["status"])
+
+
+def test_one_handle_from_two_threads_is_refused():
+    """A handle serves one host thread at a time (include/boundmpc.h): a second thread entering while a solve runs gets a
+    nonzero return code and a message, not a corrupted workspace; the first solve is unaffected."""
+    import threading
+    import time
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N = 10
+    be = HipBoundMPC(N)
+    big = scenes.make_batch(2048, N, 5, be.fk, randomize_sets=True)
+    ref = be.solve_batch(big["x0"], big["lbx"], big["ubx"], big["p"])
+    out, errs = {}, []
+
+    def long_solve():
+        out["r"] = be.solve_batch(big["x0"], big["lbx"], big["ubx"], big["p"])
+    t = threading.Thread(target=long_solve)
+    t.start()
+    time.sleep(0.02)
+    for _ in range(50):                       # hammer the handle from this thread while the other solve is running
+        if not t.is_alive():
+            break
+        try:
+            be.solve_batch(big["x0"][:4], big["lbx"][:4], big["ubx"][:4], big["p"][:4])
+        except RuntimeError as e:
+            errs.append(str(e))
+        time.sleep(0.005)
+    t.join()
+    assert errs and all("in use by another thread" in e for e in errs)
+    assert np.array_equal(out["r"]["x"], ref["x"]) and np.array_equal(out["r"]["status"], ref["status"])
