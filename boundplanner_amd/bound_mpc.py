@@ -160,8 +160,10 @@ class BoundMPC:
     def step(self, q0, dq0, ddq0, p0, v0, jerk_current, qf=np.zeros(7)):
         """One optimisation step (BoundMPC.py:388-676)."""
         w0, lbx, ubx, params, aux = self.prepare(q0, dq0, ddq0, p0, v0, jerk_current, qf)
+        self.last_aux = aux          # sets / bases of this step (mpc_data record)
         t0 = time.perf_counter()
         sol = self.solver(x0=w0, lbx=lbx, ubx=ubx, lbg=None, ubg=None, p=params)
+        self.last_cost = float(sol["f"].full().ravel()[0]) if "f" in sol else 0.0
         w_curr = sol["x"].full().flatten()
         time_elapsed = time.perf_counter() - t0
         stats = self.solver.stats()

@@ -115,7 +115,7 @@ class MPCNode:
         traj_data, ref_data, err_data, self.t_mpc, iters = self.mpc.step(
             self.q, self.dq, self.ddq, self.p_lie, self.v, self.jerk, self.qf)
         self.p_ref = ref_data["p"][1]
-        self.traj, self.traj_data, self.ref_data = traj_data["p"], traj_data, ref_data
+        self.traj, self.traj_data, self.ref_data, self.err_data = traj_data["p"], traj_data, ref_data, err_data
         self.iters.append(iters)
         self.fails.append(1.0 if self.mpc.error_count > 0 else 0.0)
         self.t_current += self.mpc.dt

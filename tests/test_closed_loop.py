@@ -118,6 +118,15 @@ def test_closed_loop_replay_matches_reference(trace):
             assert np.abs(np.asarray(mine) - g[key][k]).max() < 1e-9, (k, key)
         for key in ("q", "dq", "ddq", "jerk", "v", "qf", "p_lie"):
             assert np.abs(getattr(node, key) - g["out_" + key][k]).max() < 1e-9, (k, key)
+    if True:
+        # the MPCData-shaped record of the last step (boundmpcmsg/msg/MPCData.msg field set)
+        from boundplanner_amd import mpc_data
+        rec = mpc_data.from_node(node)
+        assert set(rec) == set(mpc_data.FIELDS)
+        assert len(rec["q"]) == traj["q"].shape[1] and np.array_equal(rec["q"][1], traj["q"][:, 1])
+        assert np.array_equal(rec["phi"], traj["phi"]) and rec["sector"] == int(g["sector"][-1])
+        assert rec["a_set_j3"].shape == (45,) and rec["b_set_elbow"].shape == (15,) and rec["iterations"] == int(g["iters"][-1])
+        assert len(rec["e_p"]) >= len(rec["q"]) - 1 and np.abs(rec["p_ref"][1] - g["ref_p1"][-1]).max() < 1e-9
     # every scenario exercises a set switch with via-point adaptation
     assert g["switch"].sum() >= 1 and g["sector"][-1] >= 1
     assert (node.mpc.phi_current[0] >= node.mpc.phi_max[0] - 0.001) == (g["phi_current"][-1][0] >= g["phi_max"][-1][0] - 0.001)
