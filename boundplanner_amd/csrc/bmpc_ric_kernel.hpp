@@ -195,6 +195,411 @@ template <int NT> BMPC_DEV double rmin(double v, LDSD* red, int lane) {
 // The Riccati kernel reads the argument block through the plain-pointer view: with global-qualified
 // pointers this compiler (ROCm 7.2) mis-assigns an odd register pair when it reloads a spilled
 // 64-bit memory operand ("Subtarget requires even aligned vector registers")
+// The stage loop of the backward recursion is cut into three non-inlined phases so that nothing stays live in registers
+// across them (the loop body as one function needed the whole register file and spilled): record -> stage matrix in
+// zeta coordinates; coupling with stage k+1; adjoint, control-block factorisation, gains, Schur complement.  Integer and
+// pointer arguments only (see the note on floating-point arguments below).
+template <int NT>
+BMPC_NOINL void ric_phase_load(const PipeArgsH& A, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
+    const double hreg = lds[R_park + 12];
+    const int N = A.N;
+    const DynC dc = make_dync(A.o.dt);
+    constexpr int NF = HREC / NT;
+    constexpr int NE2 = (NZ * 9 + 27 + NT - 1) / NT;
+    const int junk = R_misc + (lane & 31);
+    const bool term = (k == N - 1);
+    const size_t pi = pair_of(A, b, k);
+    RPROF_START();
+    // ---- stage matrix from the record (natural coordinates) ----
+    {
+        const bmpc_v2d z2 = {0.0, 0.0};
+        for (int e = lane; e < NZ * LDW / 2; e += NT) *(LDSV2*)(RL(R_W) + 2 * e) = z2;
+    }
+    BMPC_ASYNC_WAIT();
+    BMPC_SYNC();
+    double rv[NF];
+    BMPC_UNROLL
+    for (int i = 0; i < NF; i++) rv[i] = RL(R_stage)[lane + NT * i];
+    BMPC_UNROLL
+    for (int i = 0; i < NF; i++) {
+        const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
+        lds[ps == 1 ? o1 : junk] = rv[i]; lds[ps == 1 ? o2 : junk] = rv[i];
+    }
+    BMPC_SYNC();
+    // adds: every address receives at most one add per pass (order-independent result)
+    BMPC_UNROLL
+    for (int i = 0; i < NF; i++) {
+        const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
+        if (ps == 2) { BMPC_LDS_ADD(lds + o1, rv[i]); if (o2 != 8191) BMPC_LDS_ADD(lds + o2, rv[i]); }
+    }
+    if (hreg != 0.0) {
+        BMPC_SYNC();
+        if (lane < NZ) RL(R_W)[lane * LDW + lane] += hreg;
+    }
+    BMPC_SYNC();
+    if (hess_mode) {
+        BMPC_UNROLL
+        for (int i = 0; i < NF; i++) {
+            const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
+            if (ps == 3) { BMPC_LDS_ADD(lds + o1, rv[i]); if (o2 != 8191) BMPC_LDS_ADD(lds + o2, rv[i]); }
+        }
+        BMPC_SYNC();
+    }
+    // every lane has consumed the staged record: fetch the next stage's behind the rest of this stage
+    if (k > 1) bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + (pi - 1) * HREC), RL(R_stage), lane);
+    RPROF(0);
+    // ---- second-order term of the pi dynamics: multiplier lam_pi(k+1) times d2(dt w)/d(q,dq)2 ----
+    if (hess_mode && !term) {
+        const double l0 = dc.dt * RL(R_lam)[Z_PI], l1 = dc.dt * RL(R_lam)[Z_PI + 1], l2 = dc.dt * RL(R_lam)[Z_PI + 2];
+        const double lamv[3] = {l0, l1, l2};
+        auto zax = [&](int i, double* z) { z[0] = RL(R_ew)[21 + i]; z[1] = RL(R_ew)[28 + i]; z[2] = RL(R_ew)[35 + i]; };
+        auto suf = [&](int m, double* s) {   // sufz[m], m = 1..7
+            if (m >= 7) { s[0] = 0; s[1] = 0; s[2] = 0; }
+            else { s[0] = RL(R_sufz)[3 * (m - 1)]; s[1] = RL(R_sufz)[3 * (m - 1) + 1]; s[2] = RL(R_sufz)[3 * (m - 1) + 2]; }
+        };
+        for (int e = lane; e < 98; e += NT) {
+            if (e < 49) {
+                int a = e / 7, bq = e % 7;
+                double za[3], zb[3], sa[3], sm[3], u1[3] = {0, 0, 0}, u2[3], tmp[3];
+                zax(a, za); zax(bq, zb);
+                suf(a + 1, sa); suf((a > bq ? a : bq) + 1, sm);
+                if (bq < a) { cross3r(zb, za, tmp); cross3r(tmp, sa, u1); }
+                cross3r(zb, sm, tmp); cross3r(za, tmp, u2);
+                double acc = lamv[0] * (u1[0] + u2[0]) + lamv[1] * (u1[1] + u2[1]) + lamv[2] * (u1[2] + u2[2]);
+                RL(R_W)[(Z_Q + a) * LDW + Z_Q + bq] += acc;
+            } else {
+                int i = (e - 49) / 7, j = (e - 49) % 7;
+                if (i < j) {
+                    double zi[3], zj[3], zz[3];
+                    zax(i, zi); zax(j, zj);
+                    cross3r(zi, zj, zz);
+                    double acc = lamv[0] * zz[0] + lamv[1] * zz[1] + lamv[2] * zz[2];
+                    RL(R_W)[(Z_Q + i) * LDW + Z_DQ + j] += acc;
+                    RL(R_W)[(Z_DQ + j) * LDW + Z_Q + i] += acc;
+                }
+            }
+        }
+        BMPC_SYNC();
+    }
+    RPROF(1);
+    // ---- natural -> zeta coordinates: H = T^T Hy T.  Column pass, then row pass (+ the three
+    // gradient vectors); offsets precomputed per lane, every lane gathers the operands of all its
+    // entries before it stores ----
+    BMPC_UNROLL
+    for (int pass = 0; pass < 2; pass++) {
+        double s0[NE2], s1[NE2], s2[NE2], d0[NE2];
+        int od[NE2];
+        bool ij[NE2];
+        BMPC_UNROLL
+        for (int m = 0; m < NE2; m++) {
+            // entry e: (i, t) of the 41 x 9 grid (column pass: row i, transformed column t; row pass:
+            // column i, transformed row t), then the 27 vector entries (row pass only); branch-free
+            const int e = lane + NT * m;
+            const bool inw = e < NZ * 9, inv = !inw && (e < NZ * 9 + 27) && pass == 1;
+            const int ev = inw ? e : (inv ? e - NZ * 9 : 0);
+            const int i = ev / 9, t = ev - 9 * i;
+            const bool isj = t < 7;
+            const int sp = isj ? Z_Q + t : (t == 7 ? Z_RS : Z_PS), dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
+            // W entries: offset of (row, col); vector entries: i selects g0 / g1 / gz
+            const int str = pass ? LDW : 1, base = pass ? R_W + i : R_W + i * LDW;
+            const int vb = (i == 0 ? R_g0 : i == 1 ? R_g1 : R_gz);
+            int o_d = inw ? base + dp * str : vb + dp, o_s = inw ? base + sp * str : vb + sp;
+            const int st7 = inw ? 7 * str : 7;
+            if (!inw && !inv) { o_d = junk; o_s = junk; }
+            od[m] = o_d; ij[m] = isj;
+            d0[m] = lds[o_d]; s0[m] = lds[o_s];
+            s1[m] = lds[isj && (inw || inv) ? o_s + st7 : o_s]; s2[m] = lds[isj && (inw || inv) ? o_s + 2 * st7 : o_s];
+        }
+        BMPC_UNROLL
+        for (int m = 0; m < NE2; m++)
+            lds[od[m]] = d0[m] + (ij[m] ? dc.c3 : 0.5 * dc.dt) * s0[m] + (ij[m] ? dc.c2 : 0.0) * s1[m] + (ij[m] ? dc.c1 : 0.0) * s2[m];
+        BMPC_SYNC();
+    }
+    if (k == 1 && lane < 2) {   // zeta-diagonal rows rs~_1, ps~_1 >= 0
+        int pos = lane ? Z_PS : Z_RS;
+        RL(R_W)[pos * LDW + pos] += RL(R_dz2)[lane];
+        RL(R_g0)[pos] -= RL(R_dz2)[2 + lane]; RL(R_g1)[pos] -= RL(R_dz2)[4 + lane]; RL(R_gz)[pos] -= RL(R_dz2)[6 + lane];
+    }
+    RPROF(2);
+}
+
+template <int NT>
+BMPC_NOINL void ric_phase_couple(const PipeArgsH& A, LDSD* lds, int lane) {
+    const DynC dc = make_dync(A.o.dt);
+    const bool term = false;
+    RPROF_START();
+    // ---- coupling with stage k+1:  W += Phi^T P Phi,  g += Phi^T (pv + P rdef),  gz += Phi^T lam,
+    // Phi = [A B] + the three pi rows E (dt * d w / d(q~, dq~, u)) ----
+    if (!term) {
+        // C1: E^T (R_Et), Y~ = Phi0^T P[:, pi] + 1/2 E^T P[pi, pi] (R_Y), vt0 = pv0 + P rdef
+        if (lane < NZ) {
+            const int c = lane;
+            double et[3];
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) {
+                double v = 0;
+                if (c < Z_DQ) v = dc.dt * RL(R_ew)[7 * a + c];
+                else if (c < Z_DDQ) v = dc.dt * RL(R_ew)[21 + 7 * a + c - 7];
+                else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * RL(R_ew)[7 * a + c - Z_U] + dc.c2 * RL(R_ew)[21 + 7 * a + c - Z_U]);
+                et[a] = v;
+            }
+            PhiCol pc = phi_col(c, dc);
+            const LDSD* Pp = RL(R_P) + Z_PI * LDP + Z_PI;
+            double pr[3][3], pp[3][3];
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) {
+                pr[0][a] = RL(R_P)[pc.i0 * LDP + Z_PI + a]; pr[1][a] = RL(R_P)[pc.i1 * LDP + Z_PI + a]; pr[2][a] = RL(R_P)[pc.i2 * LDP + Z_PI + a];
+                pp[0][a] = Pp[a]; pp[1][a] = Pp[LDP + a]; pp[2][a] = Pp[2 * LDP + a];
+            }
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) {
+                RL(R_Et)[a * NZ + c] = et[a];
+                RL(R_Y)[c * 3 + a] = pc.c0 * pr[0][a] + pc.c1 * pr[1][a] + pc.c2 * pr[2][a] +
+                                     0.5 * (et[0] * pp[0][a] + et[1] * pp[1][a] + et[2] * pp[2][a]);
+            }
+        }
+        if (lane >= NT - 32) {
+            const int r = lane - (NT - 32);
+            double v = RL(R_pv0)[r];
+            BMPC_UNROLL
+            for (int j = 0; j < NX; j++) v += RL(R_P)[r * LDP + j] * RL(R_rdef)[j];
+            RL(R_vt0)[r] = v;
+        }
+        BMPC_SYNC();
+        RPROF(7);
+        // C2: structured part Phi0^T P Phi0.  Every lane first gathers the operands of ALL its
+        // entries (joint x joint block, two joint x single entries, two single x single entries),
+        // then computes and scatters: one LDS latency instead of five
+        {
+            const double al[4][3] = {{1.0, 0.0, 0.0}, {dc.dt, 1.0, 0.0}, {0.5 * dc.dt * dc.dt, dc.dt, 1.0}, {dc.b3, dc.b2, dc.b1}};
+            const int gpos[4] = {Z_Q, Z_DQ, Z_DDQ, Z_U};
+            LDSD* W = RL(R_W);
+            const LDSD* P = RL(R_P);
+            // (a) joint x joint: lane < 49 -> pair (a, bq)
+            const bool hasA = lane < 49;
+            const int aA = hasA ? lane / 7 : 0, bA = hasA ? lane - 7 * aA : 0;
+            double Pb[3][3], w[4][4];
+            // (b) joint rows x single columns c in [Z_PI, Z_U): 77 (a, c) pairs, lanes 49..63 take 0..14,
+            // lanes 0..61 take 15..76
+            constexpr int UB = (77 + 49 + NT - 1) / NT, UC = (121 + NT - 1) / NT;
+            int eB[UB], aB[UB], cB[UB], cwB[UB];
+            bool hasB[UB], slB[UB];
+            double pB[UB][3], wr[UB][4], wc[UB][4], xr[UB][4], xc[UB][4];
+            // (c) single x single: 121 pairs
+            int c1C[UC], c2C[UC], w1C[UC], w2C[UC];
+            bool hasC[UC], s1C[UC], s2C[UC];
+            double vC[UC], aC[UC][4];
+            if (hasA) {
+                BMPC_UNROLL
+                for (int r = 0; r < 3; r++)
+                    BMPC_UNROLL
+                    for (int s2 = 0; s2 < 3; s2++) Pb[r][s2] = P[(7 * r + aA) * LDP + 7 * s2 + bA];
+                BMPC_UNROLL
+                for (int gi = 0; gi < 4; gi++)
+                    BMPC_UNROLL
+                    for (int gj = 0; gj < 4; gj++) w[gi][gj] = W[(gpos[gi] + aA) * LDW + gpos[gj] + bA];
+            }
+            BMPC_UNROLL
+            for (int u = 0; u < UB; u++) {
+                eB[u] = lane - 49 + NT * u;
+                hasB[u] = eB[u] >= 0 && eB[u] < 77;
+                const int e = hasB[u] ? eB[u] : 0;
+                aB[u] = e / 11; cB[u] = Z_PI + (e - 11 * aB[u]);
+                slB[u] = (cB[u] == Z_RS || cB[u] == Z_PS);
+                cwB[u] = (cB[u] == Z_RS) ? Z_DRS : Z_DPS;
+                if (hasB[u]) {
+                    pB[u][0] = P[aB[u] * LDP + cB[u]]; pB[u][1] = P[(7 + aB[u]) * LDP + cB[u]]; pB[u][2] = P[(14 + aB[u]) * LDP + cB[u]];
+                    BMPC_UNROLL
+                    for (int gi = 0; gi < 4; gi++) {
+                        const int r = gpos[gi] + aB[u];
+                        wr[u][gi] = W[r * LDW + cB[u]]; wc[u][gi] = W[cB[u] * LDW + r];
+                        xr[u][gi] = slB[u] ? W[r * LDW + cwB[u]] : 0.0; xc[u][gi] = slB[u] ? W[cwB[u] * LDW + r] : 0.0;
+                    }
+                }
+            }
+            BMPC_UNROLL
+            for (int u = 0; u < UC; u++) {
+                const int ec = lane + NT * u;
+                hasC[u] = ec < 121;
+                const int q1 = hasC[u] ? ec / 11 : 0;
+                c1C[u] = Z_PI + q1; c2C[u] = Z_PI + (hasC[u] ? ec - 11 * q1 : 0);
+                s1C[u] = (c1C[u] == Z_RS || c1C[u] == Z_PS); s2C[u] = (c2C[u] == Z_RS || c2C[u] == Z_PS);
+                w1C[u] = (c1C[u] == Z_RS) ? Z_DRS : Z_DPS; w2C[u] = (c2C[u] == Z_RS) ? Z_DRS : Z_DPS;
+                if (hasC[u]) {
+                    vC[u] = P[c1C[u] * LDP + c2C[u]];
+                    aC[u][0] = W[c1C[u] * LDW + c2C[u]];
+                    aC[u][1] = s2C[u] ? W[c1C[u] * LDW + w2C[u]] : 0.0;
+                    aC[u][2] = s1C[u] ? W[w1C[u] * LDW + c2C[u]] : 0.0;
+                    aC[u][3] = (s1C[u] && s2C[u]) ? W[w1C[u] * LDW + w2C[u]] : 0.0;
+                }
+            }
+            // compute + scatter (all targets of one lane and of different lanes are distinct)
+            if (hasA) {
+                BMPC_UNROLL
+                for (int gi = 0; gi < 4; gi++) {
+                    double t0 = al[gi][0] * Pb[0][0] + al[gi][1] * Pb[1][0] + al[gi][2] * Pb[2][0];
+                    double t1 = al[gi][0] * Pb[0][1] + al[gi][1] * Pb[1][1] + al[gi][2] * Pb[2][1];
+                    double t2 = al[gi][0] * Pb[0][2] + al[gi][1] * Pb[1][2] + al[gi][2] * Pb[2][2];
+                    BMPC_UNROLL
+                    for (int gj = 0; gj < 4; gj++)
+                        W[(gpos[gi] + aA) * LDW + gpos[gj] + bA] = w[gi][gj] + t0 * al[gj][0] + t1 * al[gj][1] + t2 * al[gj][2];
+                }
+            }
+            BMPC_UNROLL
+            for (int u = 0; u < UB; u++) {
+                if (hasB[u]) {
+                    BMPC_UNROLL
+                    for (int gi = 0; gi < 4; gi++) {
+                        const int r = gpos[gi] + aB[u];
+                        double v = al[gi][0] * pB[u][0] + al[gi][1] * pB[u][1] + al[gi][2] * pB[u][2];
+                        W[r * LDW + cB[u]] = wr[u][gi] + v; W[cB[u] * LDW + r] = wc[u][gi] + v;
+                        if (slB[u]) { W[r * LDW + cwB[u]] = xr[u][gi] + dc.dt * v; W[cwB[u] * LDW + r] = xc[u][gi] + dc.dt * v; }
+                    }
+                }
+            }
+            BMPC_UNROLL
+            for (int u = 0; u < UC; u++) {
+                if (hasC[u]) {
+                    W[c1C[u] * LDW + c2C[u]] = aC[u][0] + vC[u];
+                    if (s2C[u]) W[c1C[u] * LDW + w2C[u]] = aC[u][1] + dc.dt * vC[u];
+                    if (s1C[u]) W[w1C[u] * LDW + c2C[u]] = aC[u][2] + dc.dt * vC[u];
+                    if (s1C[u] && s2C[u]) W[w1C[u] * LDW + w2C[u]] = aC[u][3] + dc.dt * dc.dt * vC[u];
+                }
+            }
+        }
+        BMPC_SYNC();
+        RPROF(8);
+        // C3: rank-3 part  D[i][j] = Y~[i] . E[:, j] + Y~[j] . E[:, i]  on the 21 columns j where E is
+        // nonzero: lane = column (three lane groups split the rows), two rows per batch
+        {
+            constexpr int G3 = NT / 21, NR = (NZ + G3 - 1) / G3, RB = 4, NB = (NR + RB - 1) / RB;   // row groups, rows per lane, rows per batch, batches
+            const bool act = lane < 21 * G3;
+            const int g3 = act ? lane / 21 : 0, jj = act ? lane - 21 * g3 : 0;
+            const int j = jj < 14 ? jj : Z_U + jj - 14;
+            LDSD* W = RL(R_W);
+            const double ej0 = RL(R_Et)[j], ej1 = RL(R_Et)[NZ + j], ej2 = RL(R_Et)[2 * NZ + j];
+            const double yj0 = RL(R_Y)[3 * j], yj1 = RL(R_Y)[3 * j + 1], yj2 = RL(R_Y)[3 * j + 2];
+            BMPC_UNROLL
+            for (int mb = 0; mb < NB; mb++) {
+                double yi[RB][3], ei[RB][3], w0[RB], w1[RB];
+                bool in_[RB], val[RB];
+                int ii[RB];
+                BMPC_UNROLL
+                for (int u = 0; u < RB; u++) {
+                    const int i = g3 + G3 * (RB * mb + u);
+                    ii[u] = i; val[u] = act && (i < NZ);
+                    const int ic = val[u] ? i : 0;
+                    in_[u] = (ic < Z_DDQ) || (ic >= Z_U && ic < Z_DRS);
+                    BMPC_UNROLL
+                    for (int a = 0; a < 3; a++) { yi[u][a] = RL(R_Y)[3 * ic + a]; ei[u][a] = RL(R_Et)[a * NZ + ic]; }
+                    w0[u] = W[ic * LDW + j]; w1[u] = W[j * LDW + ic];
+                }
+                BMPC_UNROLL
+                for (int u = 0; u < RB; u++) {
+                    if (val[u]) {
+                        double v = yi[u][0] * ej0 + yi[u][1] * ej1 + yi[u][2] * ej2 + yj0 * ei[u][0] + yj1 * ei[u][1] + yj2 * ei[u][2];
+                        W[ii[u] * LDW + j] = w0[u] + v;
+                        if (!in_[u]) W[j * LDW + ii[u]] = w1[u] + v;
+                    }
+                }
+            }
+        }
+        if (lane < NZ) {
+            const int c = lane;
+            PhiCol pc = phi_col(c, dc);
+            double l3[3], v03[3], v13[3], lp[3], v0p[3], v1p[3], ea[3];
+            l3[0] = RL(R_lam)[pc.i0]; l3[1] = RL(R_lam)[pc.i1]; l3[2] = RL(R_lam)[pc.i2];
+            v03[0] = RL(R_vt0)[pc.i0]; v03[1] = RL(R_vt0)[pc.i1]; v03[2] = RL(R_vt0)[pc.i2];
+            v13[0] = RL(R_pv1)[pc.i0]; v13[1] = RL(R_pv1)[pc.i1]; v13[2] = RL(R_pv1)[pc.i2];
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) { ea[a] = RL(R_Et)[a * NZ + c]; lp[a] = RL(R_lam)[Z_PI + a]; v0p[a] = RL(R_vt0)[Z_PI + a]; v1p[a] = RL(R_pv1)[Z_PI + a]; }
+            double gl = pc.c0 * l3[0] + pc.c1 * l3[1] + pc.c2 * l3[2];
+            double a0 = pc.c0 * v03[0] + pc.c1 * v03[1] + pc.c2 * v03[2];
+            double a1 = pc.c0 * v13[0] + pc.c1 * v13[1] + pc.c2 * v13[2];
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) { gl += ea[a] * lp[a]; a0 += ea[a] * v0p[a]; a1 += ea[a] * v1p[a]; }
+            RL(R_gz)[c] += gl; RL(R_g0)[c] += a0; RL(R_g1)[c] += a1;
+        }
+    }
+}
+
+template <int NT>
+BMPC_NOINL bool ric_phase_factor(const PipeArgsH& A, LDSD* lds, int b, int lane, int k) {
+    const double reg = 1e-9;      // fixed regularisation of the control block
+    const size_t pi = pair_of(A, b, k);
+    bool ok = true;
+    RPROF_START();
+    BMPC_SYNC();
+    RPROF(3);
+    // ---- adjoint multipliers + dual residual (gz now holds the Lagrangian gradient) ----
+    if (lane < NZ) {
+        double gl = RL(R_gz)[lane];
+        if (lane >= NX || (k == 1 && lane >= 24)) RL(R_acc)[128 + lane] = fmax(RL(R_acc)[128 + lane], fabs(gl));
+        if (lane < NX) { RL(R_lam)[lane] = gl; RL(R_acc)[lane] += fabs(gl); }
+    }
+    // ---- control block factorisation, gains, Schur complement ----
+    double Lc[45], invd[NU];
+    if (!chol9i(RL(R_W), reg, Lc, invd)) ok = false;
+    double* krec = A.krec + pi * KREC;
+    if (lane < NX + 2) {
+        double rhs[NU];
+        BMPC_UNROLL
+        for (int l = 0; l < NU; l++)
+            rhs[l] = (lane < NX) ? RL(R_W)[(NX + l) * LDW + lane] : (lane == NX ? RL(R_g0)[NX + l] : RL(R_g1)[NX + l]);
+        chol9i_solve(Lc, invd, rhs);
+        BMPC_UNROLL
+        for (int l = 0; l < NU; l++) {
+            if (lane < NX) { RL(R_Kl)[l * NX + lane] = -rhs[l]; krec[l * NX + lane] = -rhs[l]; }
+            else { RL(R_kf)[(lane - NX) * 16 + l] = -rhs[l]; krec[NU * NX + (lane - NX) * 16 + l] = -rhs[l]; }
+        }
+    }
+    BMPC_SYNC();
+    RPROF(4);
+    // P = W_xx + W_xu K: lane = column j (two half-waves split the rows), K[:, j] in registers,
+    // W_ux rows fetched two at a time as broadcast 16-byte reads; loads of a batch precede its stores
+    {
+        constexpr int NH = NT / 32, RPH = NX / NH;      // row blocks, rows per block
+        const int j = lane & 31, h = lane >> 5;
+        double kj[NU];
+        BMPC_UNROLL
+        for (int l = 0; l < NU; l++) kj[l] = RL(R_Kl)[l * NX + j];
+        const LDSD* W = RL(R_W);
+        {
+            BMPC_UNROLL
+            for (int ib = 0; ib < RPH / 4; ib++) {
+                const int i0 = RPH * h + 4 * ib;
+                bmpc_v2d wa[NU], wb[NU];
+                BMPC_UNROLL
+                for (int l = 0; l < NU; l++) {
+                    wa[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0);
+                    wb[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0 + 2);
+                }
+                double p0 = W[i0 * LDW + j], p1 = W[(i0 + 1) * LDW + j], p2 = W[(i0 + 2) * LDW + j], p3 = W[(i0 + 3) * LDW + j];
+                BMPC_UNROLL
+                for (int l = 0; l < NU; l++) { p0 += wa[l][0] * kj[l]; p1 += wa[l][1] * kj[l]; p2 += wb[l][0] * kj[l]; p3 += wb[l][1] * kj[l]; }
+                RL(R_P)[i0 * LDP + j] = p0; RL(R_P)[(i0 + 1) * LDP + j] = p1;
+                RL(R_P)[(i0 + 2) * LDP + j] = p2; RL(R_P)[(i0 + 3) * LDP + j] = p3;
+            }
+        }
+        // pv = g_x + W_xu kf (two right-hand sides)
+        if (lane < 2 * NX) {
+            const int i = lane & (NX - 1);
+            const LDSD* g = (lane < NX) ? RL(R_g0) : RL(R_g1);
+            const LDSD* kf = RL(R_kf) + ((lane < NX) ? 0 : 16);
+            double wv[NU], kv[NU];
+            BMPC_UNROLL
+            for (int l = 0; l < NU; l++) { wv[l] = W[(NX + l) * LDW + i]; kv[l] = kf[l]; }
+            double v = g[i];
+            BMPC_UNROLL
+            for (int l = 0; l < NU; l++) v += wv[l] * kv[l];
+            ((lane < NX) ? RL(R_pv0) : RL(R_pv1))[i] = v;
+        }
+    }
+    BMPC_SYNC();
+    RPROF(5);
+    return ok;
+}
+
 template <int NT>
 BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int hess_mode) {
     // no floating-point arguments: an odd-aligned 64-bit argument pair that gets spilled trips a
@@ -228,379 +633,9 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
         const size_t pi = pair_of(A, b, k);
-        RPROF_START();
-        // ---- stage matrix from the record (natural coordinates) ----
-        {
-            const bmpc_v2d z2 = {0.0, 0.0};
-            for (int e = lane; e < NZ * LDW / 2; e += NT) *(LDSV2*)(RL(R_W) + 2 * e) = z2;
-        }
-        BMPC_ASYNC_WAIT();
-        BMPC_SYNC();
-        double rv[NF];
-        BMPC_UNROLL
-        for (int i = 0; i < NF; i++) rv[i] = RL(R_stage)[lane + NT * i];
-        BMPC_UNROLL
-        for (int i = 0; i < NF; i++) {
-            const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
-            lds[ps == 1 ? o1 : junk] = rv[i]; lds[ps == 1 ? o2 : junk] = rv[i];
-        }
-        BMPC_SYNC();
-        // adds: every address receives at most one add per pass (order-independent result)
-        BMPC_UNROLL
-        for (int i = 0; i < NF; i++) {
-            const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
-            if (ps == 2) { BMPC_LDS_ADD(lds + o1, rv[i]); if (o2 != 8191) BMPC_LDS_ADD(lds + o2, rv[i]); }
-        }
-        if (hreg != 0.0) {
-            BMPC_SYNC();
-            if (lane < NZ) RL(R_W)[lane * LDW + lane] += hreg;
-        }
-        BMPC_SYNC();
-        if (hess_mode) {
-            BMPC_UNROLL
-            for (int i = 0; i < NF; i++) {
-                const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
-                if (ps == 3) { BMPC_LDS_ADD(lds + o1, rv[i]); if (o2 != 8191) BMPC_LDS_ADD(lds + o2, rv[i]); }
-            }
-            BMPC_SYNC();
-        }
-        // every lane has consumed the staged record: fetch the next stage's behind the rest of this stage
-        if (k > 1) bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + (pi - 1) * HREC), RL(R_stage), lane);
-        RPROF(0);
-        // ---- second-order term of the pi dynamics: multiplier lam_pi(k+1) times d2(dt w)/d(q,dq)2 ----
-        if (hess_mode && !term) {
-            const double l0 = dc.dt * RL(R_lam)[Z_PI], l1 = dc.dt * RL(R_lam)[Z_PI + 1], l2 = dc.dt * RL(R_lam)[Z_PI + 2];
-            const double lamv[3] = {l0, l1, l2};
-            auto zax = [&](int i, double* z) { z[0] = RL(R_ew)[21 + i]; z[1] = RL(R_ew)[28 + i]; z[2] = RL(R_ew)[35 + i]; };
-            auto suf = [&](int m, double* s) {   // sufz[m], m = 1..7
-                if (m >= 7) { s[0] = 0; s[1] = 0; s[2] = 0; }
-                else { s[0] = RL(R_sufz)[3 * (m - 1)]; s[1] = RL(R_sufz)[3 * (m - 1) + 1]; s[2] = RL(R_sufz)[3 * (m - 1) + 2]; }
-            };
-            for (int e = lane; e < 98; e += NT) {
-                if (e < 49) {
-                    int a = e / 7, bq = e % 7;
-                    double za[3], zb[3], sa[3], sm[3], u1[3] = {0, 0, 0}, u2[3], tmp[3];
-                    zax(a, za); zax(bq, zb);
-                    suf(a + 1, sa); suf((a > bq ? a : bq) + 1, sm);
-                    if (bq < a) { cross3r(zb, za, tmp); cross3r(tmp, sa, u1); }
-                    cross3r(zb, sm, tmp); cross3r(za, tmp, u2);
-                    double acc = lamv[0] * (u1[0] + u2[0]) + lamv[1] * (u1[1] + u2[1]) + lamv[2] * (u1[2] + u2[2]);
-                    RL(R_W)[(Z_Q + a) * LDW + Z_Q + bq] += acc;
-                } else {
-                    int i = (e - 49) / 7, j = (e - 49) % 7;
-                    if (i < j) {
-                        double zi[3], zj[3], zz[3];
-                        zax(i, zi); zax(j, zj);
-                        cross3r(zi, zj, zz);
-                        double acc = lamv[0] * zz[0] + lamv[1] * zz[1] + lamv[2] * zz[2];
-                        RL(R_W)[(Z_Q + i) * LDW + Z_DQ + j] += acc;
-                        RL(R_W)[(Z_DQ + j) * LDW + Z_Q + i] += acc;
-                    }
-                }
-            }
-            BMPC_SYNC();
-        }
-        RPROF(1);
-        // ---- natural -> zeta coordinates: H = T^T Hy T.  Column pass, then row pass (+ the three
-        // gradient vectors); offsets precomputed per lane, every lane gathers the operands of all its
-        // entries before it stores ----
-        BMPC_UNROLL
-        for (int pass = 0; pass < 2; pass++) {
-            double s0[NE2], s1[NE2], s2[NE2], d0[NE2];
-            int od[NE2];
-            bool ij[NE2];
-            BMPC_UNROLL
-            for (int m = 0; m < NE2; m++) {
-                // entry e: (i, t) of the 41 x 9 grid (column pass: row i, transformed column t; row pass:
-                // column i, transformed row t), then the 27 vector entries (row pass only); branch-free
-                const int e = lane + NT * m;
-                const bool inw = e < NZ * 9, inv = !inw && (e < NZ * 9 + 27) && pass == 1;
-                const int ev = inw ? e : (inv ? e - NZ * 9 : 0);
-                const int i = ev / 9, t = ev - 9 * i;
-                const bool isj = t < 7;
-                const int sp = isj ? Z_Q + t : (t == 7 ? Z_RS : Z_PS), dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
-                // W entries: offset of (row, col); vector entries: i selects g0 / g1 / gz
-                const int str = pass ? LDW : 1, base = pass ? R_W + i : R_W + i * LDW;
-                const int vb = (i == 0 ? R_g0 : i == 1 ? R_g1 : R_gz);
-                int o_d = inw ? base + dp * str : vb + dp, o_s = inw ? base + sp * str : vb + sp;
-                const int st7 = inw ? 7 * str : 7;
-                if (!inw && !inv) { o_d = junk; o_s = junk; }
-                od[m] = o_d; ij[m] = isj;
-                d0[m] = lds[o_d]; s0[m] = lds[o_s];
-                s1[m] = lds[isj && (inw || inv) ? o_s + st7 : o_s]; s2[m] = lds[isj && (inw || inv) ? o_s + 2 * st7 : o_s];
-            }
-            BMPC_UNROLL
-            for (int m = 0; m < NE2; m++)
-                lds[od[m]] = d0[m] + (ij[m] ? dc.c3 : 0.5 * dc.dt) * s0[m] + (ij[m] ? dc.c2 : 0.0) * s1[m] + (ij[m] ? dc.c1 : 0.0) * s2[m];
-            BMPC_SYNC();
-        }
-        if (k == 1 && lane < 2) {   // zeta-diagonal rows rs~_1, ps~_1 >= 0
-            int pos = lane ? Z_PS : Z_RS;
-            RL(R_W)[pos * LDW + pos] += RL(R_dz2)[lane];
-            RL(R_g0)[pos] -= RL(R_dz2)[2 + lane]; RL(R_g1)[pos] -= RL(R_dz2)[4 + lane]; RL(R_gz)[pos] -= RL(R_dz2)[6 + lane];
-        }
-        RPROF(2);
-        // ---- coupling with stage k+1:  W += Phi^T P Phi,  g += Phi^T (pv + P rdef),  gz += Phi^T lam,
-        // Phi = [A B] + the three pi rows E (dt * d w / d(q~, dq~, u)) ----
-        if (!term) {
-            // C1: E^T (R_Et), Y~ = Phi0^T P[:, pi] + 1/2 E^T P[pi, pi] (R_Y), vt0 = pv0 + P rdef
-            if (lane < NZ) {
-                const int c = lane;
-                double et[3];
-                BMPC_UNROLL
-                for (int a = 0; a < 3; a++) {
-                    double v = 0;
-                    if (c < Z_DQ) v = dc.dt * RL(R_ew)[7 * a + c];
-                    else if (c < Z_DDQ) v = dc.dt * RL(R_ew)[21 + 7 * a + c - 7];
-                    else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * RL(R_ew)[7 * a + c - Z_U] + dc.c2 * RL(R_ew)[21 + 7 * a + c - Z_U]);
-                    et[a] = v;
-                }
-                PhiCol pc = phi_col(c, dc);
-                const LDSD* Pp = RL(R_P) + Z_PI * LDP + Z_PI;
-                double pr[3][3], pp[3][3];
-                BMPC_UNROLL
-                for (int a = 0; a < 3; a++) {
-                    pr[0][a] = RL(R_P)[pc.i0 * LDP + Z_PI + a]; pr[1][a] = RL(R_P)[pc.i1 * LDP + Z_PI + a]; pr[2][a] = RL(R_P)[pc.i2 * LDP + Z_PI + a];
-                    pp[0][a] = Pp[a]; pp[1][a] = Pp[LDP + a]; pp[2][a] = Pp[2 * LDP + a];
-                }
-                BMPC_UNROLL
-                for (int a = 0; a < 3; a++) {
-                    RL(R_Et)[a * NZ + c] = et[a];
-                    RL(R_Y)[c * 3 + a] = pc.c0 * pr[0][a] + pc.c1 * pr[1][a] + pc.c2 * pr[2][a] +
-                                         0.5 * (et[0] * pp[0][a] + et[1] * pp[1][a] + et[2] * pp[2][a]);
-                }
-            }
-            if (lane >= NT - 32) {
-                const int r = lane - (NT - 32);
-                double v = RL(R_pv0)[r];
-                BMPC_UNROLL
-                for (int j = 0; j < NX; j++) v += RL(R_P)[r * LDP + j] * RL(R_rdef)[j];
-                RL(R_vt0)[r] = v;
-            }
-            BMPC_SYNC();
-            RPROF(7);
-            // C2: structured part Phi0^T P Phi0.  Every lane first gathers the operands of ALL its
-            // entries (joint x joint block, two joint x single entries, two single x single entries),
-            // then computes and scatters: one LDS latency instead of five
-            {
-                const double al[4][3] = {{1.0, 0.0, 0.0}, {dc.dt, 1.0, 0.0}, {0.5 * dc.dt * dc.dt, dc.dt, 1.0}, {dc.b3, dc.b2, dc.b1}};
-                const int gpos[4] = {Z_Q, Z_DQ, Z_DDQ, Z_U};
-                LDSD* W = RL(R_W);
-                const LDSD* P = RL(R_P);
-                // (a) joint x joint: lane < 49 -> pair (a, bq)
-                const bool hasA = lane < 49;
-                const int aA = hasA ? lane / 7 : 0, bA = hasA ? lane - 7 * aA : 0;
-                double Pb[3][3], w[4][4];
-                // (b) joint rows x single columns c in [Z_PI, Z_U): 77 (a, c) pairs, lanes 49..63 take 0..14,
-                // lanes 0..61 take 15..76
-                constexpr int UB = (77 + 49 + NT - 1) / NT, UC = (121 + NT - 1) / NT;
-                int eB[UB], aB[UB], cB[UB], cwB[UB];
-                bool hasB[UB], slB[UB];
-                double pB[UB][3], wr[UB][4], wc[UB][4], xr[UB][4], xc[UB][4];
-                // (c) single x single: 121 pairs
-                int c1C[UC], c2C[UC], w1C[UC], w2C[UC];
-                bool hasC[UC], s1C[UC], s2C[UC];
-                double vC[UC], aC[UC][4];
-                if (hasA) {
-                    BMPC_UNROLL
-                    for (int r = 0; r < 3; r++)
-                        BMPC_UNROLL
-                        for (int s2 = 0; s2 < 3; s2++) Pb[r][s2] = P[(7 * r + aA) * LDP + 7 * s2 + bA];
-                    BMPC_UNROLL
-                    for (int gi = 0; gi < 4; gi++)
-                        BMPC_UNROLL
-                        for (int gj = 0; gj < 4; gj++) w[gi][gj] = W[(gpos[gi] + aA) * LDW + gpos[gj] + bA];
-                }
-                BMPC_UNROLL
-                for (int u = 0; u < UB; u++) {
-                    eB[u] = lane - 49 + NT * u;
-                    hasB[u] = eB[u] >= 0 && eB[u] < 77;
-                    const int e = hasB[u] ? eB[u] : 0;
-                    aB[u] = e / 11; cB[u] = Z_PI + (e - 11 * aB[u]);
-                    slB[u] = (cB[u] == Z_RS || cB[u] == Z_PS);
-                    cwB[u] = (cB[u] == Z_RS) ? Z_DRS : Z_DPS;
-                    if (hasB[u]) {
-                        pB[u][0] = P[aB[u] * LDP + cB[u]]; pB[u][1] = P[(7 + aB[u]) * LDP + cB[u]]; pB[u][2] = P[(14 + aB[u]) * LDP + cB[u]];
-                        BMPC_UNROLL
-                        for (int gi = 0; gi < 4; gi++) {
-                            const int r = gpos[gi] + aB[u];
-                            wr[u][gi] = W[r * LDW + cB[u]]; wc[u][gi] = W[cB[u] * LDW + r];
-                            xr[u][gi] = slB[u] ? W[r * LDW + cwB[u]] : 0.0; xc[u][gi] = slB[u] ? W[cwB[u] * LDW + r] : 0.0;
-                        }
-                    }
-                }
-                BMPC_UNROLL
-                for (int u = 0; u < UC; u++) {
-                    const int ec = lane + NT * u;
-                    hasC[u] = ec < 121;
-                    const int q1 = hasC[u] ? ec / 11 : 0;
-                    c1C[u] = Z_PI + q1; c2C[u] = Z_PI + (hasC[u] ? ec - 11 * q1 : 0);
-                    s1C[u] = (c1C[u] == Z_RS || c1C[u] == Z_PS); s2C[u] = (c2C[u] == Z_RS || c2C[u] == Z_PS);
-                    w1C[u] = (c1C[u] == Z_RS) ? Z_DRS : Z_DPS; w2C[u] = (c2C[u] == Z_RS) ? Z_DRS : Z_DPS;
-                    if (hasC[u]) {
-                        vC[u] = P[c1C[u] * LDP + c2C[u]];
-                        aC[u][0] = W[c1C[u] * LDW + c2C[u]];
-                        aC[u][1] = s2C[u] ? W[c1C[u] * LDW + w2C[u]] : 0.0;
-                        aC[u][2] = s1C[u] ? W[w1C[u] * LDW + c2C[u]] : 0.0;
-                        aC[u][3] = (s1C[u] && s2C[u]) ? W[w1C[u] * LDW + w2C[u]] : 0.0;
-                    }
-                }
-                // compute + scatter (all targets of one lane and of different lanes are distinct)
-                if (hasA) {
-                    BMPC_UNROLL
-                    for (int gi = 0; gi < 4; gi++) {
-                        double t0 = al[gi][0] * Pb[0][0] + al[gi][1] * Pb[1][0] + al[gi][2] * Pb[2][0];
-                        double t1 = al[gi][0] * Pb[0][1] + al[gi][1] * Pb[1][1] + al[gi][2] * Pb[2][1];
-                        double t2 = al[gi][0] * Pb[0][2] + al[gi][1] * Pb[1][2] + al[gi][2] * Pb[2][2];
-                        BMPC_UNROLL
-                        for (int gj = 0; gj < 4; gj++)
-                            W[(gpos[gi] + aA) * LDW + gpos[gj] + bA] = w[gi][gj] + t0 * al[gj][0] + t1 * al[gj][1] + t2 * al[gj][2];
-                    }
-                }
-                BMPC_UNROLL
-                for (int u = 0; u < UB; u++) {
-                    if (hasB[u]) {
-                        BMPC_UNROLL
-                        for (int gi = 0; gi < 4; gi++) {
-                            const int r = gpos[gi] + aB[u];
-                            double v = al[gi][0] * pB[u][0] + al[gi][1] * pB[u][1] + al[gi][2] * pB[u][2];
-                            W[r * LDW + cB[u]] = wr[u][gi] + v; W[cB[u] * LDW + r] = wc[u][gi] + v;
-                            if (slB[u]) { W[r * LDW + cwB[u]] = xr[u][gi] + dc.dt * v; W[cwB[u] * LDW + r] = xc[u][gi] + dc.dt * v; }
-                        }
-                    }
-                }
-                BMPC_UNROLL
-                for (int u = 0; u < UC; u++) {
-                    if (hasC[u]) {
-                        W[c1C[u] * LDW + c2C[u]] = aC[u][0] + vC[u];
-                        if (s2C[u]) W[c1C[u] * LDW + w2C[u]] = aC[u][1] + dc.dt * vC[u];
-                        if (s1C[u]) W[w1C[u] * LDW + c2C[u]] = aC[u][2] + dc.dt * vC[u];
-                        if (s1C[u] && s2C[u]) W[w1C[u] * LDW + w2C[u]] = aC[u][3] + dc.dt * dc.dt * vC[u];
-                    }
-                }
-            }
-            BMPC_SYNC();
-            RPROF(8);
-            // C3: rank-3 part  D[i][j] = Y~[i] . E[:, j] + Y~[j] . E[:, i]  on the 21 columns j where E is
-            // nonzero: lane = column (three lane groups split the rows), two rows per batch
-            {
-                constexpr int G3 = NT / 21, NR = (NZ + G3 - 1) / G3, RB = 4, NB = (NR + RB - 1) / RB;   // row groups, rows per lane, rows per batch, batches
-                const bool act = lane < 21 * G3;
-                const int g3 = act ? lane / 21 : 0, jj = act ? lane - 21 * g3 : 0;
-                const int j = jj < 14 ? jj : Z_U + jj - 14;
-                LDSD* W = RL(R_W);
-                const double ej0 = RL(R_Et)[j], ej1 = RL(R_Et)[NZ + j], ej2 = RL(R_Et)[2 * NZ + j];
-                const double yj0 = RL(R_Y)[3 * j], yj1 = RL(R_Y)[3 * j + 1], yj2 = RL(R_Y)[3 * j + 2];
-                BMPC_UNROLL
-                for (int mb = 0; mb < NB; mb++) {
-                    double yi[RB][3], ei[RB][3], w0[RB], w1[RB];
-                    bool in_[RB], val[RB];
-                    int ii[RB];
-                    BMPC_UNROLL
-                    for (int u = 0; u < RB; u++) {
-                        const int i = g3 + G3 * (RB * mb + u);
-                        ii[u] = i; val[u] = act && (i < NZ);
-                        const int ic = val[u] ? i : 0;
-                        in_[u] = (ic < Z_DDQ) || (ic >= Z_U && ic < Z_DRS);
-                        BMPC_UNROLL
-                        for (int a = 0; a < 3; a++) { yi[u][a] = RL(R_Y)[3 * ic + a]; ei[u][a] = RL(R_Et)[a * NZ + ic]; }
-                        w0[u] = W[ic * LDW + j]; w1[u] = W[j * LDW + ic];
-                    }
-                    BMPC_UNROLL
-                    for (int u = 0; u < RB; u++) {
-                        if (val[u]) {
-                            double v = yi[u][0] * ej0 + yi[u][1] * ej1 + yi[u][2] * ej2 + yj0 * ei[u][0] + yj1 * ei[u][1] + yj2 * ei[u][2];
-                            W[ii[u] * LDW + j] = w0[u] + v;
-                            if (!in_[u]) W[j * LDW + ii[u]] = w1[u] + v;
-                        }
-                    }
-                }
-            }
-            if (lane < NZ) {
-                const int c = lane;
-                PhiCol pc = phi_col(c, dc);
-                double l3[3], v03[3], v13[3], lp[3], v0p[3], v1p[3], ea[3];
-                l3[0] = RL(R_lam)[pc.i0]; l3[1] = RL(R_lam)[pc.i1]; l3[2] = RL(R_lam)[pc.i2];
-                v03[0] = RL(R_vt0)[pc.i0]; v03[1] = RL(R_vt0)[pc.i1]; v03[2] = RL(R_vt0)[pc.i2];
-                v13[0] = RL(R_pv1)[pc.i0]; v13[1] = RL(R_pv1)[pc.i1]; v13[2] = RL(R_pv1)[pc.i2];
-                BMPC_UNROLL
-                for (int a = 0; a < 3; a++) { ea[a] = RL(R_Et)[a * NZ + c]; lp[a] = RL(R_lam)[Z_PI + a]; v0p[a] = RL(R_vt0)[Z_PI + a]; v1p[a] = RL(R_pv1)[Z_PI + a]; }
-                double gl = pc.c0 * l3[0] + pc.c1 * l3[1] + pc.c2 * l3[2];
-                double a0 = pc.c0 * v03[0] + pc.c1 * v03[1] + pc.c2 * v03[2];
-                double a1 = pc.c0 * v13[0] + pc.c1 * v13[1] + pc.c2 * v13[2];
-                BMPC_UNROLL
-                for (int a = 0; a < 3; a++) { gl += ea[a] * lp[a]; a0 += ea[a] * v0p[a]; a1 += ea[a] * v1p[a]; }
-                RL(R_gz)[c] += gl; RL(R_g0)[c] += a0; RL(R_g1)[c] += a1;
-            }
-        }
-        BMPC_SYNC();
-        RPROF(3);
-        // ---- adjoint multipliers + dual residual (gz now holds the Lagrangian gradient) ----
-        if (lane < NZ) {
-            double gl = RL(R_gz)[lane];
-            if (lane >= NX || (k == 1 && lane >= 24)) RL(R_acc)[128 + lane] = fmax(RL(R_acc)[128 + lane], fabs(gl));
-            if (lane < NX) { RL(R_lam)[lane] = gl; RL(R_acc)[lane] += fabs(gl); }
-        }
-        // ---- control block factorisation, gains, Schur complement ----
-        double Lc[45], invd[NU];
-        if (!chol9i(RL(R_W), reg, Lc, invd)) ok = false;
-        double* krec = A.krec + pi * KREC;
-        if (lane < NX + 2) {
-            double rhs[NU];
-            BMPC_UNROLL
-            for (int l = 0; l < NU; l++)
-                rhs[l] = (lane < NX) ? RL(R_W)[(NX + l) * LDW + lane] : (lane == NX ? RL(R_g0)[NX + l] : RL(R_g1)[NX + l]);
-            chol9i_solve(Lc, invd, rhs);
-            BMPC_UNROLL
-            for (int l = 0; l < NU; l++) {
-                if (lane < NX) { RL(R_Kl)[l * NX + lane] = -rhs[l]; krec[l * NX + lane] = -rhs[l]; }
-                else { RL(R_kf)[(lane - NX) * 16 + l] = -rhs[l]; krec[NU * NX + (lane - NX) * 16 + l] = -rhs[l]; }
-            }
-        }
-        BMPC_SYNC();
-        RPROF(4);
-        // P = W_xx + W_xu K: lane = column j (two half-waves split the rows), K[:, j] in registers,
-        // W_ux rows fetched two at a time as broadcast 16-byte reads; loads of a batch precede its stores
-        {
-            constexpr int NH = NT / 32, RPH = NX / NH;      // row blocks, rows per block
-            const int j = lane & 31, h = lane >> 5;
-            double kj[NU];
-            BMPC_UNROLL
-            for (int l = 0; l < NU; l++) kj[l] = RL(R_Kl)[l * NX + j];
-            const LDSD* W = RL(R_W);
-            {
-                BMPC_UNROLL
-                for (int ib = 0; ib < RPH / 4; ib++) {
-                    const int i0 = RPH * h + 4 * ib;
-                    bmpc_v2d wa[NU], wb[NU];
-                    BMPC_UNROLL
-                    for (int l = 0; l < NU; l++) {
-                        wa[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0);
-                        wb[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0 + 2);
-                    }
-                    double p0 = W[i0 * LDW + j], p1 = W[(i0 + 1) * LDW + j], p2 = W[(i0 + 2) * LDW + j], p3 = W[(i0 + 3) * LDW + j];
-                    BMPC_UNROLL
-                    for (int l = 0; l < NU; l++) { p0 += wa[l][0] * kj[l]; p1 += wa[l][1] * kj[l]; p2 += wb[l][0] * kj[l]; p3 += wb[l][1] * kj[l]; }
-                    RL(R_P)[i0 * LDP + j] = p0; RL(R_P)[(i0 + 1) * LDP + j] = p1;
-                    RL(R_P)[(i0 + 2) * LDP + j] = p2; RL(R_P)[(i0 + 3) * LDP + j] = p3;
-                }
-            }
-            // pv = g_x + W_xu kf (two right-hand sides)
-            if (lane < 2 * NX) {
-                const int i = lane & (NX - 1);
-                const LDSD* g = (lane < NX) ? RL(R_g0) : RL(R_g1);
-                const LDSD* kf = RL(R_kf) + ((lane < NX) ? 0 : 16);
-                double wv[NU], kv[NU];
-                BMPC_UNROLL
-                for (int l = 0; l < NU; l++) { wv[l] = W[(NX + l) * LDW + i]; kv[l] = kf[l]; }
-                double v = g[i];
-                BMPC_UNROLL
-                for (int l = 0; l < NU; l++) v += wv[l] * kv[l];
-                ((lane < NX) ? RL(R_pv0) : RL(R_pv1))[i] = v;
-            }
-        }
-        BMPC_SYNC();
-        RPROF(5);
+        ric_phase_load<NT>(A, lds, b, lane, k, hess_mode, tpk);
+        if (!term) ric_phase_couple<NT>(A, lds, lane);
+        if (!ric_phase_factor<NT>(A, lds, b, lane, k)) ok = false;
     }
     // |lambda| sum (lanes < 32 contribute) and dual-residual maximum (lanes < 41), in lane order
     BMPC_SYNC();
@@ -620,15 +655,15 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
 template <int NT>
 BMPC_NOINL bool ric_forward(const PipeArgsH& A, LDSD* lds, int b, int lane) {
     const double mu = lds[R_park + 11];
-    const int N = A.N;
-    const DynC dc = make_dync(A.o.dt);
     bool ok = true;
+    // 8 x 8 system of the free part of x_1, once per iteration: rolled loops on LDS operands (unrolled, this function alone
+    // claimed the whole register file); every lane computes it redundantly, lane 0 publishes the result
     {
         double Pf[36], rhs[8];
-        BMPC_UNROLL
+#pragma unroll 1
         for (int i = 0; i < 8; i++) {
             double s = RL(R_pv0)[24 + i] + mu * RL(R_pv1)[24 + i];
-            BMPC_UNROLL
+#pragma unroll 4
             for (int j = 0; j < 24; j++) s += RL(R_P)[(24 + i) * LDP + j] * RL(R_r0)[j];
             rhs[i] = -s;
         }
