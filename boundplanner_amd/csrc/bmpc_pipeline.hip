@@ -40,10 +40,17 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
-__global__ __launch_bounds__(BMPC_RIC_NT, BMPC_RIC_WPS) void bmpc_k_ric(PipeArgsH H) {
+__global__ __launch_bounds__(BMPC_RIC_NT, 2) void bmpc_k_ric(PipeArgsH H) {          // throughput variant: 2 wavefronts / SIMD
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
-    k_ric_body<BMPC_RIC_NT>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
+    k_ric_body<BMPC_RIC_NT, true>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
+__global__ __launch_bounds__(BMPC_RIC_NT, 1) void bmpc_k_ric_lat(PipeArgsH H) {      // latency variant for the straggler tail
+    __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
+    k_ric_body<BMPC_RIC_NT, false>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+#ifndef BMPC_RIC_LAT_BELOW
+#define BMPC_RIC_LAT_BELOW 512      // fewer active instances than this: the latency variant (every wavefront has a SIMD to itself anyway)
+#endif
 __global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
     __shared__ __attribute__((aligned(16))) double lds[FW_LDS_DOUBLES];
     k_fwd_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
@@ -110,7 +117,8 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
-    LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
+    if (n_act < BMPC_RIC_LAT_BELOW) LAUNCH(bmpc_k_ric_lat, n_act, BMPC_RIC_NT);
+    else LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH(bmpc_k_rowstep, nw, 256);      // + line-search start per instance

@@ -200,7 +200,7 @@ template <int NT> BMPC_DEV double rmin(double v, LDSD* red, int lane) {
 // zeta coordinates; coupling with stage k+1; adjoint, control-block factorisation, gains, Schur complement.  Integer and
 // pointer arguments only (see the note on floating-point arguments below).
 template <int NT>
-BMPC_NOINL void ric_phase_load(const PipeArgsH& A, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
+BMPC_INL void ric_phase_load_impl(const PipeArgsH& A, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
     const double hreg = lds[R_park + 12];
     const int N = A.N;
     const DynC dc = make_dync(A.o.dt);
@@ -324,7 +324,7 @@ BMPC_NOINL void ric_phase_load(const PipeArgsH& A, LDSD* lds, int b, int lane, i
 }
 
 template <int NT>
-BMPC_NOINL void ric_phase_couple(const PipeArgsH& A, LDSD* lds, int lane) {
+BMPC_INL void ric_phase_couple_impl(const PipeArgsH& A, LDSD* lds, int lane) {
     const DynC dc = make_dync(A.o.dt);
     const bool term = false;
     RPROF_START();
@@ -524,7 +524,7 @@ BMPC_NOINL void ric_phase_couple(const PipeArgsH& A, LDSD* lds, int lane) {
 }
 
 template <int NT>
-BMPC_NOINL bool ric_phase_factor(const PipeArgsH& A, LDSD* lds, int b, int lane, int k) {
+BMPC_INL bool ric_phase_factor_impl(const PipeArgsH& A, LDSD* lds, int b, int lane, int k) {
     const double reg = 1e-9;      // fixed regularisation of the control block
     const size_t pi = pair_of(A, b, k);
     bool ok = true;
@@ -600,7 +600,19 @@ BMPC_NOINL bool ric_phase_factor(const PipeArgsH& A, LDSD* lds, int b, int lane,
     return ok;
 }
 
-template <int NT>
+template <int NT> BMPC_NOINL void ric_phase_load(const PipeArgsH& A, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
+    ric_phase_load_impl<NT>(A, lds, b, lane, k, hess_mode, tpk);
+}
+template <int NT> BMPC_NOINL void ric_phase_couple(const PipeArgsH& A, LDSD* lds, int lane) { ric_phase_couple_impl<NT>(A, lds, lane); }
+template <int NT> BMPC_NOINL bool ric_phase_factor(const PipeArgsH& A, LDSD* lds, int b, int lane, int k) {
+    return ric_phase_factor_impl<NT>(A, lds, b, lane, k);
+}
+
+// SPLIT = true: the three phases are separate functions (230 VGPRs, two wavefronts per SIMD: the throughput variant, used while
+// many instances are alive); SPLIT = false: one body (the whole register file, one wavefront per SIMD, but 19 % less latency
+// per stage: nothing is recomputed at the phase boundaries) for the straggler tail, where latency is all that counts.
+// Same arithmetic either way.
+template <int NT, bool SPLIT>
 BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int hess_mode) {
     // no floating-point arguments: an odd-aligned 64-bit argument pair that gets spilled trips a
     // register-alignment bug of this compiler; scalars travel through LDS (R_park)
@@ -633,9 +645,15 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
         const size_t pi = pair_of(A, b, k);
-        ric_phase_load<NT>(A, lds, b, lane, k, hess_mode, tpk);
-        if (!term) ric_phase_couple<NT>(A, lds, lane);
-        if (!ric_phase_factor<NT>(A, lds, b, lane, k)) ok = false;
+        if constexpr (SPLIT) {
+            ric_phase_load<NT>(A, lds, b, lane, k, hess_mode, tpk);
+            if (!term) ric_phase_couple<NT>(A, lds, lane);
+            if (!ric_phase_factor<NT>(A, lds, b, lane, k)) ok = false;
+        } else {
+            ric_phase_load_impl<NT>(A, lds, b, lane, k, hess_mode, tpk);
+            if (!term) ric_phase_couple_impl<NT>(A, lds, lane);
+            if (!ric_phase_factor_impl<NT>(A, lds, b, lane, k)) ok = false;
+        }
     }
     // |lambda| sum (lanes < 32 contribute) and dual-residual maximum (lanes < 41), in lane order
     BMPC_SYNC();
@@ -791,7 +809,7 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
 }
 
 // lds: RIC_LDS_DOUBLES.  One workgroup (one wavefront) per entry of the eval list.
-template <int NT>
+template <int NT, bool SPLIT = true>
 BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
     const int count = A.L.cnt[0];
     if (blk >= count) return;
@@ -841,7 +859,7 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
     for (;;) {
         if (lane == 0) RL(R_park)[12] = hreg;
         BMPC_SYNC();
-        bool ok = ric_backward<NT>(A, lds, b, lane, hess_mode);
+        bool ok = ric_backward<NT, SPLIT>(A, lds, b, lane, hess_mode);
         const double lamsum = RL(R_park)[9], dual = RL(R_park)[10];
         if (first) {
             first = false;

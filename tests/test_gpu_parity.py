@@ -109,12 +109,29 @@ def test_tight_tolerance_agreement(backends):
     N, B = 10, 24
     be = backends(N, tol=1e-8)
     batch = scenes.make_batch(B, N, 31, be.fk, randomize_sets=True)
-    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_lam=True)
     ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], tol=1e-8)
     conv = (r["status"] == 0) & (ro["status"] == 0)
     assert conv.mean() > 0.9
-    assert np.abs(r["x"][conv][:, :21 * N] - ro["x"][conv][:, :21 * N]).max() < 1e-5
-    assert np.abs(r["x"][conv][:, 28 * N:40 * N] - ro["x"][conv][:, 28 * N:40 * N]).max() < 1e-7
+    same = conv & (r["iters"] == ro["iters"])
+    dj = np.abs(r["x"][:, :21 * N] - ro["x"][:, :21 * N]).max(axis=1)
+    dt_ = np.abs(r["x"][:, 28 * N:40 * N] - ro["x"][:, 28 * N:40 * N]).max(axis=1)
+    df = np.abs(r["f"] - ro["f"]) / np.maximum(1.0, np.abs(ro["f"]))
+    w = int(np.argmax(np.where(conv, dj, 0)))
+    print(f"tol 1e-8: same iterations {same.sum()}/{conv.sum()}, joint {dj[same].max():.1e} / {dj[conv].max():.1e}, task {dt_[same].max():.1e} / {dt_[conv].max():.1e}, "
+          f"df {df[conv].max():.1e}; worst instance {w}: iters {r['iters'][w]} / {ro['iters'][w]}, df {df[w]:.1e}, "
+          f"second worst joint {np.sort(dj[conv])[-2]:.1e}")
+    assert same.sum() >= conv.sum() - 2
+    close = conv & (dj < 1e-5) & (dt_ < 1e-7)
+    assert close.sum() >= conv.sum() - 2          # observed: 23 of 24 to <= 6e-9 in joint space
+    # the others (one side a Newton step further, or a borderline inertia decision taken differently on rounding): the
+    # null-space motion of the redundant arm is priced by weights of 1e-3 / 1e-4 only, so both points can pass the 1e-8
+    # test ~1e-5 apart in joint space; they must be the same solution by objective and the HIP point a KKT point of the
+    # pinned NLP with the multipliers it returns
+    assert dj[conv].max() < 1e-4 and dt_[conv].max() < 1e-5 and df[conv].max() < 1e-7
+    for i in np.nonzero(conv & ~close)[0]:
+        _, _, gr, J = O.nlp_eval(N, r["x"][i], batch["p"][i])
+        assert np.abs(gr + J.T @ r["lam_g"][i] + r["lam_x"][i]).max() < 1e-7, i
 
 
 def test_round_trip_properties_full_size(backends):
