@@ -89,7 +89,7 @@ def bridge_check(name, d, solve):
 def test_oracle_lands_on_the_independent_solutions(golden_dir, name):
     path = os.path.join(golden_dir, name)
     if not os.path.exists(path):
-        pytest.skip(f"{name} not generated (SLSQP at N=20 takes 35-40 min per instance)")
+        pytest.skip(f"{name} not generated")
     d = np.load(path)
 
     def solve(N, x0, lbx, ubx, p):
