@@ -44,6 +44,8 @@ struct bmpc_handle {
     size_t ws_blocks = 0;
     // pipeline engine workspace (grown on demand to the largest batch seen)
     int pipe_cap = 0;
+    // workspace layout (pipe_carve): slot-major; BMPC_LAYOUT=0 in the environment selects the field-major layout of round 1 (A/B runs)
+    int slot_major = [] { const char* e = getenv("BMPC_LAYOUT"); return e ? atoi(e) : 1; }();
     double* d_pipe = nullptr;      // one slab: SoA iterate/row arrays, stage records, gains, partials
     void* d_pipe_st = nullptr;     // InstState[cap]
     int* d_pipe_lists = nullptr;   // 7 lists + the slot -> row map of cap ints each + NCNT counters
@@ -249,8 +251,7 @@ static int pipe_ensure(bmpc_handle* h, int B) {
     if (h->d_pipe_st) { (void)hipFree(h->d_pipe_st); h->d_pipe_st = nullptr; }
     if (h->d_pipe_lists) { (void)hipFree(h->d_pipe_lists); h->d_pipe_lists = nullptr; }
     h->pipe_cap = 0;
-    const size_t NP = ((size_t)cap * (h->o.N - 1) + 63) / 64 * 64 + 64;
-    const size_t n = (3 * (size_t)NZ + 5 * (size_t)NSLOT + NPART + HREC + KREC) * NP + (size_t)cap * NX;
+    const size_t n = pipe_workspace_doubles(cap, h->o.N, h->slot_major);
     HIPCHK(h, hipMalloc((void**)&h->d_pipe, n * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_pipe_st, (size_t)cap * bmpc_pipe_state_bytes()));
     HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (8 * (size_t)cap + NCNT) * sizeof(int)));
@@ -272,14 +273,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.rc = h->d_rc;
     A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
     A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
-    const size_t NP = ((size_t)cap * (N - 1) + 63) / 64 * 64 + 64;
-    A.NP = NP;
-    double* w = h->d_pipe;
-    A.zeta = w; w += NZ * NP; A.zeta_t = w; w += NZ * NP; A.dz = w; w += NZ * NP;
-    A.t = w; w += NSLOT * NP; A.t_t = w; w += NSLOT * NP; A.z = w; w += NSLOT * NP; A.dt = w; w += NSLOT * NP;
-    A.dzr = w; w += NSLOT * NP;
-    A.part = w; w += NPART * NP;
-    A.hrec = w; w += HREC * NP; A.krec = w; w += KREC * NP; A.dx1 = w;
+    pipe_carve(A, h->d_pipe, cap, N, h->slot_major);
     A.st = (InstState*)h->d_pipe_st;
     int* L = h->d_pipe_lists;
     A.L.eval = L; A.L.step = L + cap; A.L.trial = L + 2 * (size_t)cap; A.L.eval_next = L + 3 * (size_t)cap;

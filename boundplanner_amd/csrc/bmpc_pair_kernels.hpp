@@ -594,7 +594,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     Emitter E;
-    E.init(lds, A.hrec, lane, m.pi, m.valid);
+    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid);
     BMPC_SYNC();
     StagePoint S;
     load_zeta(A.zeta, A.NP, m.pi, S.zeta);
@@ -776,7 +776,7 @@ BMPC_DEV void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     if (lds[EM_DOUBLES] == 0.0) return;          // uniform over the wavefront
     const DynC dc = make_dync(A.o.dt);
     Emitter E;
-    E.init(lds, A.hrec, lane, m.pi, m.valid, F_CQQ);
+    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid, F_CQQ);
     BMPC_SYNC();
     double zeta[NZ], y[NZ];
     load_zeta(A.zeta, A.NP, m.pi, zeta);
@@ -1366,7 +1366,7 @@ BMPC_DEV void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
         cq[j] = sq; cdq[j] = sd;
     }
     point_forces_to_q<0>(S.K, V.Fc, cq);
-    GD rec = A.hrec + pi * HREC;
+    GD rec = A.hrec + hrec_of(A, m.b, m.k);
     BMPC_UNROLL
     for (int j = 0; j < 7; j++) { rec[M_CQ + j] = cq[j]; rec[M_CDQ + j] = cdq[j]; rec[M_CDDQ + j] = V.lxddq[j]; }
     BMPC_UNROLL

@@ -108,13 +108,16 @@ template <int DEV> struct PipeArgsT {
     typename PT::D x, f, viol, g;
     typename PT::I iters, status;
     // workspace
-    size_t NP;                           // pair stride of the SoA arrays (>= B*(N-1))
-    typename PT::D zeta, zeta_t, dz;     // [41][NP]
-    typename PT::D t, t_t, z, dt, dzr;   // [NSLOT][NP]
-    typename PT::D hrec;                 // [pairs][HREC]
-    typename PT::D krec;                 // [pairs][KREC]
+    // element (field f, slot b, stage k) of an SoA array lives at  f * NP + b * SS + (k - 1);  the record of (b, k) at
+    // b * HS + (k - 1) * HREC (KS, KREC for the gains).  Two layouts (pipe_carve): field-major (NP = pairs of the whole pool,
+    // SS = N-1) and slot-major (all arrays of a slot in one block: NP = N-1, SS = HS = KS = block size)
+    size_t NP, SS, HS, KS;
+    typename PT::D zeta, zeta_t, dz;     // 41 fields
+    typename PT::D t, t_t, z, dt, dzr;   // NSLOT fields
+    typename PT::D hrec;                 // HREC doubles per pair
+    typename PT::D krec;                 // KREC doubles per pair
     typename PT::D dx1;                  // [B][32] step of x_1 (k_ric -> k_fwd)
-    typename PT::D part;                 // [NPART][NP]
+    typename PT::D part;                 // NPART fields
     typename PT::S st;                   // [slots]
     typename PT::I src;                  // [slots] input / output row of the instance in the slot (streaming: B rows
                                          // pass through fewer slots, a slot is refilled when its instance has retired)
@@ -130,7 +133,32 @@ typedef PipeArgsT<1> PipeArgs;           // device view (same layout)
 static_assert(sizeof(PipeArgsH) == sizeof(PipeArgs), "host/device argument layouts differ");
 typedef BMPC_AS1 InstState* GST;
 
-template <class AT> BMPC_INL size_t pair_of(const AT& A, int b, int k) { return (size_t)b * (A.N - 1) + (k - 1); }
+template <class AT> BMPC_INL size_t pair_of(const AT& A, int b, int k) { return (size_t)b * A.SS + (k - 1); }      // SoA offset
+template <class AT> BMPC_INL size_t hrec_of(const AT& A, int b, int k) { return (size_t)b * A.HS + (size_t)(k - 1) * HREC; }
+template <class AT> BMPC_INL size_t krec_of(const AT& A, int b, int k) { return (size_t)b * A.KS + (size_t)(k - 1) * KREC; }
+
+// workspace of `cap` slots: size in doubles, and the array bases inside it
+constexpr size_t PIPE_SOA_FIELDS = 3 * (size_t)NZ + 5 * (size_t)NSLOT + NPART;
+inline size_t pipe_slot_block(int N) { return ((PIPE_SOA_FIELDS + HREC + KREC) * (size_t)(N - 1) + 15) / 16 * 16 + 16; }
+inline size_t pipe_np_field_major(int cap, int N) { return ((size_t)cap * (N - 1) + 63) / 64 * 64 + 64; }
+inline size_t pipe_workspace_doubles(int cap, int N, int slot_major) {
+    return (slot_major ? pipe_slot_block(N) * (size_t)cap + 64
+                       : (PIPE_SOA_FIELDS + HREC + KREC) * pipe_np_field_major(cap, N)) + (size_t)cap * NX;
+}
+template <class AT> inline void pipe_carve(AT& A, double* w, int cap, int N, int slot_major) {
+    const size_t S = (size_t)(N - 1);
+    if (slot_major) { A.NP = S; A.SS = A.HS = A.KS = pipe_slot_block(N); }
+    else { A.NP = pipe_np_field_major(cap, N); A.SS = S; A.HS = S * HREC; A.KS = S * KREC; }
+    const size_t NP = A.NP;
+    double* w0 = w;
+    A.zeta = w; w += NZ * NP; A.zeta_t = w; w += NZ * NP; A.dz = w; w += NZ * NP;
+    A.t = w; w += NSLOT * NP; A.t_t = w; w += NSLOT * NP; A.z = w; w += NSLOT * NP; A.dt = w; w += NSLOT * NP;
+    A.dzr = w; w += NSLOT * NP;
+    A.part = w; w += NPART * NP;
+    if (slot_major) w = w0 + ((size_t)(w - w0) + 15) / 16 * 16;      // records 128-byte aligned inside the slot block
+    A.hrec = w; w += HREC * NP; A.krec = w; w += KREC * NP;
+    A.dx1 = slot_major ? w0 + pipe_slot_block(N) * (size_t)cap + 64 : w;
+}
 
 // parameters of the instances of a wavefront are staged in LDS (every thread reads ~500 of them):
 // pointer type of the staged copy
@@ -180,11 +208,11 @@ struct Emitter {
     LDSD* tile;        // [16][EM_LD]
     GD out;            // record array base
     int lane, f;
-    BMPC_INL void init(LDSD* lds, GD out_, int lane_, size_t pi, bool valid, int f0 = 0) {
-        tile = lds; out = out_; lane = lane_; f = f0;     // f0: multiple of 16
+    BMPC_INL void init(LDSD* lds, GD out_, int lane_, size_t rec, bool valid, int f0 = 0) {
+        tile = lds; out = out_; lane = lane_; f = f0;     // f0: multiple of 16; rec: offset of this lane's record in `out`
         // publish every lane's record base (exact in a double: < 2^53) for the transposed store;
         // -1 = this lane must not store
-        lds[16 * EM_LD + lane] = valid ? (double)(pi * HREC) : -1.0;
+        lds[16 * EM_LD + lane] = valid ? (double)rec : -1.0;
     }
     BMPC_INL void put(double v) {
         tile[(f & 15) * EM_LD + lane] = v;

@@ -246,7 +246,7 @@ BMPC_INL void ric_phase_load_impl(const PipeArgsH& A, LDSD* lds, int b, int lane
         BMPC_SYNC();
     }
     // every lane has consumed the staged record: fetch the next stage's behind the rest of this stage
-    if (k > 1) bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + (pi - 1) * HREC), RL(R_stage), lane);
+    if (k > 1) bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + hrec_of(A, b, k - 1)), RL(R_stage), lane);
     RPROF(0);
     // ---- second-order term of the pi dynamics: multiplier lam_pi(k+1) times d2(dt w)/d(q,dq)2 ----
     if (hess_mode && !term) {
@@ -540,7 +540,7 @@ BMPC_INL bool ric_phase_factor_impl(const PipeArgsH& A, LDSD* lds, int b, int la
     // ---- control block factorisation, gains, Schur complement ----
     double Lc[45], invd[NU];
     if (!chol9i(RL(R_W), reg, Lc, invd)) ok = false;
-    double* krec = A.krec + pi * KREC;
+    double* krec = A.krec + krec_of(A, b, k);
     if (lane < NX + 2) {
         double rhs[NU];
         BMPC_UNROLL
@@ -641,7 +641,7 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
     }
     constexpr int NE2 = (NZ * 9 + 27 + NT - 1) / NT;
     static_assert((NT == 64 || NT == 128) && HREC % 128 == 0, "record DMA: 1 KiB per wavefront instruction");
-    bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + pair_of(A, b, N - 1) * HREC), RL(R_stage), lane);
+    bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + hrec_of(A, b, N - 1)), RL(R_stage), lane);
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
         const size_t pi = pair_of(A, b, k);
@@ -749,8 +749,8 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
     double fK[NK], fkf = 0, few = 0, frd = 0;      // stage data in flight (prefetched one stage ahead)
     auto fetch = [&](int k) {
         const size_t pi = pair_of(A, b, k);
-        GCD krec = A.krec + pi * KREC;
-        GCD rec = A.hrec + pi * HREC;
+        GCD krec = A.krec + krec_of(A, b, k);
+        GCD rec = A.hrec + hrec_of(A, b, k);
         BMPC_UNROLL
         for (int m = 0; m < NK; m++) { int e = lane + 64 * m; fK[m] = (e < NU * NX) ? krec[e] : 0.0; }
         if (lane < 32) fkf = krec[NU * NX + lane];
@@ -998,7 +998,7 @@ BMPC_DEV void k_mult_sweep_body(const PipeArgs& A, int b) {
     double lq[7], ldq[7], lddq[7], lprot[3] = {0, 0, 0}, lrs = 0, lps = 0;
     for (int j = 0; j < 7; j++) { lq[j] = 0; ldq[j] = 0; lddq[j] = 0; }
     for (int k = N - 1; k >= 1; k--) {
-        GCD rec = A.hrec + pair_of(A, b, k) * HREC;
+        GCD rec = A.hrec + hrec_of(A, b, k);
         GD blk = lg + 35 * (k - 1);
         const double n0 = lprot[0], n1 = lprot[1], n2 = lprot[2];          // lam_p_rot of the next block
         double nq[7], ndq[7], nddq[7];

@@ -77,16 +77,14 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.p = p;
     A.x = x; A.f = f; A.viol = viol; A.g = g; A.iters = iters; A.status = status;
     const int cap = (slots > 0 && slots < B) ? slots : B;       // pool of `cap` slots: B > cap streams through it
-    const size_t NP = ((size_t)cap * (N - 1) + 63) / 64 * 64 + 64;
-    A.NP = NP;
-    std::vector<double> zeta(NZ * NP), zeta_t(NZ * NP), dz(NZ * NP), t(NSLOT * NP, 1.0), t_t(NSLOT * NP, 1.0),
-        z(NSLOT * NP), dtv(NSLOT * NP), dzr(NSLOT * NP), hrec(NP * HREC), krec(NP * KREC), part(NPART * NP), dx1v((size_t)cap * NX);
+    const char* lay = getenv("BMPC_LAYOUT");
+    const int slot_major = lay ? atoi(lay) : 1;
+    std::vector<double> work(pipe_workspace_doubles(cap, N, slot_major));
+    pipe_carve(A, work.data(), cap, N, slot_major);
     std::vector<InstState> st(cap);
     std::vector<int> l_eval(cap), l_step(cap), l_trial(cap), l_evn(cap), l_trn(cap), l_done(cap), l_admit(cap), srcv(cap), cnt(NCNT, 0), tbl(3 * HREC);
     build_scatter_table(tbl.data());
-    A.zeta = zeta.data(); A.zeta_t = zeta_t.data(); A.dz = dz.data();
-    A.t = t.data(); A.t_t = t_t.data(); A.z = z.data(); A.dt = dtv.data(); A.dzr = dzr.data();
-    A.hrec = hrec.data(); A.krec = krec.data(); A.dx1 = dx1v.data(); A.part = part.data(); A.st = st.data();
+    A.st = st.data();
     A.L.eval = l_eval.data(); A.L.step = l_step.data(); A.L.trial = l_trial.data();
     A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
     A.L.done = l_done.data(); A.L.admit = l_admit.data(); A.src = srcv.data();

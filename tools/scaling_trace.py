@@ -1,0 +1,54 @@
+"""Per-kernel duration against the number of live instances: solves the first B instances of one configs[2] batch for a few
+interior-point iterations (max_iter 4: every instance is alive in every super-step), B = 256 ... 8192.  Run under
+`rocprofv3 --kernel-trace`, then `python tools/scaling_trace.py --parse <kernel_trace.csv>` prints, per B, the mean duration
+of each pipeline kernel over the super-steps of that solve.  One wavefront per SIMD = 1024 wavefronts = 3072 instances at N=20."""
+import argparse
+import collections
+import csv
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SIZES = [256, 1024, 2048, 3072, 4096, 6144, 8192]
+
+
+def run():
+    import numpy as np
+    import torch  # noqa: F401  (HIP runtime first)
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N = 20
+    be = HipBoundMPC(N, max_iter=4)
+    d = scenes.make_batch(max(SIZES), N, 8192, be.fk, randomize_sets=True)
+    x0, lbx, ubx, p = d["x0"], d["lbx"], d["ubx"], d["p"]
+    for B in SIZES:
+        r = be.solve_batch(x0[:B], lbx[:B], ubx[:B], p[:B])
+        print(B, int(r["iters"].max()), flush=True)
+
+
+def parse(path):
+    rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith("bmpc_k_")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    solves, cur = [], []
+    for r in rows:
+        name = r["Kernel_Name"].split("(")[0]
+        if name == "bmpc_k_init_inst" and cur:
+            solves.append(cur); cur = []
+        cur.append((name, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
+    solves.append(cur)
+    names = ["bmpc_k_points", "bmpc_k_eval", "bmpc_k_curv", "bmpc_k_ric", "bmpc_k_ric_lat", "bmpc_k_fwd", "bmpc_k_step", "bmpc_k_rowstep",
+             "bmpc_k_trial", "bmpc_k_rowtrial"]
+    print("B      " + " ".join(f"{n[7:]:>9s}" for n in names) + "   (mean us per launch; k_eval workgroups)")
+    for B, sv in zip(SIZES, solves):
+        d = collections.defaultdict(list)
+        for n, us, wg in sv:
+            d[n].append(us)
+        wg = max(w for n, _, w in sv if n == "bmpc_k_eval")
+        print(f"{B:6d} " + " ".join(f"{(sum(d[n]) / len(d[n]) if d[n] else 0):9.1f}" for n in names) + f"   {wg}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--parse")
+    a = ap.parse_args()
+    parse(a.parse) if a.parse else run()
