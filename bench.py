@@ -24,6 +24,10 @@ import time
 
 import numpy as np
 
+# Four solver calls in flight need four hardware queues of their own; the HIP runtime's default is 4 per process, one of which
+# the null stream holds (a fourth stream would share a queue and serialise).  Set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -88,7 +92,7 @@ def main():
     ap.add_argument("--wpi", type=int, default=None, help="wavefronts per instance (1, 2, 4)")
     ap.add_argument("--bpc", type=int, default=None, help="resident workgroups per CU")
     ap.add_argument("--depth", type=int, default=None, help="solver calls in flight (the straggler tail of one overlaps the bulk of "
-                    "the next); 1: one at a time.  Default 3")
+                    "the next); 1: one at a time.  Default 4 (with GPU_MAX_HW_QUEUES=8, set above)")
     ap.add_argument("--merge", type=int, default=2, help="--pool 0 only: batches handed to the solver per call (they are "
                     "independent: a larger launch amortises the straggler tail over more bulk work)")
     ap.add_argument("--gate", type=float, default=1.0, help="start the next solver call when the others have < gate * their instances "
@@ -115,7 +119,7 @@ def main():
 
     from boundplanner_amd import scenes
     N, B = args.horizon, args.batch
-    depth = max(1, min(args.depth if args.depth is not None else 3, 4))
+    depth = max(1, min(args.depth if args.depth is not None else 4, 4))
     M = max(1, min(args.merge, 4))
     if args.pool > 0:
         M = max(1, min((args.steps + depth - 1) // depth, MAX_DISTINCT))      # the timed batches in `depth` streaming calls

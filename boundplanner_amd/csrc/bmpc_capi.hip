@@ -48,7 +48,7 @@ struct bmpc_handle {
     int slot_major = [] { const char* e = getenv("BMPC_LAYOUT"); return e ? atoi(e) : 1; }();
     double* d_pipe = nullptr;      // one slab: SoA iterate/row arrays, stage records, gains, partials
     void* d_pipe_st = nullptr;     // InstState[cap]
-    int* d_pipe_lists = nullptr;   // 7 lists + the slot -> row map of cap ints each + NCNT counters
+    int* d_pipe_lists = nullptr;   // 8 lists + the slot -> row map of cap ints each + NCNT counters
     int* d_pipe_tbl = nullptr;     // scatter table of the stage record
     int* h_cnt = nullptr;          // pinned host copy of the counters
     int last_steps = 0;
@@ -254,7 +254,7 @@ static int pipe_ensure(bmpc_handle* h, int B) {
     const size_t n = pipe_workspace_doubles(cap, h->o.N, h->slot_major);
     HIPCHK(h, hipMalloc((void**)&h->d_pipe, n * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_pipe_st, (size_t)cap * bmpc_pipe_state_bytes()));
-    HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (8 * (size_t)cap + NCNT) * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (9 * (size_t)cap + NCNT) * sizeof(int)));
     h->pipe_cap = cap;
     return 0;
 }
@@ -278,7 +278,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     int* L = h->d_pipe_lists;
     A.L.eval = L; A.L.step = L + cap; A.L.trial = L + 2 * (size_t)cap; A.L.eval_next = L + 3 * (size_t)cap;
     A.L.trial_next = L + 4 * (size_t)cap; A.L.done = L + 5 * (size_t)cap; A.L.admit = L + 6 * (size_t)cap;
-    A.src = L + 7 * (size_t)cap; A.L.cnt = L + 8 * (size_t)cap;
+    A.src = L + 7 * (size_t)cap; A.L.curv = L + 8 * (size_t)cap; A.L.cnt = L + 9 * (size_t)cap;
     A.tbl = h->d_pipe_tbl;
     A.prof = h->d_prof;
     A.lam_g = nullptr; A.lam_x = nullptr;

@@ -716,6 +716,11 @@ BMPC_DEV void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     const int count = A.L.cnt[0], N = A.N;
     if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    // instances in hess_mode get their second-order terms from k_curv: list them (any order: per-pair arithmetic only)
+    if (m.valid && m.k == 1 && A.o.hess == 2 && A.st[m.b].hess_mode) {
+        int pos = BMPC_ATOMIC_INC(A.L.cnt + 10);
+        A.L.curv[pos] = m.b;
+    }
     const DynC dc = make_dync(A.o.dt);
     PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds_par);
     double zeta[NZ], y[NZ];
@@ -763,17 +768,12 @@ BMPC_DEV void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 
 // ------------------------------------------------------------------------------------------
 // k_curv: second-order kinematic terms of the Lagrangian Hessian (record fields F_CQQ, F_CQD) for the
-// instances in hess_mode; forces from k_eval.  Skipped by wavefronts without such an instance.
+// instances in hess_mode (the list k_points built: wavefronts made of such instances only); forces from k_eval.
 // ------------------------------------------------------------------------------------------
 BMPC_DEV void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
-    const int count = A.L.cnt[0], N = A.N;
+    const int count = A.L.cnt[10], N = A.N;
     if (A.o.hess != 2 || wave * ipw_of(N) >= count) return;
-    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
-    if (lane == 0) lds[EM_DOUBLES] = 0.0;
-    BMPC_SYNC();
-    if (A.st[m.b].hess_mode) lds[EM_DOUBLES] = 1.0;
-    BMPC_SYNC();
-    if (lds[EM_DOUBLES] == 0.0) return;          // uniform over the wavefront
+    PairMap m = pair_map(A, A.L.curv, count, wave, lane);
     const DynC dc = make_dync(A.o.dt);
     Emitter E;
     E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid, F_CQQ);
@@ -1050,7 +1050,7 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
     return false;
 }
 
-// k_rowstep: dt = c - t (c from k_step), dz_row = (mu - t z - z dt) / t, fraction-to-boundary step lengths and the
+// k_rowstep: dt = c - t (c from k_step, left in A.dt), dz_row = (mu - t z - z dt) / t, fraction-to-boundary step lengths and the
 // barrier part of the merit derivative, reduced over the pair in slot-group order; then, the pairs of an instance
 // being lanes of this workgroup, the line-search start of every instance in it (what a kernel of its own did before)
 BMPC_DEV void k_rowstep_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
@@ -1067,7 +1067,7 @@ BMPC_DEV void k_rowstep_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
             double t = A.t[o], rt = 1.0 / t;
             double dti = A.dt[o] - t;
             double dzi = (mu - t * z - z * dti) * rt;
-            if (m.valid) { A.dt[o] = dti; A.dzr[o] = dzi; }
+            if (m.valid) A.dzr[o] = dzi;      // dt stays in k_step's form (c = t + dt): k_rowtrial subtracts t again
             rp = fmax(rp, -dti * rt); rd = fmax(rd, -dzi / z);
             dbar -= mu * dti * rt;
         }
@@ -1098,7 +1098,8 @@ BMPC_DEV void k_rowtrial_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
     for (int s = g; s < NSLOT; s += ROW_GROUPS) {
         size_t o = (size_t)s * A.NP + m.pi;
         if (A.z[o] > 0.0) {
-            double tn = A.t[o] + alpha * A.dt[o];
+            const double t = A.t[o];
+            double tn = t + alpha * (A.dt[o] - t);
             th += fabs(A.t_t[o] + tn); ls += log(tn);
             if (m.valid) A.t_t[o] = tn;
         }

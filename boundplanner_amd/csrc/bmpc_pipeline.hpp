@@ -93,9 +93,10 @@ template <> struct PtrT<1> {
 
 template <int DEV> struct ListsT {           // work lists (slot ids) with their counters
     typename PtrT<DEV>::I eval, step, trial, eval_next, trial_next;
+    typename PtrT<DEV>::I curv;          // slots whose instance is in hess_mode this super-step (k_points appends, k_curv consumes)
     typename PtrT<DEV>::I done, admit;   // slots whose instance finished (to retire) / slots that got a new instance (to initialise)
     typename PtrT<DEV>::I cnt;   // [0] n_eval [1] n_step [2] n_trial [3] n_eval_next [4] n_trial_next [5] finished (cumulative)
-                                 // [6] next input row to admit [7] retired (cumulative) [8] n_done [9] n_admit
+                                 // [6] next input row to admit [7] retired (cumulative) [8] n_done [9] n_admit [10] n_curv
 };
 constexpr int NCNT = 12;
 

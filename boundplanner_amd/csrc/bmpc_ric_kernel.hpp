@@ -970,7 +970,7 @@ BMPC_DEV void k_pool_reset_body(const PipeArgs& A, bool done_too) {
 // rotate the list counters between super-steps (one thread)
 BMPC_DEV void k_rotate_body(const PipeArgs& A) {
     GI c = A.L.cnt;
-    c[0] = c[3]; c[3] = 0; c[1] = 0; c[2] = c[4]; c[4] = 0;
+    c[0] = c[3]; c[3] = 0; c[1] = 0; c[2] = c[4]; c[4] = 0; c[10] = 0;
 }
 
 // per-instance outputs after k_out (done list)

@@ -82,12 +82,12 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     std::vector<double> work(pipe_workspace_doubles(cap, N, slot_major));
     pipe_carve(A, work.data(), cap, N, slot_major);
     std::vector<InstState> st(cap);
-    std::vector<int> l_eval(cap), l_step(cap), l_trial(cap), l_evn(cap), l_trn(cap), l_done(cap), l_admit(cap), srcv(cap), cnt(NCNT, 0), tbl(3 * HREC);
+    std::vector<int> l_eval(cap), l_step(cap), l_trial(cap), l_evn(cap), l_trn(cap), l_done(cap), l_admit(cap), l_curv(cap), srcv(cap), cnt(NCNT, 0), tbl(3 * HREC);
     build_scatter_table(tbl.data());
     A.st = st.data();
     A.L.eval = l_eval.data(); A.L.step = l_step.data(); A.L.trial = l_trial.data();
     A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
-    A.L.done = l_done.data(); A.L.admit = l_admit.data(); A.src = srcv.data();
+    A.L.done = l_done.data(); A.L.admit = l_admit.data(); A.L.curv = l_curv.data(); A.src = srcv.data();
     A.tbl = tbl.data();
     std::vector<double> lds(std::max<size_t>(pair_lds_doubles(N, true), RIC_LDS_DOUBLES) + 64);
     const int n0 = cap;
@@ -112,7 +112,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         if (verbose) printf("step %d: n_eval %d n_trial %d finished %d retired %d next row %d\n", steps, cnt[0], cnt[2], cnt[5], cnt[7], cnt[6]);
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_points_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
-        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
+        launch(waves_for(N, cnt[10]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
         launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
         launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
