@@ -58,7 +58,9 @@ template <class F> static void launch(int nblocks, F body, int nt = 64) {
     for (int l = 0; l < nt; l++)
         th.emplace_back([&, l] {
             t_lane = l;
-            for (int blk = 0; blk < nblocks; blk++) body(blk, l);
+            // workgroups run one after the other on the same LDS buffer: nobody starts the next one's LDS writes
+            // while a slower lane still reads this one's
+            for (int blk = 0; blk < nblocks; blk++) { body(blk, l); bar.arrive_and_wait(); }
         });
     for (auto& t : th) t.join();
 }

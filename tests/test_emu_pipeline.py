@@ -40,3 +40,18 @@ def test_emulated_pool_streams_more_instances_than_slots():
     for k in ("x", "g", "f", "iters", "status", "viol"):
         assert np.array_equal(full[k], pool[k]), k
     assert (full["status"] == 0).all() and len(set(full["iters"].tolist())) > 1      # they finish at different times
+
+
+def test_emulated_pipeline_several_wavefronts_per_kernel():
+    """N = 18: three instances per wavefront, 5 instances = one full and one ragged wavefront per thread-per-pair kernel (the
+    emulator runs the workgroups of a launch one after the other on one LDS buffer, with a barrier between them), and the
+    same through a pool of 2 slots."""
+    N, B = 18, 5
+    batch = scenes.make_batch(B, N, 18, O.fk_batch, randomize_sets=True)
+    ro = O.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], nthreads=1)
+    r = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    assert np.array_equal(r["status"], ro["status"]) and np.array_equal(r["iters"], ro["iters"])
+    assert np.abs(r["x"] - ro["x"]).max() < 1e-5
+    pool = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True, slots=2)
+    for k in ("x", "g", "f", "iters", "status", "viol"):
+        assert np.array_equal(r[k], pool[k]), k
