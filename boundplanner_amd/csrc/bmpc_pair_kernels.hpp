@@ -90,7 +90,7 @@ BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
     GCD x0 = A.x0 + row * n_w;
     GCD lbx = A.lbx + row * n_w;
     GCD ubx = A.ubx + row * n_w;
-    PGP pg = stage_params(A, A.L.admit, count, wave, lane, m, lds_par);
+    PGP pg = stage_params<false>(A, A.L.admit, count, wave, lane, m, lds_par);
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
@@ -190,8 +190,11 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
     }
     BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
         size_t o = (size_t)s * A->NP + pi;
-        double t = A->t[o];          // read-only here: the accepted trial was made current by k_rowtrial (loads can run ahead)
-        zz = A->z[o];
+        row_tz(A->t[o], A->z[o], h, sg, r0, r1, zz);     // read-only here: the accepted trial was made current by k_rowtrial
+    }
+    // the same with the slack t and the multiplier z of the row already in registers (RowPre)
+    BMPC_INL void row_tz(double t, double z_in, double h, double& sg, double& r0, double& r1, double& zz) {
+        zz = z_in;
         r1 = 1.0 / t; sg = zz * r1; r0 = sg * (h + t);
         double c = t * zz;
         cmax = fmax(cmax, c); csum += c; cmin = fmin(cmin, c); zsum += zz;
@@ -200,10 +203,35 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
     }
 };
 
+// Row data (t, z) of the contiguous slots S0 .. S0+CNT-1 and box bounds of the dg positions I0 .. I0+CNT-1, loaded in one
+// batch ahead of their use: a thread that loads them where the row is walked waits one memory round trip per row (the
+// walk is conditional, the compiler cannot hoist the loads), and those round trips are what bounds the thread-per-pair kernels
+template <int S0_, int CNT_> struct RowPre {
+    static constexpr int S0 = S0_, CNT = CNT_;
+    double t[CNT_], z[CNT_];
+    BMPC_INL void load(const PipeArgs& A, size_t pi) {
+        BMPC_UNROLL
+        for (int i = 0; i < CNT_; i++) { size_t o = (size_t)(S0_ + i) * A.NP + pi; t[i] = A.t[o]; z[i] = A.z[o]; }
+    }
+};
+template <int I0_, int CNT_> struct BndPre {
+    static constexpr int I0 = I0_, CNT = CNT_;
+    double ub[CNT_], lb[CNT_];
+    BMPC_INL void load(GCD lbx, GCD ubx, int N, int k) {
+        BMPC_UNROLL
+        for (int i = 0; i < CNT_; i++) {
+            const int I = I0_ + i, blk = I / 7, jj = I % 7;
+            size_t wi = (size_t)blk * 7 * N + (size_t)jj * N + k;
+            ub[i] = ubx[wi]; lb[i] = lbx[wi];
+        }
+    }
+};
+
 struct PointAsm {
     RowAcc* R; const KinT* K;
     double M3[6], mc[3], sc, b30[3], b31[3], b3z[3], bc0, bc1, bcz;
     double Hqq[28], gq0[7], gq1[7], gqz[7], dD[6], gD0[6], gD1[6], gDz[6], cd[6][7], Fc[6][3];
+    double pt[15], pz[15];        // row data of the current point's 15 slots, loaded in one batch (see RowPre)
     BMPC_INL void init() {
         BMPC_UNROLL
         for (int i = 0; i < 28; i++) Hqq[i] = 0;
@@ -213,6 +241,8 @@ struct PointAsm {
     BMPC_INL void skip(int) {}
     template <int C> BMPC_INL void point_begin() {
         BMPC_UNROLL
+        for (int i = 0; i < 15; i++) { size_t o = (size_t)(S_COL + 15 * C + i) * R->A->NP + R->pi; pt[i] = R->A->t[o]; pz[i] = R->A->z[o]; }
+        BMPC_UNROLL
         for (int i = 0; i < 6; i++) M3[i] = 0;
         BMPC_UNROLL
         for (int i = 0; i < 3; i++) { mc[i] = 0; b30[i] = 0; b31[i] = 0; b3z[i] = 0; }
@@ -220,7 +250,7 @@ struct PointAsm {
     }
     template <int C> BMPC_INL void point(int s, const double* a, double h) {
         double sg, r0, r1, zz;
-        R->row(s, h, sg, r0, r1, zz);
+        R->row_tz(pt[s - (S_COL + 15 * C)], pz[s - (S_COL + 15 * C)], h, sg, r0, r1, zz);
         BMPC_UNROLL
         for (int i = 0; i < 3; i++) {
             BMPC_UNROLL
@@ -262,12 +292,31 @@ struct PointAsm {
 // results of k_points for one pair, loaded from the side array where they are needed
 struct PointRes {
     GCD base; size_t NP;      // base = A.part + PT_SIDE * NP + pair
+    // loaded one batch per consuming phase of k_eval (see RowPre): q-block pieces for p17_emit_all, the q x q block for
+    // chain_all, the d-column pieces for dg_emit_all
+    double cd5_[7], gq_[21], hqq_[28], dD_[6], gD_[18];
     BMPC_INL double at(int slot) const { return base[(size_t)slot * NP]; }
-    BMPC_INL double cd5(int i) const { return at(SD_CD5 + i); }
-    BMPC_INL double hqq(int e) const { return at(SD_HQQ + e); }
-    BMPC_INL double gq(int v, int i) const { return at(SD_GQ + 7 * v + i); }
-    BMPC_INL double dD(int c) const { return at(SD_DD + c); }
-    BMPC_INL double gD(int v, int c) const { return at(SD_GD + 6 * v + c); }
+    BMPC_INL void load_p17() {
+        BMPC_UNROLL
+        for (int i = 0; i < 7; i++) cd5_[i] = at(SD_CD5 + i);
+        BMPC_UNROLL
+        for (int i = 0; i < 21; i++) gq_[i] = at(SD_GQ + i);
+    }
+    BMPC_INL void load_hqq() {
+        BMPC_UNROLL
+        for (int i = 0; i < 28; i++) hqq_[i] = at(SD_HQQ + i);
+    }
+    BMPC_INL void load_dg() {
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) dD_[i] = at(SD_DD + i);
+        BMPC_UNROLL
+        for (int i = 0; i < 18; i++) gD_[i] = at(SD_GD + i);
+    }
+    BMPC_INL double cd5(int i) const { return cd5_[i]; }
+    BMPC_INL double hqq(int e) const { return hqq_[e]; }
+    BMPC_INL double gq(int v, int i) const { return gq_[7 * v + i]; }
+    BMPC_INL double dD(int c) const { return dD_[c]; }
+    BMPC_INL double gD(int v, int c) const { return gD_[6 * v + c]; }
 };
 
 struct PoseAsm {
@@ -286,9 +335,9 @@ struct PoseAsm {
         for (int i = 0; i < 6; i++) { bp0[i] = g12[i]; bpz[i] = g12[i]; bp1[i] = 0; }
     }
     // NA = number of leading nonzero coefficients (3 for position-only rows)
-    template <int NA, int SEL> BMPC_INL void add(int s, const double* a, double h) {
+    template <int NA, int SEL> BMPC_INL void add(const double* a, double h, double t, double z) {
         double sg, r0, r1, zz;
-        R->row(s, h, sg, r0, r1, zz);
+        R->row_tz(t, z, h, sg, r0, r1, zz);
         BMPC_UNROLL
         for (int i = 0; i < NA; i++) {
             BMPC_UNROLL
@@ -300,10 +349,11 @@ struct PoseAsm {
     }
 };
 
-// pose rows of one stage in slot order, for any visitor exposing add<NA, SEL>(s, a, h)
-template <class V>
-BMPC_INL void walk_pose_rows(PGP pg, int N, int k, const double* y, const SegCtx& C, V& v) {
-    const bool term = (k == N - 1);
+// pose rows of one stage in slot order, for any visitor exposing add<NA, SEL>(a, h, t, z); row data from the preloaded
+// groups g1 (S_EE .. S_ROTL+2), (t_phi, z_phi), g2 (S_TSET .. S_TROTL+2)
+template <class V, class G1>
+BMPC_INL void walk_pose_rows(PGP pg, int N, int k, const double* y, const SegCtx& C, V& v, const G1& g1, double t_phi, double z_phi) {
+    static_assert(G1::S0 == S_EE && G1::CNT == 21, "pose row group");
     {
         PGP a = pg + P_ASET + 45 * C.s;
         BMPC_UNROLL
@@ -311,7 +361,7 @@ BMPC_INL void walk_pose_rows(PGP pg, int N, int k, const double* y, const SegCtx
             double a3[3] = {a[rr], a[rr + 15], a[rr + 30]};
             double bb = pg[P_BSET + rr * 4 + C.s];
             if (!(a3[0] == 0 && a3[1] == 0 && a3[2] == 0 && bb > 0))
-                v.template add<3, 1>(S_EE + rr, a3, a3[0] * C.pose[0] + a3[1] * C.pose[1] + a3[2] * C.pose[2] - bb - y[Z_PS]);
+                v.template add<3, 1>(a3, a3[0] * C.pose[0] + a3[1] * C.pose[1] + a3[2] * C.pose[2] - bb - y[Z_PS], g1.t[rr], g1.z[rr]);
         }
     }
     BMPC_UNROLL
@@ -319,10 +369,15 @@ BMPC_INL void walk_pose_rows(PGP pg, int N, int k, const double* y, const SegCtx
         double al[6];
         BMPC_UNROLL
         for (int c = 0; c < 6; c++) al[c] = -C.gs[m][c];
-        v.template add<6, 2>(S_ROTU + m, C.gs[m], C.proj[m] - C.ub[m] - y[Z_RS]);
-        v.template add<6, 2>(S_ROTL + m, al, -(C.proj[m] - C.lb[m] + y[Z_RS]));
+        v.template add<6, 2>(C.gs[m], C.proj[m] - C.ub[m] - y[Z_RS], g1.t[S_ROTU - S_EE + m], g1.z[S_ROTU - S_EE + m]);
+        v.template add<6, 2>(al, -(C.proj[m] - C.lb[m] + y[Z_RS]), g1.t[S_ROTL - S_EE + m], g1.z[S_ROTL - S_EE + m]);
     }
-    v.template add<3, 0>(S_PHI, C.dpp, C.phi - (C.phiend + 0.005));
+    v.template add<3, 0>(C.dpp, C.phi - (C.phiend + 0.005), t_phi, z_phi);
+}
+template <class V, class G2>
+BMPC_INL void walk_pose_rows_term(PGP pg, int N, int k, const double* y, const SegCtx& C, V& v, const G2& g2) {
+    static_assert(G2::S0 == S_TSET && G2::CNT == 21, "terminal pose row group");
+    const bool term = (k == N - 1);
     if (term) {
         PGP a = pg + P_ASET + 45 * C.n;
         BMPC_UNROLL
@@ -340,7 +395,7 @@ BMPC_INL void walk_pose_rows(PGP pg, int N, int k, const double* y, const SegCtx
                     for (int a_ = 0; a_ < 3; a_++) tt += (a1 * C.bp1[a_] + a2 * C.bp2[a_]) * C.Dep[a_][c];
                     a3[c] = tt;
                 }
-                v.template add<3, 3>(S_TSET + rr, a3, a1 * C.tz[0] + a2 * C.tz[1] - bnew - C.sl[5]);
+                v.template add<3, 3>(a3, a1 * C.tz[0] + a2 * C.tz[1] - bnew - C.sl[5], g2.t[rr], g2.z[rr]);
             }
         }
         BMPC_UNROLL
@@ -348,28 +403,32 @@ BMPC_INL void walk_pose_rows(PGP pg, int N, int k, const double* y, const SegCtx
             double al[6];
             BMPC_UNROLL
             for (int c = 0; c < 6; c++) al[c] = -C.gsn[m][c];
-            v.template add<6, 3>(S_TROTU + m, C.gsn[m], C.projn[m] - C.ubn[m] - C.sl[5]);
-            v.template add<6, 3>(S_TROTL + m, al, -(C.projn[m] - C.lbn[m] + C.sl[5]));
+            v.template add<6, 3>(C.gsn[m], C.projn[m] - C.ubn[m] - C.sl[5], g2.t[S_TROTU - S_TSET + m], g2.z[S_TROTU - S_TSET + m]);
+            v.template add<6, 3>(al, -(C.projn[m] - C.lbn[m] + C.sl[5]), g2.t[S_TROTL - S_TSET + m], g2.z[S_TROTL - S_TSET + m]);
         }
     }
 }
 
-// natural-diagonal rows of DG position I (dg_pos order); calls v.diag(s, coef, h) per active row
-template <int I, class V>
-BMPC_INL void walk_diag_pos(GCD lbx, GCD ubx, int N, int k, const double* y, V& v) {
+// natural-diagonal rows of DG position I (dg_pos order); calls v.diag(coef, h, t, z) per active row; row data and box
+// bounds from the preloaded groups rp (slots) and bp (box positions)
+template <int I, class V, class RP, class BP>
+BMPC_INL void walk_diag_pos(const RP& rp, const BP& bp, int k, const double* y, V& v) {
     if constexpr (I < 28) {
         constexpr int blk = I / 7, jj = I % 7;
         constexpr int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + jj;
-        size_t wi = (size_t)blk * 7 * N + (size_t)jj * N + k;
-        double ub = ubx[wi], lb = lbx[wi];
-        if (ub < BIGB) v.diag(2 * I, 1.0, y[pos] - ub);
-        if (lb > -BIGB) v.diag(2 * I + 1, -1.0, lb - y[pos]);
+        static_assert(I >= BP::I0 && I < BP::I0 + BP::CNT && 2 * I >= RP::S0 && 2 * I + 1 < RP::S0 + RP::CNT, "preloaded range");
+        const double ub = bp.ub[I - BP::I0], lb = bp.lb[I - BP::I0];
+        if (ub < BIGB) v.diag(1.0, y[pos] - ub, rp.t[2 * I - RP::S0], rp.z[2 * I - RP::S0]);
+        if (lb > -BIGB) v.diag(-1.0, lb - y[pos], rp.t[2 * I + 1 - RP::S0], rp.z[2 * I + 1 - RP::S0]);
     } else if constexpr (I < 32) {
         constexpr int pos = (I == 28 ? Z_RS : I == 29 ? Z_DRS : I == 30 ? Z_PS : Z_DPS);
-        constexpr int m = (I == 28 ? 0 : I == 29 ? 1 : I == 30 ? 2 : 3);
-        v.diag(S_NONNEG + m, -1.0, -y[pos]);
+        constexpr int s = S_NONNEG + (I == 28 ? 0 : I == 29 ? 1 : I == 30 ? 2 : 3);
+        static_assert(s >= RP::S0 && s < RP::S0 + RP::CNT, "preloaded range");
+        v.diag(-1.0, -y[pos], rp.t[s - RP::S0], rp.z[s - RP::S0]);
     } else if constexpr (I < 38) {
-        if (k == 1) v.diag(S_D1 + (I - 32), -1.0, -y[Z_D + I - 32]);
+        constexpr int s = S_D1 + (I - 32);
+        static_assert(s >= RP::S0 && s < RP::S0 + RP::CNT, "preloaded range");
+        if (k == 1) v.diag(-1.0, -y[Z_D + I - 32], rp.t[s - RP::S0], rp.z[s - RP::S0]);
     }
 }
 
@@ -377,9 +436,9 @@ struct DiagAsm {
     RowAcc* R;
     double D, g0, g1, gz;
     BMPC_INL void begin() { D = 0; g0 = 0; g1 = 0; gz = 0; }
-    BMPC_INL void diag(int s, double coef, double h) {
+    BMPC_INL void diag(double coef, double h, double t, double z) {
         double sg, r0, r1, zz;
-        R->row(s, h, sg, r0, r1, zz);
+        R->row_tz(t, z, h, sg, r0, r1, zz);
         D += sg; g0 += coef * r0; g1 += coef * r1; gz += coef * zz;
     }
 };
@@ -439,8 +498,8 @@ BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][
 }
 // P17 blocks: for position I of the (q, dq, pi) block emit the three slack-column couplings, then
 // D, g0, g1, gz of that position (its diagonal rows are walked here), 7 fields
-template <int I>
-BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, const double* y, const KinT& K,
+template <int I, class RP, class BP>
+BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp, int k, const double* y, const KinT& K,
                            const double Jl[3][7], const double G[6][7], double hdt, RowAcc& R, const PointRes& PA,
                            const PoseAsm& P, const double* bv, Emitter& E) {
     if constexpr (I < 17) {
@@ -466,7 +525,7 @@ BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, c
         DiagAsm dgv;
         dgv.R = &R;
         dgv.begin();
-        walk_diag_pos<DI>(lbx, ubx, A.N, k, y, dgv);
+        if constexpr (DI < 38) walk_diag_pos<DI>(rp, bp, k, y, dgv);
         double D = dgv.D;
         g0 += dgv.g0; g1 += dgv.g1; gz += dgv.gz;
         if constexpr (I < 7) { g0 += PA.gq(0, I); g1 += PA.gq(1, I); gz += PA.gq(2, I); }
@@ -475,7 +534,7 @@ BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, c
             D += w2; g0 += val; gz += val;
         }
         E.put(D); E.put(g0); E.put(g1); E.put(gz);
-        p17_emit_all<I + 1>(A, pg, lbx, ubx, k, y, K, Jl, G, hdt, R, PA, P, bv, E);
+        p17_emit_all<I + 1>(A, pg, rp, bp, k, y, K, Jl, G, hdt, R, PA, P, bv, E);
     }
 }
 
@@ -537,15 +596,15 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
 }
 
 // DG entries: position I of the dg order
-template <int I>
-BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, bool term,
+template <int I, class RP, class BP>
+BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp, int k, bool term,
                           const double* y, RowAcc& R, const PointRes& PA, const PoseAsm& PO, Emitter& E) {
     if constexpr (I < 38) {
         PGP wts = pg + P_W;
         DiagAsm dgv;
         dgv.R = &R;
         dgv.begin();
-        walk_diag_pos<I>(lbx, ubx, A.N, k, y, dgv);
+        walk_diag_pos<I>(rp, bp, k, y, dgv);
         double D = dgv.D, g0 = dgv.g0, g1 = dgv.g1, gz = dgv.gz;
         // slack columns of the pose rows (ps, rs, d5) and of the point rows (d_c)
         if constexpr (I == 30) { D += PO.sS[0]; g0 += PO.bS0[0]; g1 += PO.bS1[0]; gz += PO.bSz[0]; }
@@ -574,7 +633,7 @@ BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, GCD lbx, GCD ubx, int k, bo
             }
         }
         E.put(D); E.put(g0); E.put(g1); E.put(gz);
-        dg_emit_all<I + 1>(A, pg, lbx, ubx, k, term, y, R, PA, PO, E);
+        dg_emit_all<I + 1>(A, pg, rp, bp, k, term, y, R, PA, PO, E);
     }
 }
 
@@ -598,6 +657,10 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     BMPC_SYNC();
     StagePoint S;
     load_zeta(A.zeta, A.NP, m.pi, S.zeta);
+    // row data of the pose rows: in flight while the kinematics are evaluated
+    RowPre<S_EE, 21> rp_pose;
+    rp_pose.load(A, m.pi);
+    const double t_phi = A.t[(size_t)S_PHI * A.NP + m.pi], z_phi = A.z[(size_t)S_PHI * A.NP + m.pi];
     stage_point(A, pg, iw0, k, dc, S);
     double G[6][7];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);
@@ -610,16 +673,27 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     RowAcc R;
     R.init(&A, m.pi, m.valid, ad);
     // ---- collision-point results of k_points: q x d columns first, the rest where it is needed ----
-    PointRes PA{A.part + (size_t)PT_SIDE * A.NP + m.pi, A.NP};
+    PointRes PA;
+    PA.base = A.part + (size_t)PT_SIDE * A.NP + m.pi; PA.NP = A.NP;
     R.cmax = PA.at(SD_KKT); R.csum = PA.at(SD_KKT + 1); R.cmin = PA.at(SD_KKT + 2); R.zsum = PA.at(SD_KKT + 3);
     R.prim = PA.at(SD_KKT + 4); R.nrows = PA.at(SD_KKT + 5);
-    BMPC_UNROLL
-    for (int i = 0; i < 35; i++) E.put(PA.at(SD_CD + i));
+    {
+        double cdv[35];
+        BMPC_UNROLL
+        for (int i = 0; i < 35; i++) cdv[i] = PA.at(SD_CD + i);
+        BMPC_UNROLL
+        for (int i = 0; i < 35; i++) E.put(cdv[i]);
+    }
     // ---- pose rows -> chained (q, dq, pi) block ----
     PoseAsm PO;
     PO.R = &R;
     PO.init(Hp, g12);
-    walk_pose_rows(pg, N, k, S.y, S.C, PO);
+    walk_pose_rows(pg, N, k, S.y, S.C, PO, rp_pose, t_phi, z_phi);
+    {
+        RowPre<S_TSET, 21> rp_term;          // one batch of loads per row group, right before the group is walked
+        rp_term.load(A, m.pi);
+        walk_pose_rows_term(pg, N, k, S.y, S.C, PO, rp_term);
+    }
     const double hdt = 0.5 * dc.dt;
     // generalised forces for the second-order kinematic terms (k_curv)
     if (m.valid && A.o.hess == 2) {
@@ -630,15 +704,26 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         for (int a = 0; a < 6; a++) F[(size_t)(3 + a) * A.NP] = g12[6 + a] + (a >= 3 ? hdt * PO.bpz[a] : 0.0);
     }
     // ---- slack-column couplings + gradients + diagonal rows of the 17 chained positions ----
-    p17_emit_all<0>(A, pg, lbx, ubx, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, g12 + 6, E);
+    {
+        RowPre<0, 28> rp_a;                  // rows + bounds of the q, dq box
+        BndPre<0, 14> bp_a;
+        rp_a.load(A, m.pi); bp_a.load(lbx, ubx, N, k);
+        PA.load_p17();
+        p17_emit_all<0>(A, pg, rp_a, bp_a, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, g12 + 6, E);
+    }
     // ---- chained (q, dq, pi) block ----
     {
         double HpX[21], Hv[21];
         cost_hess(pg, S.C, term, HpX, Hv);
+        PA.load_hqq();
         chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA, E);
     }
     // ---- remaining diagonal rows + gradients: ddq, u, rs, drs, ps, dps, d ----
-    dg_emit_all<14>(A, pg, lbx, ubx, k, term, S.y, R, PA, PO, E);
+    RowPre<28, 40> rp_b;                     // rows + bounds of the ddq, u box, the slack rows, the zeta-diagonal rows
+    BndPre<14, 14> bp_b;
+    rp_b.load(A, m.pi); bp_b.load(lbx, ubx, N, k);
+    PA.load_dg();
+    dg_emit_all<14>(A, pg, rp_b, bp_b, k, term, S.y, R, PA, PO, E);
     // ---- zeta-diagonal rows (k == 1) ----
     {
         double sg2[2] = {0, 0}, r2[3][2] = {{0, 0}, {0, 0}, {0, 0}};
@@ -646,7 +731,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             BMPC_UNROLL
             for (int i = 0; i < 2; i++) {
                 double sg, r0, r1, zz;
-                R.row(S_RS1 + i, -S.zeta[i ? Z_PS : Z_RS], sg, r0, r1, zz);
+                R.row_tz(rp_b.t[S_RS1 - 28 + i], rp_b.z[S_RS1 - 28 + i], -S.zeta[i ? Z_PS : Z_RS], sg, r0, r1, zz);
                 sg2[i] = sg; r2[0][i] = r0; r2[1][i] = r1; r2[2][i] = zz;
             }
         }
@@ -1160,7 +1245,7 @@ BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[8], N = A.N;          // the done list: instances that finished since the last retirement
     if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.done, count, wave, lane);
-    PGP pg = stage_params(A, A.L.done, count, wave, lane, m, lds_par);
+    PGP pg = stage_params<false>(A, A.L.done, count, wave, lane, m, lds_par);
     if (!m.valid) return;
     const int k = m.k, n_w = 44 * N + 6;
     const size_t b = (size_t)A.src[m.b];            // output row of the instance
@@ -1314,7 +1399,7 @@ BMPC_DEV void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
         if (!m.valid) { e = wave * ipw; kk = 0; li = 0; }
         m.b = e; m.k = kk + 1; m.li = li; m.pi = pair_of(A, m.b, m.k);
     }
-    PGP pg = stage_params(A, (GCI)nullptr, count, wave, lane, m, lds_par);
+    PGP pg = stage_params<false>(A, (GCI)nullptr, count, wave, lane, m, lds_par);
     if (!m.valid) return;
     const int k = m.k, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
     const size_t b = (size_t)A.src[m.b];

@@ -185,13 +185,41 @@ BMPC_HD int waves_for(int N, int count) { int ipw = ipw_of(N); return (count + i
 
 // stage the parameter vectors of this wavefront's instances: lds_par[li][NPAR]; returns the calling
 // lane's copy.  All 64 lanes must call it (contains a barrier).
+// BATCHED (the kernels of the super-step): three instances at a time, all loads issued before the first LDS store.  The
+// retirement / admission kernels (k_init, k_out, k_mult) keep the plain loop: k_init compiled with the batched form does
+// not terminate on gfx950 (ROCm 7.2; the CPU emulation of the same source does) -- not root-caused, see DESIGN.md section 7
+template <bool BATCHED = true>
 BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int lane, const PairMap& m, LDSD* lds_par) {
     const int ipw = ipw_of(A.N);
-    for (int li = 0; li < ipw; li++) {
-        const int e = wave * ipw + li;
-        if (e < count) {
-            GCD src = A.p + (size_t)A.src[list ? list[e] : e] * NPAR;
-            for (int i = lane; i < NPAR; i += 64) lds_par[li * NPAR + i] = src[i];
+    if constexpr (!BATCHED) {
+        for (int li = 0; li < ipw; li++) {
+            const int e = wave * ipw + li;
+            if (e < count) {
+                GCD src = A.p + (size_t)A.src[list ? list[e] : e] * NPAR;
+                for (int i = lane; i < NPAR; i += 64) lds_par[li * NPAR + i] = src[i];
+            }
+        }
+        BMPC_SYNC();
+        return lds_par + m.li * NPAR;
+    }
+    // three instances at a time: all their loads are issued before the first LDS store (one memory round trip per chunk)
+    constexpr int NJ = (NPAR + 63) / 64;
+    for (int l0 = 0; l0 < ipw; l0 += 3) {
+        double v[3][NJ];
+        BMPC_UNROLL
+        for (int c = 0; c < 3; c++) {
+            const int li = l0 + c, e = wave * ipw + li;
+            const bool on = li < ipw && e < count;
+            GCD src = A.p + (size_t)A.src[on ? (list ? list[e] : e) : (list ? list[wave * ipw] : wave * ipw)] * NPAR;
+            BMPC_UNROLL
+            for (int j = 0; j < NJ; j++) { const int i = lane + 64 * j; v[c][j] = (i < NPAR) ? src[i] : 0.0; }
+        }
+        BMPC_UNROLL
+        for (int c = 0; c < 3; c++) {
+            const int li = l0 + c, e = wave * ipw + li;
+            if (li < ipw && e < count)
+                BMPC_UNROLL
+                for (int j = 0; j < NJ; j++) { const int i = lane + 64 * j; if (i < NPAR) lds_par[li * NPAR + i] = v[c][j]; }
         }
     }
     BMPC_SYNC();

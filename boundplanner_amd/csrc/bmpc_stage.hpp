@@ -390,17 +390,27 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
                         const double* zeta, const KinT& K, const SegCtx& C, V& v) {
     const bool term = (k == N - 1);
     // box bounds on q, dq, ddq, u (BoundMPC.py:171-186, 544-589)
+    // the bounds of 14 positions are loaded in one batch: the walk is conditional, so loads issued where they are used
+    // cost one memory round trip each (the thread-per-pair kernels run one wavefront per SIMD: nothing hides it)
     BMPC_UNROLL
-    for (int blk = 0; blk < 4; blk++)
+    for (int half = 0; half < 2; half++) {
+        double ubv[14], lbv[14];
         BMPC_UNROLL
-        for (int jj = 0; jj < 7; jj++) {
+        for (int i = 0; i < 14; i++) {
+            const int blk = 2 * half + i / 7, jj = i % 7;
+            size_t wi = (size_t)blk * 7 * N + (size_t)jj * N + k;
+            ubv[i] = ubx[wi]; lbv[i] = lbx[wi];
+        }
+        BMPC_UNROLL
+        for (int i = 0; i < 14; i++) {
+            const int blk = 2 * half + i / 7, jj = i % 7;
             const int pos = (blk == 0 ? Z_Q : blk == 1 ? Z_DQ : blk == 2 ? Z_DDQ : Z_U) + jj;
             const int s = 2 * (blk * 7 + jj);
-            size_t wi = (size_t)blk * 7 * N + (size_t)jj * N + k;
-            double ub = ubx[wi], lb = lbx[wi];
+            const double ub = ubv[i], lb = lbv[i];
             if (ub < BIGB) v.diag(s, pos, 1.0, y[pos] - ub); else v.skip(s);
             if (lb > -BIGB) v.diag(s + 1, pos, -1.0, lb - y[pos]); else v.skip(s + 1);
         }
+    }
     // rs, drs, ps, dps >= 0 (Q6)
     v.diag(S_NONNEG + 0, Z_RS, -1.0, -y[Z_RS]);
     v.diag(S_NONNEG + 1, Z_DRS, -1.0, -y[Z_DRS]);
