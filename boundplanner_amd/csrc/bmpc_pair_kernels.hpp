@@ -718,12 +718,19 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         PA.load_hqq();
         chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA, E);
     }
+    // The iterate is read again (and its natural form recomputed) for the rest of the kernel instead of being carried
+    // through the chained block: there the register file is needed for the kinematic columns (K, Jl, G), which the register
+    // allocator otherwise parks in scratch memory and reloads for every entry of the block
+    const double vang[3] = {S.C.v[3], S.C.v[4], S.C.v[5]};
+    double zeta2[NZ], y2[NZ];
+    load_zeta(A.zeta, A.NP, m.pi, zeta2);
+    nat_all(zeta2, dc, y2);
     // ---- remaining diagonal rows + gradients: ddq, u, rs, drs, ps, dps, d ----
     RowPre<28, 40> rp_b;                     // rows + bounds of the ddq, u box, the slack rows, the zeta-diagonal rows
     BndPre<14, 14> bp_b;
     rp_b.load(A, m.pi); bp_b.load(lbx, ubx, N, k);
     PA.load_dg();
-    dg_emit_all<14>(A, pg, rp_b, bp_b, k, term, S.y, R, PA, PO, E);
+    dg_emit_all<14>(A, pg, rp_b, bp_b, k, term, y2, R, PA, PO, E);
     // ---- zeta-diagonal rows (k == 1) ----
     {
         double sg2[2] = {0, 0}, r2[3][2] = {{0, 0}, {0, 0}, {0, 0}};
@@ -731,7 +738,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             BMPC_UNROLL
             for (int i = 0; i < 2; i++) {
                 double sg, r0, r1, zz;
-                R.row_tz(rp_b.t[S_RS1 - 28 + i], rp_b.z[S_RS1 - 28 + i], -S.zeta[i ? Z_PS : Z_RS], sg, r0, r1, zz);
+                R.row_tz(rp_b.t[S_RS1 - 28 + i], rp_b.z[S_RS1 - 28 + i], -zeta2[i ? Z_PS : Z_RS], sg, r0, r1, zz);
                 sg2[i] = sg; r2[0][i] = r0; r2[1][i] = r1; r2[2][i] = zz;
             }
         }
@@ -753,7 +760,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         BMPC_UNROLL
         for (int j = 6; j >= 0; j--)
             BMPC_UNROLL
-            for (int a = 0; a < 3; a++) { sz[a] += S.K.zx[j][a] * S.y[Z_DQ + j]; sufz[j][a] = sz[a]; }
+            for (int a = 0; a < 3; a++) { sz[a] += S.K.zx[j][a] * y2[Z_DQ + j]; sufz[j][a] = sz[a]; }
         // sufz[m] for m = 1..7 (sufz[7] = 0)
         BMPC_UNROLL
         for (int mm = 1; mm < 8; mm++)
@@ -767,7 +774,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             double zn[NX];
             BMPC_UNROLL
             for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1];
-            defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+            defect_all(zeta2, zn, vang, dc, rdef);
             BMPC_UNROLL
             for (int i = 0; i < NX; i++) prim = fmax(prim, fabs(rdef[i]));
         } else {
@@ -782,7 +789,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         double x1fix[24];
         x1fix_eval(lbx, N, dc.dt, x1fix);
         BMPC_UNROLL
-        for (int i = 0; i < 24; i++) prim = fmax(prim, fabs(x1fix[i] - S.zeta[i]));
+        for (int i = 0; i < 24; i++) prim = fmax(prim, fabs(x1fix[i] - zeta2[i]));
     }
     if (m.valid) {
         GD P = A.part + m.pi;
