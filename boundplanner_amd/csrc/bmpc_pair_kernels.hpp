@@ -543,10 +543,13 @@ BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp
 BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double* dq, const double* Fp, const double* Fv,
                              const double Fc[6][3], Emitter& E) {
     const int njc[6] = {2, 3, 4, 5, 6, 4};
+    // q x q block: third derivatives of the kinematics contracted with forces and dq -- symmetric in (a, bq), so the upper
+    // triangle is computed and both halves are emitted from it
+    double tri[28];
     BMPC_UNROLL
     for (int a = 0; a < 7; a++)
         BMPC_UNROLL
-        for (int bq = 0; bq < 7; bq++) {
+        for (int bq = a; bq < 7; bq++) {
             const int m = a < bq ? a : bq, M = a < bq ? bq : a;
             double cM[3] = {Jl[0][M], Jl[1][M], Jl[2][M]}, zc[3];
             cross3r(K.zx[m], cM, zc);
@@ -580,8 +583,12 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
                 }
                 acc += dq[j] * (lin + ang);
             }
-            E.put(acc);
+            tri[sym7(a, bq)] = acc;
         }
+    BMPC_UNROLL
+    for (int a = 0; a < 7; a++)
+        BMPC_UNROLL
+        for (int bq = 0; bq < 7; bq++) E.put(tri[sym7(a, bq)]);
     BMPC_UNROLL
     for (int i = 0; i < 7; i++)
         BMPC_UNROLL

@@ -553,8 +553,9 @@ static void assemble_stage(prob_t* pb, int k, double mu) {
             const double* dqv = y + Y_DQ;
             double cc[7][3];
             for (int j = 0; j < 7; j++) for (int a = 0; a < 3; a++) cc[j][a] = s->J[a][j];
+            /* symmetric in (a, b) (third derivatives of the kinematics): upper triangle, mirrored */
             for (int a = 0; a < 7; a++)
-                for (int b = 0; b < 7; b++) {
+                for (int b = a; b < 7; b++) {
                     double acc = 0;
                     for (int j = 0; j < 7; j++) {
                         if (dqv[j] == 0.0) continue;
@@ -576,6 +577,7 @@ static void assemble_stage(prob_t* pb, int k, double mu) {
                         acc += dqv[j] * (lin + ang);
                     }
                     Hy[(Y_Q + a) * NZ + Y_Q + b] += acc;
+                    if (b != a) Hy[(Y_Q + b) * NZ + Y_Q + a] += acc;
                 }
         }
         for (int c = 0; c < 6; c++) {
