@@ -74,13 +74,14 @@ struct InitVisitor {
     BMPC_INL void diag(int s, int, double, double h) { set(s, h); }
     BMPC_INL void zdiag(int s, int, double, double h) { set(s, h); }
     BMPC_INL void pose(int s, const double*, int, double h) { set(s, h); }
+    template <int S0, int CNT> BMPC_INL void group() {}
     template <int C> BMPC_INL void point_begin() {}
     template <int C> BMPC_INL void point(int s, const double*, double h) { set(s, h); }
     template <int C> BMPC_INL void point_end() {}
 };
 
 // over the admit list: slots that just received an instance
-BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
+BMPC_KBODY void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[9], N = A.N;
     if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.admit, count, wave, lane);
@@ -90,7 +91,7 @@ BMPC_DEV void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
     GCD x0 = A.x0 + row * n_w;
     GCD lbx = A.lbx + row * n_w;
     GCD ubx = A.ubx + row * n_w;
-    PGP pg = stage_params<false>(A, A.L.admit, count, wave, lane, m, lds_par);
+    PGP pg = stage_params(A, A.L.admit, count, wave, lane, m, lds_par);
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
@@ -811,7 +812,7 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
 // A kernel of its own because together with the pose / chain work of k_eval it does not fit the
 // register file (the spills were what bound k_eval).
 // ------------------------------------------------------------------------------------------
-BMPC_DEV void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
+BMPC_KBODY void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[0], N = A.N;
     if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
@@ -869,7 +870,7 @@ BMPC_DEV void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 // k_curv: second-order kinematic terms of the Lagrangian Hessian (record fields F_CQQ, F_CQD) for the
 // instances in hess_mode (the list k_points built: wavefronts made of such instances only); forces from k_eval.
 // ------------------------------------------------------------------------------------------
-BMPC_DEV void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
+BMPC_KBODY void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const int count = A.L.cnt[10], N = A.N;
     if (A.o.hess != 2 || wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.curv, count, wave, lane);
@@ -898,195 +899,8 @@ BMPC_DEV void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     E.pad_to(HREC);
 }
 
-// ------------------------------------------------------------------------------------------
-// k_step: row steps for the Newton direction dz (forward_sweep of bmpc_solver.hpp, row part)
-// ------------------------------------------------------------------------------------------
-struct StepVisitor {
-    const PipeArgs* A; size_t pi; bool valid;
-    double mu, tau;
-    const double* dy;     // natural step
-    const double* dzt;    // zeta step
-    double dloc[6], dpt[6][3];
-    BMPC_INL void fin(int s, double h, double adot) {
-        // dt = -(h + t) - a.d = c - t: the part that needs no row data, finished by k_rowstep
-        if (valid) A->dt[(size_t)s * A->NP + pi] = -h - adot;
-    }
-    BMPC_INL void skip(int) {}
-    BMPC_INL void diag(int s, int pos, double coef, double h) { fin(s, h, coef * dy[pos]); }
-    BMPC_INL void zdiag(int s, int pos, double coef, double h) { fin(s, h, coef * dzt[pos]); }
-    BMPC_INL void pose(int s, const double* a, int sel, double h) {
-        double adot = 0;
-        BMPC_UNROLL
-        for (int c = 0; c < 6; c++) adot += a[c] * dloc[c];
-        if (sel == 1) adot -= dy[Z_PS];
-        else if (sel == 2) adot -= dy[Z_RS];
-        else if (sel == 3) adot -= dy[Z_D + 5];
-        fin(s, h, adot);
-    }
-    template <int C> BMPC_INL void point_begin() {}
-    template <int C> BMPC_INL void point(int s, const double* a, double h) {
-        fin(s, h, a[0] * dpt[C][0] + a[1] * dpt[C][1] + a[2] * dpt[C][2] - dy[Z_D + C]);
-    }
-    template <int C> BMPC_INL void point_end() {}
-};
-
-template <int C>
-BMPC_INL void point_dirs(const KinT& K, const double* dyq, double dpt[6][3]) {
-    if constexpr (C < 6) {
-        constexpr int nj = PointNJ<C>::value;
-        const double* pc = kin_point<C>(K);
-        double s[3] = {0, 0, 0};
-        BMPC_UNROLL
-        for (int i = 0; i < nj; i++) {
-            double r[3] = {pc[0] - K.o[i][0], pc[1] - K.o[i][1], pc[2] - K.o[i][2]}, c[3];
-            cross3r(K.zx[i], r, c);
-            s[0] += c[0] * dyq[i]; s[1] += c[1] * dyq[i]; s[2] += c[2] * dyq[i];
-        }
-        dpt[C][0] = s[0]; dpt[C][1] = s[1]; dpt[C][2] = s[2];
-        point_dirs<C + 1>(K, dyq, dpt);
-    }
-}
-
-BMPC_DEV void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
-    const int count = A.L.cnt[1], N = A.N;
-    if (wave * ipw_of(N) >= count) return;
-    PairMap m = pair_map(A, A.L.step, count, wave, lane);
-    const int k = m.k, n_w = 44 * N + 6;
-    const bool term = (k == N - 1);
-    const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
-    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
-    PGP pg = stage_params(A, A.L.step, count, wave, lane, m, lds_par);
-    PGP wts = pg + P_W;
-    const double mu = A.st[m.b].mu;
-    double iw0[3];
-    BMPC_UNROLL
-    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
-    StagePoint S;
-    load_zeta(A.zeta, A.NP, m.pi, S.zeta);
-    stage_point(A, pg, iw0, k, dc, S);
-    double G[6][7], g12[12];
-    kin_G(S.K, S.Jl, S.y + Z_DQ, G);
-    cost_grad12(pg, S.C, term, g12);
-    double dzt[NZ], dy[NZ];
-    load_zeta(A.dz, A.NP, m.pi, dzt);
-    nat_all(dzt, dc, dy);
-    StepVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu);
-    V.dy = dy; V.dzt = dzt;
-    double dv[6];
-    BMPC_UNROLL
-    for (int a = 0; a < 6; a++) {
-        double s = 0;
-        BMPC_UNROLL
-        for (int j = 0; j < 7; j++) s += G[a][j] * dy[Z_Q + j] + (a < 3 ? S.Jl[a][j] : S.K.zx[j][a - 3]) * dy[Z_DQ + j];
-        dv[a] = s;
-    }
-    BMPC_UNROLL
-    for (int a = 0; a < 3; a++) {
-        double s = 0;
-        BMPC_UNROLL
-        for (int j = 0; j < 7; j++) s += S.Jl[a][j] * dy[Z_Q + j];
-        V.dloc[a] = s;
-        V.dloc[3 + a] = dy[Z_PI + a] + 0.5 * dc.dt * dv[3 + a];
-    }
-    point_dirs<0>(S.K, dy + Z_Q, V.dpt);
-    // directional derivative of f
-    double dphi_f = 0;
-    BMPC_UNROLL
-    for (int a = 0; a < 6; a++) dphi_f += g12[a] * V.dloc[a] + g12[6 + a] * dv[a];
-    BMPC_UNROLL
-    for (int j = 2; j <= 4; j++) dphi_f += 2 * wts[6] * S.y[Z_DQ + j] * dy[Z_DQ + j];
-    BMPC_UNROLL
-    for (int j = 0; j < 7; j++) dphi_f += 2 * wts[7] * S.y[Z_U + j] * dy[Z_U + j];
-    dphi_f += 2 * wts[9] * S.y[Z_RS] * dy[Z_RS] + 2 * wts[10] * S.y[Z_DRS] * dy[Z_DRS] +
-              2 * wts[9] * S.y[Z_PS] * dy[Z_PS] + 2 * wts[10] * S.y[Z_DPS] * dy[Z_DPS];
-    if (term)
-        BMPC_UNROLL
-        for (int i = 0; i < 6; i++) {
-            double gg = 2 * wts[10] * S.y[Z_D + i] + (i != 4 ? 2 * wts[8] * (pg[P_SLACKS0 + i] + S.y[Z_D + i]) : 0.0);
-            dphi_f += gg * dy[Z_D + i];
-        }
-    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
-    if (m.valid) {
-        GD P = A.part + m.pi;
-        P[PT_DPHIF * A.NP] = dphi_f;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_trial: zeta + alpha dz, t + alpha dt -> f, theta, sum log t
-// ------------------------------------------------------------------------------------------
-struct TrialVisitor {
-    const PipeArgs* A; size_t pi; bool valid;
-    BMPC_INL void fin(int s, double h) {
-        if (valid) A->t_t[(size_t)s * A->NP + pi] = h;     // finished in place by k_rowtrial: t + alpha dt
-    }
-    BMPC_INL void skip(int) {}
-    BMPC_INL void diag(int s, int, double, double h) { fin(s, h); }
-    BMPC_INL void zdiag(int s, int, double, double h) { fin(s, h); }
-    BMPC_INL void pose(int s, const double*, int, double h) { fin(s, h); }
-    template <int C> BMPC_INL void point_begin() {}
-    template <int C> BMPC_INL void point(int s, const double*, double h) { fin(s, h); }
-    template <int C> BMPC_INL void point_end() {}
-};
-
-BMPC_DEV void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
-    const int count = A.L.cnt[2], N = A.N;
-    if (wave * ipw_of(N) >= count) return;
-    PairMap m = pair_map(A, A.L.trial, count, wave, lane);
-    const int k = m.k, n_w = 44 * N + 6;
-    const bool term = (k == N - 1);
-    const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
-    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
-    PGP pg = stage_params(A, A.L.trial, count, wave, lane, m, lds_par);
-    const double alpha = A.st[m.b].alpha;
-    double iw0[3];
-    BMPC_UNROLL
-    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
-    StagePoint S;
-    BMPC_UNROLL
-    for (int i = 0; i < NZ; i++) S.zeta[i] = A.zeta[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
-    if (m.valid)
-        BMPC_UNROLL
-        for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
-    stage_point(A, pg, iw0, k, dc, S);
-    TrialVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid;
-    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
-    double th = 0;     // dynamics / initial-state part of theta; the row part is added by k_rowtrial
-    if (!term) {
-        double zn[NX], rdef[NX];
-        BMPC_UNROLL
-        for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
-        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
-        BMPC_UNROLL
-        for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
-    }
-    if (k == 1) {
-        double x1fix[24];
-        x1fix_eval(lbx, N, dc.dt, x1fix);
-        BMPC_UNROLL
-        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
-    }
-    if (m.valid) {
-        GD P = A.part + m.pi;
-        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// streaming row kernels: 256 threads = 64 pairs x 4 slot groups; a thread walks slots g, g+4, ...
-// These carry every load-modify-store on the row arrays (t, z, dt, dz_row): little register state, so
-// they run at full occupancy and hide the HBM latency that a thread-per-pair kernel cannot.
-// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 3 * 256 doubles.
-// They also run the per-instance line-search logic: the pairs of an instance are lanes of one workgroup.
-// ------------------------------------------------------------------------------------------
-constexpr int ROW_GROUPS = 4;
-
 // line-search start of one instance (fraction-to-boundary step lengths, merit derivative) from the per-pair partials of
-// k_step / k_rowstep, summed in pair order (fixed order -> reproducible)
+// k_step, summed in pair order (fixed order -> reproducible)
 BMPC_INL void ls0_instance(const PipeArgs& A, int b) {
     const int N = A.N;
     GST st = A.st + b;
@@ -1149,39 +963,210 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
     return false;
 }
 
-// k_rowstep: dt = c - t (c from k_step, left in A.dt), dz_row = (mu - t z - z dt) / t, fraction-to-boundary step lengths and the
-// barrier part of the merit derivative, reduced over the pair in slot-group order; then, the pairs of an instance
-// being lanes of this workgroup, the line-search start of every instance in it (what a kernel of its own did before)
-BMPC_DEV void k_rowstep_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
+// ------------------------------------------------------------------------------------------
+// k_step: row steps for the Newton direction dz (forward_sweep of bmpc_solver.hpp, row part)
+// ------------------------------------------------------------------------------------------
+struct StepVisitor {
+    const PipeArgs* A; size_t pi; bool valid;
+    double mu, tau;
+    const double* dy;     // natural step
+    const double* dzt;    // zeta step
+    double dloc[6], dpt[6][3];
+    double gt[ROW_GROUP_MAX], gz[ROW_GROUP_MAX];     // slack t and multiplier z of the current row group, loaded in one batch
+    double rp, rd, dbar;                              // max(-dt/t), max(-dz/z), -mu sum dt/t over the rows of this pair
+    template <int S0, int CNT> BMPC_INL void group() {
+        static_assert(CNT <= ROW_GROUP_MAX, "row group size");
+        BMPC_UNROLL
+        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = A->t[o]; gz[i] = A->z[o]; }
+    }
+    BMPC_INL void fin(int s, double h, double adot) {
+        // row step: t + dt = c = -h - a.d (stored in A.dt: k_trial and the accept pass subtract t again),
+        // dz_row = (mu - t z - z dt) / t, fraction-to-boundary ratios, barrier part of the merit derivative
+        const double c = -h - adot, t = gt[s - row_group_base(s)], z = gz[s - row_group_base(s)];
+        const double rt = 1.0 / t, dti = c - t, dzi = (mu - t * z - z * dti) * rt;
+        if (valid) { size_t o = (size_t)s * A->NP + pi; A->dt[o] = c; A->dzr[o] = dzi; }
+        rp = fmax(rp, -dti * rt); rd = fmax(rd, -dzi / z);
+        dbar -= mu * dti * rt;
+    }
+    BMPC_INL void skip(int) {}
+    BMPC_INL void diag(int s, int pos, double coef, double h) { fin(s, h, coef * dy[pos]); }
+    BMPC_INL void zdiag(int s, int pos, double coef, double h) { fin(s, h, coef * dzt[pos]); }
+    BMPC_INL void pose(int s, const double* a, int sel, double h) {
+        double adot = 0;
+        BMPC_UNROLL
+        for (int c = 0; c < 6; c++) adot += a[c] * dloc[c];
+        if (sel == 1) adot -= dy[Z_PS];
+        else if (sel == 2) adot -= dy[Z_RS];
+        else if (sel == 3) adot -= dy[Z_D + 5];
+        fin(s, h, adot);
+    }
+    template <int C> BMPC_INL void point_begin() { group<S_COL + 15 * C, 15>(); }
+    template <int C> BMPC_INL void point(int s, const double* a, double h) {
+        fin(s, h, a[0] * dpt[C][0] + a[1] * dpt[C][1] + a[2] * dpt[C][2] - dy[Z_D + C]);
+    }
+    template <int C> BMPC_INL void point_end() {}
+};
+
+template <int C>
+BMPC_INL void point_dirs(const KinT& K, const double* dyq, double dpt[6][3]) {
+    if constexpr (C < 6) {
+        constexpr int nj = PointNJ<C>::value;
+        const double* pc = kin_point<C>(K);
+        double s[3] = {0, 0, 0};
+        BMPC_UNROLL
+        for (int i = 0; i < nj; i++) {
+            double r[3] = {pc[0] - K.o[i][0], pc[1] - K.o[i][1], pc[2] - K.o[i][2]}, c[3];
+            cross3r(K.zx[i], r, c);
+            s[0] += c[0] * dyq[i]; s[1] += c[1] * dyq[i]; s[2] += c[2] * dyq[i];
+        }
+        dpt[C][0] = s[0]; dpt[C][1] = s[1]; dpt[C][2] = s[2];
+        point_dirs<C + 1>(K, dyq, dpt);
+    }
+}
+
+BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[1], N = A.N;
     if (wave * ipw_of(N) >= count) return;
-    const int lane = tid & 63, g = tid >> 6;
     PairMap m = pair_map(A, A.L.step, count, wave, lane);
-    const double mu = A.st[m.b].mu, tau = fmax(0.99, 1.0 - mu);
-    double rp = 0.0, rd = 0.0, dbar = 0.0;       // max(-dt/t), max(-dz/z), -mu sum dt/t
-    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
-        size_t o = (size_t)s * A.NP + m.pi;
-        double z = A.z[o];
-        if (z > 0.0) {
-            double t = A.t[o], rt = 1.0 / t;
-            double dti = A.dt[o] - t;
-            double dzi = (mu - t * z - z * dti) * rt;
-            if (m.valid) A.dzr[o] = dzi;      // dt stays in k_step's form (c = t + dt): k_rowtrial subtracts t again
-            rp = fmax(rp, -dti * rt); rd = fmax(rd, -dzi / z);
-            dbar -= mu * dti * rt;
+    const int k = m.k, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
+    const DynC dc = make_dync(A.o.dt);
+    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
+    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
+    PGP pg = stage_params(A, A.L.step, count, wave, lane, m, lds_par);
+    PGP wts = pg + P_W;
+    const double mu = A.st[m.b].mu;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    StagePoint S;
+    load_zeta(A.zeta, A.NP, m.pi, S.zeta);
+    stage_point(A, pg, iw0, k, dc, S);
+    double G[6][7], g12[12];
+    kin_G(S.K, S.Jl, S.y + Z_DQ, G);
+    cost_grad12(pg, S.C, term, g12);
+    double dzt[NZ], dy[NZ];
+    load_zeta(A.dz, A.NP, m.pi, dzt);
+    nat_all(dzt, dc, dy);
+    StepVisitor V;
+    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu);
+    V.dy = dy; V.dzt = dzt; V.rp = 0.0; V.rd = 0.0; V.dbar = 0.0;
+    double dv[6];
+    BMPC_UNROLL
+    for (int a = 0; a < 6; a++) {
+        double s = 0;
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) s += G[a][j] * dy[Z_Q + j] + (a < 3 ? S.Jl[a][j] : S.K.zx[j][a - 3]) * dy[Z_DQ + j];
+        dv[a] = s;
+    }
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) {
+        double s = 0;
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) s += S.Jl[a][j] * dy[Z_Q + j];
+        V.dloc[a] = s;
+        V.dloc[3 + a] = dy[Z_PI + a] + 0.5 * dc.dt * dv[3 + a];
+    }
+    point_dirs<0>(S.K, dy + Z_Q, V.dpt);
+    // directional derivative of f
+    double dphi_f = 0;
+    BMPC_UNROLL
+    for (int a = 0; a < 6; a++) dphi_f += g12[a] * V.dloc[a] + g12[6 + a] * dv[a];
+    BMPC_UNROLL
+    for (int j = 2; j <= 4; j++) dphi_f += 2 * wts[6] * S.y[Z_DQ + j] * dy[Z_DQ + j];
+    BMPC_UNROLL
+    for (int j = 0; j < 7; j++) dphi_f += 2 * wts[7] * S.y[Z_U + j] * dy[Z_U + j];
+    dphi_f += 2 * wts[9] * S.y[Z_RS] * dy[Z_RS] + 2 * wts[10] * S.y[Z_DRS] * dy[Z_DRS] +
+              2 * wts[9] * S.y[Z_PS] * dy[Z_PS] + 2 * wts[10] * S.y[Z_DPS] * dy[Z_DPS];
+    if (term)
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) {
+            double gg = 2 * wts[10] * S.y[Z_D + i] + (i != 4 ? 2 * wts[8] * (pg[P_SLACKS0 + i] + S.y[Z_D + i]) : 0.0);
+            dphi_f += gg * dy[Z_D + i];
         }
-    }
-    lds[tid] = rp; lds[256 + tid] = rd; lds[512 + tid] = dbar;
-    BMPC_SYNC();
-    if (g == 0 && m.valid) {
-        double db = 0.0;
-        for (int q = 0; q < ROW_GROUPS; q++) { rp = fmax(rp, lds[64 * q + lane]); rd = fmax(rd, lds[256 + 64 * q + lane]); db += lds[512 + 64 * q + lane]; }
+    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    if (m.valid) {
         GD P = A.part + m.pi;
-        P[PT_AP * A.NP] = (rp > 0) ? tau / rp : 1.0; P[PT_AD * A.NP] = (rd > 0) ? tau / rd : 1.0; P[PT_DBAR * A.NP] = db;
+        P[PT_DPHIF * A.NP] = dphi_f;
+        P[PT_AP * A.NP] = (V.rp > 0) ? V.tau / V.rp : 1.0; P[PT_AD * A.NP] = (V.rd > 0) ? V.tau / V.rd : 1.0; P[PT_DBAR * A.NP] = V.dbar;
     }
-    BMPC_FENCE_SYNC();                              // the partials of every pair of the instance are visible
-    if (g == 0 && m.valid && m.k == 1) ls0_instance(A, m.b);
+    // the pairs of an instance are lanes of this wavefront: line-search start per instance (a kernel of its own, then part
+    // of the streaming row kernel k_rowstep, before the row steps moved in here)
+    BMPC_FENCE_SYNC();
+    if (m.valid && m.k == 1) ls0_instance(A, m.b);
 }
+
+// ------------------------------------------------------------------------------------------
+// k_trial: zeta + alpha dz, t + alpha dt -> f, theta, sum log t
+// ------------------------------------------------------------------------------------------
+struct TrialVisitor {
+    const PipeArgs* A; size_t pi; bool valid;
+    BMPC_INL void fin(int s, double h) {
+        if (valid) A->t_t[(size_t)s * A->NP + pi] = h;     // finished in place by k_rowtrial: t + alpha dt
+    }
+    BMPC_INL void skip(int) {}
+    BMPC_INL void diag(int s, int, double, double h) { fin(s, h); }
+    BMPC_INL void zdiag(int s, int, double, double h) { fin(s, h); }
+    BMPC_INL void pose(int s, const double*, int, double h) { fin(s, h); }
+    template <int S0, int CNT> BMPC_INL void group() {}
+    template <int C> BMPC_INL void point_begin() {}
+    template <int C> BMPC_INL void point(int s, const double*, double h) { fin(s, h); }
+    template <int C> BMPC_INL void point_end() {}
+};
+
+BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
+    const int count = A.L.cnt[2], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    PairMap m = pair_map(A, A.L.trial, count, wave, lane);
+    const int k = m.k, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
+    const DynC dc = make_dync(A.o.dt);
+    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
+    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
+    PGP pg = stage_params(A, A.L.trial, count, wave, lane, m, lds_par);
+    const double alpha = A.st[m.b].alpha;
+    double iw0[3];
+    BMPC_UNROLL
+    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+    StagePoint S;
+    BMPC_UNROLL
+    for (int i = 0; i < NZ; i++) S.zeta[i] = A.zeta[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
+    if (m.valid)
+        BMPC_UNROLL
+        for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
+    stage_point(A, pg, iw0, k, dc, S);
+    TrialVisitor V;
+    V.A = &A; V.pi = m.pi; V.valid = m.valid;
+    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    double th = 0;     // dynamics / initial-state part of theta; the row part is added by k_rowtrial
+    if (!term) {
+        double zn[NX], rdef[NX];
+        BMPC_UNROLL
+        for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
+        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+        BMPC_UNROLL
+        for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
+    }
+    if (k == 1) {
+        double x1fix[24];
+        x1fix_eval(lbx, N, dc.dt, x1fix);
+        BMPC_UNROLL
+        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
+    }
+    if (m.valid) {
+        GD P = A.part + m.pi;
+        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming row kernels: 256 threads = 64 pairs x 4 slot groups; a thread walks slots g, g+4, ...
+// These carry every load-modify-store on the row arrays (t, z, dt, dz_row): little register state, so
+// they run at full occupancy and hide the HBM latency that a thread-per-pair kernel cannot.
+// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 3 * 256 doubles.
+// They also run the per-instance line-search logic: the pairs of an instance are lanes of one workgroup.
+// ------------------------------------------------------------------------------------------
+constexpr int ROW_GROUPS = 4;
 
 // k_rowtrial: t_t = t + alpha dt (in place over the h values k_trial left there), theta += |h + t_t|, sum log t_t,
 // reduced over the pair in slot-group order and added to k_trial's partials; then, per instance of this workgroup, the
@@ -1250,16 +1235,17 @@ struct OutVisitor {
     BMPC_INL void diag(int, int, double, double) {}     // box bounds are not part of g / viol
     BMPC_INL void zdiag(int, int, double, double) {}
     BMPC_INL void pose(int s, const double*, int, double h) { rowv(s, h, (s >= S_ROTL && s < S_COL) || (s >= S_TROTL)); }
+    template <int S0, int CNT> BMPC_INL void group() {}
     template <int C_> BMPC_INL void point_begin() {}
     template <int C_> BMPC_INL void point(int s, const double*, double h) { rowv(s, h, false); }
     template <int C_> BMPC_INL void point_end() {}
 };
 
-BMPC_DEV void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
+BMPC_KBODY void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[8], N = A.N;          // the done list: instances that finished since the last retirement
     if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.done, count, wave, lane);
-    PGP pg = stage_params<false>(A, A.L.done, count, wave, lane, m, lds_par);
+    PGP pg = stage_params(A, A.L.done, count, wave, lane, m, lds_par);
     if (!m.valid) return;
     const int k = m.k, n_w = 44 * N + 6;
     const size_t b = (size_t)A.src[m.b];            // output row of the instance
@@ -1376,6 +1362,7 @@ struct MultVisitor {
         for (int c = 0; c < 6; c++) bz[c] += z * a[c];
         if (sel == 1) sPS -= z; else if (sel == 2) sRS -= z; else if (sel == 3) sD[5] -= z;
     }
+    template <int S0, int CNT> BMPC_INL void group() {}
     template <int C> BMPC_INL void point_begin() {}
     template <int C> BMPC_INL void point(int s, const double* a, double) {
         const double z = zrow(s);
@@ -1401,7 +1388,7 @@ BMPC_INL void point_forces_to_q(const KinT& K, const double Fc[6][3], double* cq
     }
 }
 
-BMPC_DEV void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
+BMPC_KBODY void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.B, N = A.N;
     if (wave * ipw_of(N) >= count) return;
     PairMap m;
@@ -1413,7 +1400,7 @@ BMPC_DEV void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) 
         if (!m.valid) { e = wave * ipw; kk = 0; li = 0; }
         m.b = e; m.k = kk + 1; m.li = li; m.pi = pair_of(A, m.b, m.k);
     }
-    PGP pg = stage_params<false>(A, (GCI)nullptr, count, wave, lane, m, lds_par);
+    PGP pg = stage_params(A, (GCI)nullptr, count, wave, lane, m, lds_par);
     if (!m.valid) return;
     const int k = m.k, n_w = 44 * N + 6, n_g = 147 * (N - 1) + 21;
     const size_t b = (size_t)A.src[m.b];

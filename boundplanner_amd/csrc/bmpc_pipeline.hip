@@ -56,11 +56,7 @@ __global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
     k_fwd_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
-// streaming row kernels: 64 pairs x 4 slot groups per workgroup
-__global__ __launch_bounds__(256) void bmpc_k_rowstep(PipeArgsH H) {
-    __shared__ double lds[768];
-    k_rowstep_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
-}
+// streaming row kernel: 64 pairs x 4 slot groups per workgroup
 __global__ __launch_bounds__(256) void bmpc_k_rowtrial(PipeArgsH H) {
     __shared__ double lds[512 + 8];
     k_rowtrial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
@@ -121,7 +117,6 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     else LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH(bmpc_k_rowstep, nw, 256);      // + line-search start per instance
     LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH(bmpc_k_rowtrial, nw, 256);     // + filter test per instance, accepted trials become the iterate
     LAUNCH(bmpc_k_rotate, 1, 64);

@@ -185,9 +185,7 @@ BMPC_HD int waves_for(int N, int count) { int ipw = ipw_of(N); return (count + i
 
 // stage the parameter vectors of this wavefront's instances: lds_par[li][NPAR]; returns the calling
 // lane's copy.  All 64 lanes must call it (contains a barrier).
-// BATCHED (the kernels of the super-step): three instances at a time, all loads issued before the first LDS store.  The
-// retirement / admission kernels (k_init, k_out, k_mult) keep the plain loop: k_init compiled with the batched form does
-// not terminate on gfx950 (ROCm 7.2; the CPU emulation of the same source does) -- not root-caused, see DESIGN.md section 7
+// BATCHED: three instances at a time, all loads issued before the first LDS store (the plain loop is kept for A/B runs)
 template <bool BATCHED = true>
 BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int lane, const PairMap& m, LDSD* lds_par) {
     const int ipw = ipw_of(A.N);

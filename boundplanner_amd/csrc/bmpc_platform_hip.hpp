@@ -6,6 +6,9 @@
 
 #define BMPC_DEV __device__
 #define BMPC_INL __device__ __forceinline__
+// kernel bodies: always inlined into their __global__ wrapper (as a separate function the body loses the wrapper's launch
+// bounds, and two such bodies -- k_init with batched parameter staging, k_step with the row steps -- did not terminate on gfx950)
+#define BMPC_KBODY __device__ __forceinline__
 #define BMPC_SYNC() __syncthreads()
 // barrier after which the GLOBAL-memory writes of the workgroup's threads are visible to each other
 #define BMPC_FENCE_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)

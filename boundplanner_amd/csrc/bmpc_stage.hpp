@@ -366,6 +366,14 @@ BMPC_INL void cost_hess(PGP pg, const SegCtx& C, bool term, double* Hp /*21*/, d
 //   v.point<C>(s, a3, h)               collision-point row of point C (slack d_C, coef -1)
 // and v.skip(s) for inactive slots.  Slot numbering: bmpc_device.hpp (S_*).
 // ------------------------------------------------------------------------------------------
+// Row groups of walk_rows: before the rows of a group are walked the visitor's group<S0, CNT>() hook runs (the six point
+// groups announce themselves through point_begin<C>()), so that a visitor which needs per-row data from memory can load a
+// whole group in one batch.  row_group_base(s) = first slot of the group of slot s.
+BMPC_HD constexpr int row_group_base(int s) {
+    return s < 28 ? 0 : s < S_NONNEG ? 28 : s < S_EE ? S_NONNEG : s < S_COL ? S_EE : s < S_PHI ? S_COL + 15 * ((s - S_COL) / 15) : S_PHI;
+}
+constexpr int ROW_GROUP_MAX = 28;
+
 template <class V, int C0>
 BMPC_INL void walk_points(PGP pg, const KinT& K, const SegCtx& C, V& v) {
     if constexpr (C0 < 6) {
@@ -394,6 +402,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
     // cost one memory round trip each (the thread-per-pair kernels run one wavefront per SIMD: nothing hides it)
     BMPC_UNROLL
     for (int half = 0; half < 2; half++) {
+        if (half == 0) v.template group<0, 28>(); else v.template group<28, 28>();
         double ubv[14], lbv[14];
         BMPC_UNROLL
         for (int i = 0; i < 14; i++) {
@@ -412,6 +421,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         }
     }
     // rs, drs, ps, dps >= 0 (Q6)
+    v.template group<S_NONNEG, S_EE - S_NONNEG>();
     v.diag(S_NONNEG + 0, Z_RS, -1.0, -y[Z_RS]);
     v.diag(S_NONNEG + 1, Z_DRS, -1.0, -y[Z_DRS]);
     v.diag(S_NONNEG + 2, Z_PS, -1.0, -y[Z_PS]);
@@ -426,6 +436,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         for (int i = 0; i < 8; i++) v.skip(S_RS1 + i);
     }
     // EE in current set (ocp :304)
+    v.template group<S_EE, S_COL - S_EE>();
     {
         PGP a = pg + P_ASET + 45 * C.s;
         BMPC_UNROLL
@@ -449,6 +460,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
     // collision points (ocp :323-330)
     walk_points<V, 0>(pg, K, C, v);
     // phi cap (ocp :332)
+    v.template group<S_PHI, S_END - S_PHI>();
     {
         double a6[6] = {C.dpp[0], C.dpp[1], C.dpp[2], 0, 0, 0};
         v.pose(S_PHI, a6, 0, C.phi - (C.phiend + 0.005));

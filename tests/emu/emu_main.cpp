@@ -15,6 +15,7 @@ static std::barrier<>* g_bar = nullptr;
 static thread_local int t_lane = 0;
 #define BMPC_DEV
 #define BMPC_INL inline
+#define BMPC_KBODY inline
 #define BMPC_HD inline
 #define BMPC_NOINL
 typedef double LDSD;

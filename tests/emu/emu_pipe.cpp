@@ -15,6 +15,7 @@ static std::barrier<>* g_bar = nullptr;
 static thread_local int t_lane = 0;
 #define BMPC_DEV inline
 #define BMPC_INL inline
+#define BMPC_KBODY inline
 #define BMPC_HD inline
 #define BMPC_NOINL
 typedef double LDSD;
@@ -118,7 +119,6 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
         launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
-        launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_rowstep_body(A, blk, l, lds.data()); }, 256);
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_rowtrial_body(A, blk, l, lds.data()); }, 256);
         k_rotate_body(A);
