@@ -191,7 +191,7 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
     }
     BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
         size_t o = (size_t)s * A->NP + pi;
-        row_tz(A->t[o], A->z[o], h, sg, r0, r1, zz);     // read-only here: the accepted trial was made current by k_rowtrial
+        row_tz(A->t[o], A->z[o], h, sg, r0, r1, zz);     // read-only here: the accepted trial was made current by k_accept
     }
     // the same with the slack t and the multiplier z of the row already in registers (RowPre)
     BMPC_INL void row_tz(double t, double z_in, double h, double& sg, double& r0, double& r1, double& zz) {
@@ -922,7 +922,7 @@ BMPC_INL void ls0_instance(const PipeArgs& A, int b) {
 }
 
 // filter acceptance test of one instance's trial point (Waechter & Biegler 2006, Sec. 2.3) from the per-pair partials of
-// k_trial / k_rowtrial; returns true when the trial becomes the iterate
+// k_trial; returns true when the trial becomes the iterate
 BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
     const int N = A.N;
     GST st = A.st + b;
@@ -1101,15 +1101,30 @@ BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 // ------------------------------------------------------------------------------------------
 struct TrialVisitor {
     const PipeArgs* A; size_t pi; bool valid;
+    double alpha;
+    double gt[ROW_GROUP_MAX], gc[ROW_GROUP_MAX];      // slack t and t + dt (k_step's c) of the current row group, one batch of loads
+    double thr;                                       // row part of theta
+    double lp; int le;                                // sum log t of the trial point as log of the running product lp * 2^le
+                                                      // (mantissa renormalised every row: one log per pair instead of one per row)
+    template <int S0, int CNT> BMPC_INL void group() {
+        static_assert(CNT <= ROW_GROUP_MAX, "row group size");
+        BMPC_UNROLL
+        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = A->t[o]; gc[i] = A->dt[o]; }
+    }
     BMPC_INL void fin(int s, double h) {
-        if (valid) A->t_t[(size_t)s * A->NP + pi] = h;     // finished in place by k_rowtrial: t + alpha dt
+        // trial slack t + alpha dt, its share of theta and of the barrier term; kept for the accept pass
+        const double t = gt[s - row_group_base(s)];
+        const double tn = t + alpha * (gc[s - row_group_base(s)] - t);
+        thr += fabs(h + tn);
+        int e;
+        lp = frexp(lp * tn, &e); le += e;
+        if (valid) A->t_t[(size_t)s * A->NP + pi] = tn;
     }
     BMPC_INL void skip(int) {}
     BMPC_INL void diag(int s, int, double, double h) { fin(s, h); }
     BMPC_INL void zdiag(int s, int, double, double h) { fin(s, h); }
     BMPC_INL void pose(int s, const double*, int, double h) { fin(s, h); }
-    template <int S0, int CNT> BMPC_INL void group() {}
-    template <int C> BMPC_INL void point_begin() {}
+    template <int C> BMPC_INL void point_begin() { group<S_COL + 15 * C, 15>(); }
     template <int C> BMPC_INL void point(int s, const double*, double h) { fin(s, h); }
     template <int C> BMPC_INL void point_end() {}
 };
@@ -1136,9 +1151,9 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
         for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
     stage_point(A, pg, iw0, k, dc, S);
     TrialVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid;
+    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0;
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
-    double th = 0;     // dynamics / initial-state part of theta; the row part is added by k_rowtrial
+    double th = 0;     // dynamics / initial-state part of theta
     if (!term) {
         double zn[NX], rdef[NX];
         BMPC_UNROLL
@@ -1155,52 +1170,31 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
     }
     if (m.valid) {
         GD P = A.part + m.pi;
-        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th;
+        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th + V.thr;
+        P[PT_LS1 * A.NP] = log(V.lp) + (double)V.le * 0.69314718055994530942;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// streaming row kernels: 256 threads = 64 pairs x 4 slot groups; a thread walks slots g, g+4, ...
-// These carry every load-modify-store on the row arrays (t, z, dt, dz_row): little register state, so
-// they run at full occupancy and hide the HBM latency that a thread-per-pair kernel cannot.
-// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 3 * 256 doubles.
-// They also run the per-instance line-search logic: the pairs of an instance are lanes of one workgroup.
+// k_accept: 256 threads = 64 pairs x 4 slot groups (a thread walks slots g, g+4, ...): per instance of the workgroup the
+// filter acceptance test on the partials k_trial left, and for an accepted trial the streaming copy that makes it the
+// iterate: t = t_t, z += alpha_dual dz_row, zeta = zeta_t.  Little register state, so it runs at full occupancy.
+// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 8 doubles.
+// (Round 1 had three streaming row kernels and three per-instance control kernels here; the row arithmetic now lives in
+// k_step and k_trial, whose row groups are loaded in batches.)
 // ------------------------------------------------------------------------------------------
 constexpr int ROW_GROUPS = 4;
 
-// k_rowtrial: t_t = t + alpha dt (in place over the h values k_trial left there), theta += |h + t_t|, sum log t_t,
-// reduced over the pair in slot-group order and added to k_trial's partials; then, per instance of this workgroup, the
-// filter acceptance test, and for an accepted trial the copy that makes it the iterate: t = t_t, z += alpha_dual dz_row,
-// zeta = zeta_t (rows still hot in L2; these were two more kernels and a cold re-read before)
-BMPC_DEV void k_rowtrial_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
+BMPC_DEV void k_accept_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
     const int count = A.L.cnt[2], N = A.N;
     if (wave * ipw_of(N) >= count) return;
     const int lane = tid & 63, g = tid >> 6;
     PairMap m = pair_map(A, A.L.trial, count, wave, lane);
-    const double alpha = A.st[m.b].alpha;
-    double th = 0.0, ls = 0.0;
-    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
-        size_t o = (size_t)s * A.NP + m.pi;
-        if (A.z[o] > 0.0) {
-            const double t = A.t[o];
-            double tn = t + alpha * (A.dt[o] - t);
-            th += fabs(A.t_t[o] + tn); ls += log(tn);
-            if (m.valid) A.t_t[o] = tn;
-        }
-    }
-    lds[tid] = th; lds[256 + tid] = ls;
+    if (tid < IPW_MAX) lds[tid] = 0.0;       // per-instance verdicts
     BMPC_SYNC();
-    if (g == 0 && m.valid) {
-        double a = 0.0, b = 0.0;
-        for (int q = 0; q < ROW_GROUPS; q++) { a += lds[64 * q + lane]; b += lds[256 + 64 * q + lane]; }
-        GD P = A.part + m.pi;
-        P[PT_TH1 * A.NP] += a; P[PT_LS1 * A.NP] = b;
-    }
-    if (tid < IPW_MAX) lds[512 + tid] = 0.0;       // per-instance verdicts
+    if (g == 0 && m.valid && m.k == 1 && ls_instance(A, m.b)) lds[m.li] = 1.0;
     BMPC_FENCE_SYNC();
-    if (g == 0 && m.valid && m.k == 1 && ls_instance(A, m.b)) lds[512 + m.li] = 1.0;
-    BMPC_FENCE_SYNC();
-    if (!m.valid || lds[512 + m.li] == 0.0) return;
+    if (!m.valid || lds[m.li] == 0.0) return;
     const double ad = A.st[m.b].ad;
     for (int s = g; s < NSLOT; s += ROW_GROUPS) {
         size_t o = (size_t)s * A.NP + m.pi;

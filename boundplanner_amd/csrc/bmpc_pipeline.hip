@@ -56,10 +56,10 @@ __global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
     k_fwd_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
-// streaming row kernel: 64 pairs x 4 slot groups per workgroup
-__global__ __launch_bounds__(256) void bmpc_k_rowtrial(PipeArgsH H) {
-    __shared__ double lds[512 + 8];
-    k_rowtrial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
+// filter test per instance + streaming accept pass: 64 pairs x 4 slot groups per workgroup
+__global__ __launch_bounds__(256) void bmpc_k_accept(PipeArgsH H) {
+    __shared__ double lds[8];
+    k_accept_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64) void bmpc_k_admit(PipeArgsH H) { k_admit_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
@@ -118,7 +118,7 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH(bmpc_k_rowtrial, nw, 256);     // + filter test per instance, accepted trials become the iterate
+    LAUNCH(bmpc_k_accept, nw, 256);       // filter test per instance, accepted trials become the iterate
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
     t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;

@@ -120,7 +120,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l, lds.data()); });
-        launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_rowtrial_body(A, blk, l, lds.data()); }, 256);
+        launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_accept_body(A, blk, l, lds.data()); }, 256);
         k_rotate_body(A);
         std::swap(A.L.eval, A.L.eval_next);
         std::swap(A.L.trial, A.L.trial_next);
