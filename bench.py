@@ -36,7 +36,7 @@ HORIZON = 20
 BATCH_PER_GPU = 8192
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VEC_PEAK_TFLOPS = 78.6    # vector FP64 peak (spec); the binding resource of this kernel
-MAX_DISTINCT = 16              # distinct batches resident at once (231 MB each); longer runs cycle through them
+MAX_DISTINCT = 24              # distinct batches resident at once (231 MB each); longer runs cycle through them
 
 
 def alg_bytes_per_solve(N):
@@ -84,7 +84,7 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16, help="timed batches (default 16: four streaming calls of four batches)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=HORIZON)
