@@ -724,6 +724,18 @@ BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         double HpX[21], Hv[21];
         cost_hess(pg, S.C, term, HpX, Hv);
         PA.load_hqq();
+        // register-resident copies of the kinematic columns for this block (they are read ~20 times each here; the originals
+        // were parked in scratch while the pose / diagonal rows needed the registers)
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++)
+            BMPC_UNROLL
+            for (int j = 0; j < 7; j++) { BMPC_PIN(S.Jl[a][j]); BMPC_PIN(S.K.zx[j][a]); }
+        BMPC_UNROLL
+        for (int a = 0; a < 6; a++)
+            BMPC_UNROLL
+            for (int j = 0; j < 7; j++) BMPC_PIN(G[a][j]);
+        BMPC_UNROLL
+        for (int i = 0; i < 21; i++) BMPC_PIN(PO.M6[i]);
         chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA, E);
     }
     // The iterate is read again (and its natural form recomputed) for the rest of the kernel instead of being carried

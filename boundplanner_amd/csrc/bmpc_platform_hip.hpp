@@ -10,6 +10,9 @@
 // bounds, and two such bodies -- k_init with batched parameter staging, k_step with the row steps -- did not terminate on gfx950)
 #define BMPC_KBODY __device__ __forceinline__
 #define BMPC_SYNC() __syncthreads()
+// optimisation barrier on a double in a vector register: the value after it is a new one for the register allocator
+// (used to end the live range of a spilled value and start a register-resident copy for a hot block)
+#define BMPC_PIN(x) asm volatile("" : "+v"(x))
 // barrier after which the GLOBAL-memory writes of the workgroup's threads are visible to each other
 #define BMPC_FENCE_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 #define BMPC_LANE() ((int)threadIdx.x)

@@ -16,6 +16,7 @@ static thread_local int t_lane = 0;
 #define BMPC_DEV
 #define BMPC_INL inline
 #define BMPC_KBODY inline
+#define BMPC_PIN(x) do {} while (0)
 #define BMPC_HD inline
 #define BMPC_NOINL
 typedef double LDSD;
