@@ -1166,11 +1166,17 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
     V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0;
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
     double th = 0;     // dynamics / initial-state part of theta
+    // the trial point is formed again from memory here instead of being carried through the row walk (same arithmetic;
+    // carried, it sits in scratch and is reloaded entry by entry)
+    const double vang[3] = {S.C.v[3], S.C.v[4], S.C.v[5]};
+    double zt[NZ];
+    BMPC_UNROLL
+    for (int i = 0; i < NZ; i++) zt[i] = A.zeta[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
     if (!term) {
         double zn[NX], rdef[NX];
         BMPC_UNROLL
         for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
-        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+        defect_all(zt, zn, vang, dc, rdef);
         BMPC_UNROLL
         for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
     }
@@ -1178,7 +1184,7 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
         double x1fix[24];
         x1fix_eval(lbx, N, dc.dt, x1fix);
         BMPC_UNROLL
-        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
+        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - zt[i]);
     }
     if (m.valid) {
         GD P = A.part + m.pi;
