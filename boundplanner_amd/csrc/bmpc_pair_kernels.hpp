@@ -985,7 +985,8 @@ struct StepVisitor {
     const double* dzt;    // zeta step
     double dloc[6], dpt[6][3];
     double gt[ROW_GROUP_MAX], gz[ROW_GROUP_MAX];     // slack t and multiplier z of the current row group, loaded in one batch
-    double rp, rd, dbar;                              // max(-dt/t), max(-dz/z), -mu sum dt/t over the rows of this pair
+    double rp, rdn, rdd, dbar;                        // max(-dt/t), max(-dz/z) as the fraction rdn / rdd (one division per pair
+                                                      // instead of one per row), -mu sum dt/t over the rows of this pair
     template <int S0, int CNT> BMPC_INL void group() {
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
         BMPC_UNROLL
@@ -997,7 +998,8 @@ struct StepVisitor {
         const double c = -h - adot, t = gt[s - row_group_base(s)], z = gz[s - row_group_base(s)];
         const double rt = 1.0 / t, dti = c - t, dzi = (mu - t * z - z * dti) * rt;
         if (valid) { size_t o = (size_t)s * A->NP + pi; A->dt[o] = c; A->dzr[o] = dzi; }
-        rp = fmax(rp, -dti * rt); rd = fmax(rd, -dzi / z);
+        rp = fmax(rp, -dti * rt);
+        if (-dzi * rdd > rdn * z) { rdn = -dzi; rdd = z; }          // -dzi / z > rdn / rdd  (z, rdd > 0)
         dbar -= mu * dti * rt;
     }
     BMPC_INL void skip(int) {}
@@ -1062,7 +1064,7 @@ BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     nat_all(dzt, dc, dy);
     StepVisitor V;
     V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu);
-    V.dy = dy; V.dzt = dzt; V.rp = 0.0; V.rd = 0.0; V.dbar = 0.0;
+    V.dy = dy; V.dzt = dzt; V.rp = 0.0; V.rdn = 0.0; V.rdd = 1.0; V.dbar = 0.0;
     double dv[6];
     BMPC_UNROLL
     for (int a = 0; a < 6; a++) {
@@ -1100,7 +1102,7 @@ BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     if (m.valid) {
         GD P = A.part + m.pi;
         P[PT_DPHIF * A.NP] = dphi_f;
-        P[PT_AP * A.NP] = (V.rp > 0) ? V.tau / V.rp : 1.0; P[PT_AD * A.NP] = (V.rd > 0) ? V.tau / V.rd : 1.0; P[PT_DBAR * A.NP] = V.dbar;
+        P[PT_AP * A.NP] = (V.rp > 0) ? V.tau / V.rp : 1.0; P[PT_AD * A.NP] = (V.rdn > 0) ? V.tau / (V.rdn / V.rdd) : 1.0; P[PT_DBAR * A.NP] = V.dbar;
     }
     // the pairs of an instance are lanes of this wavefront: line-search start per instance (a kernel of its own, then part
     // of the streaming row kernel k_rowstep, before the row steps moved in here)
@@ -1166,17 +1168,11 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
     V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0;
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
     double th = 0;     // dynamics / initial-state part of theta
-    // the trial point is formed again from memory here instead of being carried through the row walk (same arithmetic;
-    // carried, it sits in scratch and is reloaded entry by entry)
-    const double vang[3] = {S.C.v[3], S.C.v[4], S.C.v[5]};
-    double zt[NZ];
-    BMPC_UNROLL
-    for (int i = 0; i < NZ; i++) zt[i] = A.zeta[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
     if (!term) {
         double zn[NX], rdef[NX];
         BMPC_UNROLL
         for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
-        defect_all(zt, zn, vang, dc, rdef);
+        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
         BMPC_UNROLL
         for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
     }
@@ -1184,7 +1180,7 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
         double x1fix[24];
         x1fix_eval(lbx, N, dc.dt, x1fix);
         BMPC_UNROLL
-        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - zt[i]);
+        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
     }
     if (m.valid) {
         GD P = A.part + m.pi;
@@ -1214,15 +1210,31 @@ BMPC_DEV void k_accept_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
     BMPC_FENCE_SYNC();
     if (!m.valid || lds[m.li] == 0.0) return;
     const double ad = A.st[m.b].ad;
-    for (int s = g; s < NSLOT; s += ROW_GROUPS) {
-        size_t o = (size_t)s * A.NP + m.pi;
-        double z = A.z[o];
-        if (z > 0.0) {
-            A.t[o] = A.t_t[o];
-            if (ad != 0.0) A.z[o] = z + ad * A.dzr[o];
+    // four slots per trip, all their loads issued before the first store (a trip per slot is two dependent round trips)
+    static_assert(NSLOT % (4 * ROW_GROUPS) == 0, "slots per thread");
+    for (int s0 = g; s0 < NSLOT; s0 += 4 * ROW_GROUPS) {
+        double z4[4], t4[4], d4[4];
+        BMPC_UNROLL
+        for (int u = 0; u < 4; u++) {
+            size_t o = (size_t)(s0 + u * ROW_GROUPS) * A.NP + m.pi;
+            z4[u] = A.z[o]; t4[u] = A.t_t[o]; d4[u] = A.dzr[o];
+        }
+        BMPC_UNROLL
+        for (int u = 0; u < 4; u++) {
+            size_t o = (size_t)(s0 + u * ROW_GROUPS) * A.NP + m.pi;
+            if (z4[u] > 0.0) {
+                A.t[o] = t4[u];
+                if (ad != 0.0) A.z[o] = z4[u] + ad * d4[u];
+            }
         }
     }
-    for (int i = g; i < NZ; i += ROW_GROUPS) A.zeta[(size_t)i * A.NP + m.pi] = A.zeta_t[(size_t)i * A.NP + m.pi];
+    {
+        double zc[(NZ + ROW_GROUPS - 1) / ROW_GROUPS];
+        BMPC_UNROLL
+        for (int u = 0; u < (NZ + ROW_GROUPS - 1) / ROW_GROUPS; u++) { int i = g + u * ROW_GROUPS; zc[u] = (i < NZ) ? A.zeta_t[(size_t)i * A.NP + m.pi] : 0.0; }
+        BMPC_UNROLL
+        for (int u = 0; u < (NZ + ROW_GROUPS - 1) / ROW_GROUPS; u++) { int i = g + u * ROW_GROUPS; if (i < NZ) A.zeta[(size_t)i * A.NP + m.pi] = zc[u]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
