@@ -538,10 +538,14 @@ BMPC_INL bool ric_phase_factor_impl(const PipeArgsH& A, LDSD* lds, int b, int la
         if (lane < NX) { RL(R_lam)[lane] = gl; RL(R_acc)[lane] += fabs(gl); }
     }
     // ---- control block factorisation, gains, Schur complement ----
-    double Lc[45], invd[NU];
-    if (!chol9i(RL(R_W), reg, Lc, invd)) ok = false;
+    // the factor is needed by the 34 lanes that solve for a gain column: the first wavefront computes it (every lane for
+    // itself: no LDS round trips inside the factorisation), the second skips the whole block; the verdict travels through LDS
     double* krec = A.krec + krec_of(A, b, k);
-    if (lane < NX + 2) {
+    if (lane < 64) {
+      double Lc[45], invd[NU];
+      const bool pd = chol9i(RL(R_W), reg, Lc, invd);
+      if (lane == 0) RL(R_park)[13] = pd ? 1.0 : 0.0;
+      if (lane < NX + 2) {
         double rhs[NU];
         BMPC_UNROLL
         for (int l = 0; l < NU; l++)
@@ -552,8 +556,10 @@ BMPC_INL bool ric_phase_factor_impl(const PipeArgsH& A, LDSD* lds, int b, int la
             if (lane < NX) { RL(R_Kl)[l * NX + lane] = -rhs[l]; krec[l * NX + lane] = -rhs[l]; }
             else { RL(R_kf)[(lane - NX) * 16 + l] = -rhs[l]; krec[NU * NX + (lane - NX) * 16 + l] = -rhs[l]; }
         }
+      }
     }
     BMPC_SYNC();
+    if (RL(R_park)[13] == 0.0) ok = false;
     RPROF(4);
     // P = W_xx + W_xu K: lane = column j (two half-waves split the rows), K[:, j] in registers,
     // W_ux rows fetched two at a time as broadcast 16-byte reads; loads of a batch precede its stores
