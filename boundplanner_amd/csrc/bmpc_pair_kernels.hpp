@@ -646,7 +646,7 @@ BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp,
 }
 
 // lds: EM_DOUBLES doubles per wave
-BMPC_DEV void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
+BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const int count = A.L.cnt[0], N = A.N;
     if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
