@@ -1,7 +1,8 @@
 """Per-kernel duration against the number of live instances: solves the first B instances of one configs[2] batch for a few
 interior-point iterations (max_iter 4: every instance is alive in every super-step), B = 256 ... 8192.  Run under
 `rocprofv3 --kernel-trace`, then `python tools/scaling_trace.py --parse <kernel_trace.csv>` prints, per B, the mean duration
-of each pipeline kernel over the super-steps of that solve.  One wavefront per SIMD = 1024 wavefronts = 3072 instances at N=20."""
+of each pipeline kernel in the FIRST super-step of that solve (all B instances alive; later launches of the same solve work on
+fewer and fewer instances).  One wavefront per SIMD = 1024 wavefronts = 3072 instances at N=20."""
 import argparse
 import collections
 import csv
@@ -37,12 +38,12 @@ def parse(path):
         cur.append((name, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
     solves.append(cur)
     names = ["bmpc_k_points", "bmpc_k_eval", "bmpc_k_curv", "bmpc_k_ric", "bmpc_k_ric_lat", "bmpc_k_fwd", "bmpc_k_step",
-             "bmpc_k_trial", "bmpc_k_accept"]
-    print("B      " + " ".join(f"{n[7:]:>9s}" for n in names) + "   (mean us per launch; k_eval workgroups)")
+             "bmpc_k_trial", "bmpc_k_accept", "bmpc_k_rowstep", "bmpc_k_rowtrial"]      # the last two: builds before the row fusion
+    print("B      " + " ".join(f"{n[7:]:>9s}" for n in names) + "   (us, first super-step of the solve; k_eval workgroups)")
     for B, sv in zip(SIZES, solves):
         d = collections.defaultdict(list)
         for n, us, wg in sv:
-            d[n].append(us)
+            if not d[n]: d[n].append(us)          # the first launch of each kernel = the first super-step
         wg = max(w for n, _, w in sv if n == "bmpc_k_eval")
         print(f"{B:6d} " + " ".join(f"{(sum(d[n]) / len(d[n]) if d[n] else 0):9.1f}" for n in names) + f"   {wg}")
 
