@@ -184,14 +184,15 @@ BMPC_KBODY void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 // ------------------------------------------------------------------------------------------
 struct RowAcc {   // row data access (accepting the trial values) + KKT partial sums
     const PipeArgs* A; size_t pi; bool valid; double ad;
+    GCD tc;                                          // the copy of the slack array that holds the iterate (cur_t)
     double cmax, csum, cmin, zsum, prim, nrows;     // f, theta, sum log t of this point: k_trial / k_init
-    BMPC_INL void init(const PipeArgs* A_, size_t pi_, bool valid_, double ad_) {
-        A = A_; pi = pi_; valid = valid_; ad = ad_;
+    BMPC_INL void init(const PipeArgs* A_, size_t pi_, bool valid_, double ad_, GCD tc_) {
+        A = A_; pi = pi_; valid = valid_; ad = ad_; tc = tc_;
         cmax = 0; csum = 0; cmin = 1e300; zsum = 0; prim = 0; nrows = 0;
     }
     BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
         size_t o = (size_t)s * A->NP + pi;
-        row_tz(A->t[o], A->z[o], h, sg, r0, r1, zz);     // read-only here: the accepted trial was made current by k_accept
+        row_tz(tc[o], A->z[o], h, sg, r0, r1, zz);     // read-only here: the accepted trial was made current by k_accept
     }
     // the same with the slack t and the multiplier z of the row already in registers (RowPre)
     BMPC_INL void row_tz(double t, double z_in, double h, double& sg, double& r0, double& r1, double& zz) {
@@ -210,9 +211,9 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
 template <int S0_, int CNT_> struct RowPre {
     static constexpr int S0 = S0_, CNT = CNT_;
     double t[CNT_], z[CNT_];
-    BMPC_INL void load(const PipeArgs& A, size_t pi) {
+    BMPC_INL void load(const PipeArgs& A, GCD tc, size_t pi) {
         BMPC_UNROLL
-        for (int i = 0; i < CNT_; i++) { size_t o = (size_t)(S0_ + i) * A.NP + pi; t[i] = A.t[o]; z[i] = A.z[o]; }
+        for (int i = 0; i < CNT_; i++) { size_t o = (size_t)(S0_ + i) * A.NP + pi; t[i] = tc[o]; z[i] = A.z[o]; }
     }
 };
 template <int I0_, int CNT_> struct BndPre {
@@ -242,7 +243,7 @@ struct PointAsm {
     BMPC_INL void skip(int) {}
     template <int C> BMPC_INL void point_begin() {
         BMPC_UNROLL
-        for (int i = 0; i < 15; i++) { size_t o = (size_t)(S_COL + 15 * C + i) * R->A->NP + R->pi; pt[i] = R->A->t[o]; pz[i] = R->A->z[o]; }
+        for (int i = 0; i < 15; i++) { size_t o = (size_t)(S_COL + 15 * C + i) * R->A->NP + R->pi; pt[i] = R->tc[o]; pz[i] = R->A->z[o]; }
         BMPC_UNROLL
         for (int i = 0; i < 6; i++) M3[i] = 0;
         BMPC_UNROLL
@@ -664,11 +665,13 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid);
     BMPC_SYNC();
     StagePoint S;
-    load_zeta(A.zeta, A.NP, m.pi, S.zeta);
+    const int flip = A.st[m.b].flip;
+    GCD zc = cur_zeta(A, flip), tc = cur_t(A, flip);
+    load_zeta(zc, A.NP, m.pi, S.zeta);
     // row data of the pose rows: in flight while the kinematics are evaluated
     RowPre<S_EE, 21> rp_pose;
-    rp_pose.load(A, m.pi);
-    const double t_phi = A.t[(size_t)S_PHI * A.NP + m.pi], z_phi = A.z[(size_t)S_PHI * A.NP + m.pi];
+    rp_pose.load(A, tc, m.pi);
+    const double t_phi = tc[(size_t)S_PHI * A.NP + m.pi], z_phi = A.z[(size_t)S_PHI * A.NP + m.pi];
     stage_point(A, pg, iw0, k, dc, S);
     double G[6][7];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);
@@ -679,7 +682,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         cost_hess(pg, S.C, term, Hp, HvX);
     }
     RowAcc R;
-    R.init(&A, m.pi, m.valid, ad);
+    R.init(&A, m.pi, m.valid, ad, tc);
     // ---- collision-point results of k_points: q x d columns first, the rest where it is needed ----
     PointRes PA;
     PA.base = A.part + (size_t)PT_SIDE * A.NP + m.pi; PA.NP = A.NP;
@@ -699,7 +702,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     walk_pose_rows(pg, N, k, S.y, S.C, PO, rp_pose, t_phi, z_phi);
     {
         RowPre<S_TSET, 21> rp_term;          // one batch of loads per row group, right before the group is walked
-        rp_term.load(A, m.pi);
+        rp_term.load(A, tc, m.pi);
         walk_pose_rows_term(pg, N, k, S.y, S.C, PO, rp_term);
     }
     const double hdt = 0.5 * dc.dt;
@@ -715,7 +718,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     {
         RowPre<0, 28> rp_a;                  // rows + bounds of the q, dq box
         BndPre<0, 14> bp_a;
-        rp_a.load(A, m.pi); bp_a.load(lbx, ubx, N, k);
+        rp_a.load(A, tc, m.pi); bp_a.load(lbx, ubx, N, k);
         PA.load_p17();
         p17_emit_all<0>(A, pg, rp_a, bp_a, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, g12 + 6, E);
     }
@@ -743,12 +746,12 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     // allocator otherwise parks in scratch memory and reloads for every entry of the block
     const double vang[3] = {S.C.v[3], S.C.v[4], S.C.v[5]};
     double zeta2[NZ], y2[NZ];
-    load_zeta(A.zeta, A.NP, m.pi, zeta2);
+    load_zeta(zc, A.NP, m.pi, zeta2);
     nat_all(zeta2, dc, y2);
     // ---- remaining diagonal rows + gradients: ddq, u, rs, drs, ps, dps, d ----
     RowPre<28, 40> rp_b;                     // rows + bounds of the ddq, u box, the slack rows, the zeta-diagonal rows
     BndPre<14, 14> bp_b;
-    rp_b.load(A, m.pi); bp_b.load(lbx, ubx, N, k);
+    rp_b.load(A, tc, m.pi); bp_b.load(lbx, ubx, N, k);
     PA.load_dg();
     dg_emit_all<14>(A, pg, rp_b, bp_b, k, term, y2, R, PA, PO, E);
     // ---- zeta-diagonal rows (k == 1) ----
@@ -793,7 +796,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         if (!term) {
             double zn[NX];
             BMPC_UNROLL
-            for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1];
+            for (int i = 0; i < NX; i++) zn[i] = zc[(size_t)i * A.NP + m.pi + 1];
             defect_all(zeta2, zn, vang, dc, rdef);
             BMPC_UNROLL
             for (int i = 0; i < NX; i++) prim = fmax(prim, fabs(rdef[i]));
@@ -836,7 +839,8 @@ BMPC_KBODY void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_p
     const DynC dc = make_dync(A.o.dt);
     PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds_par);
     double zeta[NZ], y[NZ];
-    load_zeta(A.zeta, A.NP, m.pi, zeta);
+    const int flip = A.st[m.b].flip;
+    load_zeta(cur_zeta(A, flip), A.NP, m.pi, zeta);
     nat_all(zeta, dc, y);
     KinT K;
     kin_chain(A.rc, y + Z_Q, K);
@@ -844,7 +848,7 @@ BMPC_KBODY void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_p
     BMPC_UNROLL
     for (int i = 0; i < 6; i++) C.sl[i] = pg[P_SLACKS0 + i] + y[Z_D + i];
     RowAcc R;
-    R.init(&A, m.pi, m.valid, 0.0);
+    R.init(&A, m.pi, m.valid, 0.0, cur_t(A, flip));
     PointAsm PA;
     PA.R = &R; PA.K = &K;
     PA.init();
@@ -891,7 +895,7 @@ BMPC_KBODY void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid, F_CQQ);
     BMPC_SYNC();
     double zeta[NZ], y[NZ];
-    load_zeta(A.zeta, A.NP, m.pi, zeta);
+    load_zeta(cur_zeta(A, A.st[m.b].flip), A.NP, m.pi, zeta);
     nat_all(zeta, dc, y);
     KinT K;
     double Jl[3][7];
@@ -962,6 +966,7 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
             st->nfilt = nf + 1;
         }
         st->f0 = f1; st->th0 = th1; st->ls0 = ls1;      // merit pieces of the accepted point
+        st->flip ^= 1;                                   // the trial copy of t / zeta is the iterate now (cur_t, cur_zeta)
         st->it += 1;
         st->hess_mode = (A.o.hess == 2 && st->err_prev < A.o.hess_switch) ? 1 : 0;
         st->state = ST_EVAL;
@@ -984,13 +989,14 @@ struct StepVisitor {
     const double* dy;     // natural step
     const double* dzt;    // zeta step
     double dloc[6], dpt[6][3];
+    GCD tc;                                          // cur_t of the instance
     double gt[ROW_GROUP_MAX], gz[ROW_GROUP_MAX];     // slack t and multiplier z of the current row group, loaded in one batch
     double rp, rdn, rdd, dbar;                        // max(-dt/t), max(-dz/z) as the fraction rdn / rdd (one division per pair
                                                       // instead of one per row), -mu sum dt/t over the rows of this pair
     template <int S0, int CNT> BMPC_INL void group() {
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
         BMPC_UNROLL
-        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = A->t[o]; gz[i] = A->z[o]; }
+        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gz[i] = A->z[o]; }
     }
     BMPC_INL void fin(int s, double h, double adot) {
         // row step: t + dt = c = -h - a.d (stored in A.dt: k_trial and the accept pass subtract t again),
@@ -1054,7 +1060,8 @@ BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     StagePoint S;
-    load_zeta(A.zeta, A.NP, m.pi, S.zeta);
+    const int flip = A.st[m.b].flip;
+    load_zeta(cur_zeta(A, flip), A.NP, m.pi, S.zeta);
     stage_point(A, pg, iw0, k, dc, S);
     double G[6][7], g12[12];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);
@@ -1063,7 +1070,7 @@ BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     load_zeta(A.dz, A.NP, m.pi, dzt);
     nat_all(dzt, dc, dy);
     StepVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu);
+    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu); V.tc = cur_t(A, flip);
     V.dy = dy; V.dzt = dzt; V.rp = 0.0; V.rdn = 0.0; V.rdd = 1.0; V.dbar = 0.0;
     double dv[6];
     BMPC_UNROLL
@@ -1116,6 +1123,7 @@ BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 struct TrialVisitor {
     const PipeArgs* A; size_t pi; bool valid;
     double alpha;
+    GCD tc; GD tn_out;                                // cur_t (read) and oth_t (the trial slacks go there) of the instance
     double gt[ROW_GROUP_MAX], gc[ROW_GROUP_MAX];      // slack t and t + dt (k_step's c) of the current row group, one batch of loads
     double thr;                                       // row part of theta
     double lp; int le;                                // sum log t of the trial point as log of the running product lp * 2^le
@@ -1123,7 +1131,7 @@ struct TrialVisitor {
     template <int S0, int CNT> BMPC_INL void group() {
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
         BMPC_UNROLL
-        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = A->t[o]; gc[i] = A->dt[o]; }
+        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gc[i] = A->dt[o]; }
     }
     BMPC_INL void fin(int s, double h) {
         // trial slack t + alpha dt, its share of theta and of the barrier term; kept for the accept pass
@@ -1132,7 +1140,7 @@ struct TrialVisitor {
         thr += fabs(h + tn);
         int e;
         lp = frexp(lp * tn, &e); le += e;
-        if (valid) A->t_t[(size_t)s * A->NP + pi] = tn;
+        if (valid) tn_out[(size_t)s * A->NP + pi] = tn;
     }
     BMPC_INL void skip(int) {}
     BMPC_INL void diag(int s, int, double, double h) { fin(s, h); }
@@ -1158,20 +1166,23 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     StagePoint S;
+    const int flip = A.st[m.b].flip;
+    GCD zc = cur_zeta(A, flip);
+    GD zo = oth_zeta(A, flip);
     BMPC_UNROLL
-    for (int i = 0; i < NZ; i++) S.zeta[i] = A.zeta[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
+    for (int i = 0; i < NZ; i++) S.zeta[i] = zc[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
     if (m.valid)
         BMPC_UNROLL
-        for (int i = 0; i < NZ; i++) A.zeta_t[(size_t)i * A.NP + m.pi] = S.zeta[i];
+        for (int i = 0; i < NZ; i++) zo[(size_t)i * A.NP + m.pi] = S.zeta[i];
     stage_point(A, pg, iw0, k, dc, S);
     TrialVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0;
+    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
     walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
     double th = 0;     // dynamics / initial-state part of theta
     if (!term) {
         double zn[NX], rdef[NX];
         BMPC_UNROLL
-        for (int i = 0; i < NX; i++) zn[i] = A.zeta[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
+        for (int i = 0; i < NX; i++) zn[i] = zc[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
         defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
         BMPC_UNROLL
         for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
@@ -1191,8 +1202,8 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
 
 // ------------------------------------------------------------------------------------------
 // k_accept: 256 threads = 64 pairs x 4 slot groups (a thread walks slots g, g+4, ...): per instance of the workgroup the
-// filter acceptance test on the partials k_trial left, and for an accepted trial the streaming copy that makes it the
-// iterate: t = t_t, z += alpha_dual dz_row, zeta = zeta_t.  Little register state, so it runs at full occupancy.
+// filter acceptance test on the partials k_trial left, and for an accepted trial the streaming update z += alpha_dual dz_row
+// (t and zeta: the instance's flip bit switches to the copies k_trial wrote).  Little register state: full occupancy.
 // A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 8 doubles.
 // (Round 1 had three streaming row kernels and three per-instance control kernels here; the row arithmetic now lives in
 // k_step and k_trial, whose row groups are loaded in batches.)
@@ -1210,30 +1221,22 @@ BMPC_DEV void k_accept_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
     BMPC_FENCE_SYNC();
     if (!m.valid || lds[m.li] == 0.0) return;
     const double ad = A.st[m.b].ad;
-    // four slots per trip, all their loads issued before the first store (a trip per slot is two dependent round trips)
+    if (ad == 0.0) return;
+    // z += alpha_dual dz_row; four slots per trip, all their loads issued before the first store (a trip per slot is two
+    // dependent round trips).  t and zeta need no copy: the instance's flip bit now points at the trial copies.
     static_assert(NSLOT % (4 * ROW_GROUPS) == 0, "slots per thread");
     for (int s0 = g; s0 < NSLOT; s0 += 4 * ROW_GROUPS) {
-        double z4[4], t4[4], d4[4];
+        double z4[4], d4[4];
         BMPC_UNROLL
         for (int u = 0; u < 4; u++) {
             size_t o = (size_t)(s0 + u * ROW_GROUPS) * A.NP + m.pi;
-            z4[u] = A.z[o]; t4[u] = A.t_t[o]; d4[u] = A.dzr[o];
+            z4[u] = A.z[o]; d4[u] = A.dzr[o];
         }
         BMPC_UNROLL
         for (int u = 0; u < 4; u++) {
             size_t o = (size_t)(s0 + u * ROW_GROUPS) * A.NP + m.pi;
-            if (z4[u] > 0.0) {
-                A.t[o] = t4[u];
-                if (ad != 0.0) A.z[o] = z4[u] + ad * d4[u];
-            }
+            if (z4[u] > 0.0) A.z[o] = z4[u] + ad * d4[u];
         }
-    }
-    {
-        double zc[(NZ + ROW_GROUPS - 1) / ROW_GROUPS];
-        BMPC_UNROLL
-        for (int u = 0; u < (NZ + ROW_GROUPS - 1) / ROW_GROUPS; u++) { int i = g + u * ROW_GROUPS; zc[u] = (i < NZ) ? A.zeta_t[(size_t)i * A.NP + m.pi] : 0.0; }
-        BMPC_UNROLL
-        for (int u = 0; u < (NZ + ROW_GROUPS - 1) / ROW_GROUPS; u++) { int i = g + u * ROW_GROUPS; if (i < NZ) A.zeta[(size_t)i * A.NP + m.pi] = zc[u]; }
     }
 }
 
@@ -1282,7 +1285,8 @@ BMPC_KBODY void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par)
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     StagePoint S;
-    load_zeta(A.zeta_t, A.NP, pi, S.zeta);     // the last evaluated point of the instance
+    GCD zc = cur_zeta(A, A.st[m.b].flip);
+    load_zeta(zc, A.NP, pi, S.zeta);           // the iterate the instance finished on
     stage_point(A, pg, iw0, k, dc, S);
     GD x = A.x + b * n_w;
     BMPC_UNROLL
@@ -1316,7 +1320,7 @@ BMPC_KBODY void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par)
     if (!term) {
         double zn[NX];
         BMPC_UNROLL
-        for (int i = 0; i < NX; i++) zn[i] = A.zeta_t[(size_t)i * A.NP + pi + 1];
+        for (int i = 0; i < NX; i++) zn[i] = zc[(size_t)i * A.NP + pi + 1];
         defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
         BMPC_UNROLL
         for (int i = 0; i < Z_D; i++) { double r = fabs(rdef[i]); if (r > 1e-6) V.viol += r; }
@@ -1438,7 +1442,7 @@ BMPC_KBODY void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
     StagePoint S;
-    load_zeta(A.zeta_t, A.NP, pi, S.zeta);     // the final point of the instance
+    load_zeta(cur_zeta(A, A.st[m.b].flip), A.NP, pi, S.zeta);     // the final point of the instance
     stage_point(A, pg, iw0, k, dc, S);
     double G[6][7], g12[12];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);

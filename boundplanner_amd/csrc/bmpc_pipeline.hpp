@@ -75,6 +75,7 @@ enum { ST_EVAL = 0, ST_STEP = 1, ST_TRIAL = 2, ST_DONE = 3 };
 // per-instance solver state (AoS, one per instance)
 struct InstState {
     int state, it, status, nfilt, hess_mode, bt, armijo, tries;
+    int flip, pad_;              // which copy of the double-buffered arrays (t / t_t, zeta / zeta_t) holds the iterate (cur_* below)
     double mu, alpha, ad, ap, hreg, err_prev, filt_mu, theta_max, theta_min;
     double f0, th0, ls0, D, phi0, fk;
     double filt_th[8], filt_phi[8];
@@ -134,6 +135,12 @@ typedef PipeArgsT<1> PipeArgs;           // device view (same layout)
 static_assert(sizeof(PipeArgsH) == sizeof(PipeArgs), "host/device argument layouts differ");
 typedef BMPC_AS1 InstState* GST;
 
+// The iterate's slacks and zeta live in t / zeta or in t_t / zeta_t, per instance (InstState.flip): k_trial writes the trial
+// point into the other copy and an accepted trial becomes the iterate by flipping the bit -- no copy pass.
+template <class AT> BMPC_INL auto cur_t(const AT& A, int flip) -> decltype(A.t) { return flip ? A.t_t : A.t; }
+template <class AT> BMPC_INL auto oth_t(const AT& A, int flip) -> decltype(A.t) { return flip ? A.t : A.t_t; }
+template <class AT> BMPC_INL auto cur_zeta(const AT& A, int flip) -> decltype(A.zeta) { return flip ? A.zeta_t : A.zeta; }
+template <class AT> BMPC_INL auto oth_zeta(const AT& A, int flip) -> decltype(A.zeta) { return flip ? A.zeta : A.zeta_t; }
 template <class AT> BMPC_INL size_t pair_of(const AT& A, int b, int k) { return (size_t)b * A.SS + (k - 1); }      // SoA offset
 template <class AT> BMPC_INL size_t hrec_of(const AT& A, int b, int k) { return (size_t)b * A.HS + (size_t)(k - 1) * HREC; }
 template <class AT> BMPC_INL size_t krec_of(const AT& A, int b, int k) { return (size_t)b * A.KS + (size_t)(k - 1) * KREC; }

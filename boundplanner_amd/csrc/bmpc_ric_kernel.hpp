@@ -831,7 +831,7 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
         for (int i = 0; i < 24; i++) RL(R_x1fix)[i] = x1fix[i];
     }
     BMPC_SYNC();
-    if (lane < 24) RL(R_r0)[lane] = RL(R_x1fix)[lane] - A.zeta[(size_t)lane * A.NP + pair_of(A, b, 1)];
+    if (lane < 24) RL(R_r0)[lane] = RL(R_x1fix)[lane] - cur_zeta(A, A.st[b].flip)[(size_t)lane * A.NP + pair_of(A, b, 1)];
     // KKT partial sums of the pairs: staged in LDS [quantity][pair], then one lane per quantity adds them
     // in pair order (fixed order -> reproducible; N - 1 <= 63 pairs)
     {
@@ -920,6 +920,7 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
 BMPC_INL void inst_reset(const PipeArgs& A, int slot) {
     GST st = A.st + slot;
     st->state = ST_EVAL; st->it = 0; st->status = 1; st->nfilt = 0; st->hess_mode = 0; st->bt = 0; st->armijo = 0; st->tries = 0;
+    st->flip = 0; st->pad_ = 0;
     st->mu = A.o.mu_init; st->alpha = 0; st->ad = 0; st->ap = 0; st->hreg = 0; st->err_prev = 1e300; st->filt_mu = -1;
     st->theta_max = 1e300; st->theta_min = 0; st->fk = 0;
 }
