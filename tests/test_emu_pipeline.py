@@ -55,3 +55,15 @@ def test_emulated_pipeline_several_wavefronts_per_kernel():
     pool = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True, slots=2)
     for k in ("x", "g", "f", "iters", "status", "viol"):
         assert np.array_equal(r[k], pool[k]), k
+
+
+def test_emulated_field_major_layout_is_bitwise_the_same(monkeypatch):
+    """BMPC_LAYOUT=0 (the field-major workspace of round 1, kept for A/B runs) against the slot-major default: the layouts
+    only move data, so every output is bitwise identical."""
+    N, B = 6, 5
+    batch = scenes.make_batch(B, N, 6, O.fk_batch, randomize_sets=True)
+    a = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    monkeypatch.setenv("BMPC_LAYOUT", "0")
+    b = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    for k in ("x", "g", "f", "iters", "status", "viol"):
+        assert np.array_equal(a[k], b[k]), k

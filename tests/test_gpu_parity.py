@@ -355,6 +355,25 @@ def test_pool_streams_a_batch_through_fewer_slots(backends):
         pool.close()
 
 
+def test_field_major_layout_is_bitwise_the_same(monkeypatch):
+    """BMPC_LAYOUT=0 selects the field-major workspace of round 1 (kept for A/B measurements) when a handle is created; it
+    only moves data: outputs are bitwise those of the slot-major default, also through a streaming pool."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N, B = 10, 700
+    ref = HipBoundMPC(N)
+    batch = scenes.make_batch(B, N, 2048, ref.fk, randomize_sets=True)
+    a = ref.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    monkeypatch.setenv("BMPC_LAYOUT", "0")
+    for kw in ({}, {"pool_slots": 256}):
+        other = HipBoundMPC(N, **kw)
+        b = other.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+        for k in ("x", "g", "f", "iters", "status", "viol"):
+            assert np.array_equal(a[k], b[k]), (kw, k)
+        other.close()
+    ref.close()
+
+
 def test_hip_matches_committed_slsqp_solutions(backends, golden_dir):
     """SURVEY 8(c) bridge (ii) on the product path: the HIP solve (through the C ABI) of the committed
     N=10 instances lands on the solutions an independent SLSQP run found (tests/golden/gen/gen_slsqp.py)."""
