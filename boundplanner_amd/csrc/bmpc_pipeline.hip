@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
-__global__ __launch_bounds__(BMPC_RIC_NT, 2) void bmpc_k_ric(PipeArgsH H) {          // throughput variant: 2 wavefronts / SIMD
+__global__ __launch_bounds__(BMPC_RIC_NT, 3) void bmpc_k_ric(PipeArgsH H) {          // throughput variant: 5 workgroups per CU (2.5 wavefronts / SIMD)
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
     k_ric_body<BMPC_RIC_NT, true>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
 }

@@ -13,9 +13,14 @@
 // optimisation barrier on a double in a vector register: the value after it is a new one for the register allocator
 // (used to end the live range of a spilled value and start a register-resident copy for a hot block)
 #define BMPC_PIN(x) asm volatile("" : "+v"(x))
+// an integer the compiler must treat as new from here on (32-bit vector register): keeps per-lane index arithmetic that
+// depends on it inside the loop iteration instead of hoisting hundreds of offsets out of the loop
+#define BMPC_OPAQUE_I(x) asm volatile("" : "+v"(x))
 // barrier after which the GLOBAL-memory writes of the workgroup's threads are visible to each other
 #define BMPC_FENCE_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 #define BMPC_LANE() ((int)threadIdx.x)
+// a value that is the same in every lane, moved to a scalar register (frees a vector register across calls)
+#define BMPC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define BMPC_BLOCK() ((int)blockIdx.x)
 #define BMPC_NBLOCKS() ((int)gridDim.x)
 #define BMPC_HD __host__ __device__ inline
@@ -56,3 +61,7 @@ __device__ __forceinline__ void bmpc_async_copy(__attribute__((address_space(1))
     }
 }
 #define BMPC_ASYNC_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// bring the cache line of a global address into the L2 without a register and without anyone waiting for it: a 4-byte
+// LDS-DMA load per lane into a junk area of LDS (64 lanes x 4 bytes from lds_junk on)
+#define BMPC_TOUCH_LINE(gptr, lds_junk) \
+    __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lds_junk), 4, 0, 0)

@@ -29,19 +29,19 @@ constexpr int R_Y = R_Et + 3 * NZ;          // 41 x 3
 constexpr int R_ew = R_Y + 3 * NZ;          // G_ang[3][7], J_ang[3][7]
 constexpr int R_sufz = R_ew + 42;           // [7][3]
 constexpr int R_dz2 = R_sufz + 24;          // sigma[2], r0[2], r1[2], zz[2]
-constexpr int R_dx = R_dz2 + 8;
-constexpr int R_dxn = R_dx + NX;
-constexpr int R_r0 = R_dxn + NX;
-constexpr int R_x1fix = R_r0 + NX;
-constexpr int R_dzeta = R_x1fix + NX;       // 48
-constexpr int R_dy = R_dzeta + ZPAD;        // 48
-constexpr int R_red = R_dy + ZPAD;          // up to 128 lanes
-constexpr int R_misc = R_red + 128;         // 48: junk targets of the scatter [0,32), phase timers [32,48)
-constexpr int R_acc = R_misc + 48;          // 2 x 128: per-lane |lambda| sums and dual-residual maxima
-constexpr int R_park = R_acc + 256;         // 16: uniform scalars parked across the sweep calls
-constexpr int R_stage = R_park + 16;        // HREC: the stage record, filled by LDS-DMA one stage ahead
-constexpr int RIC_LDS_DOUBLES = R_stage + HREC;
-static_assert(R_stage % 2 == 0 && RIC_LDS_DOUBLES * 8 <= 40960, "k_ric LDS: 4 workgroups per CU");
+constexpr int R_r0 = R_dz2 + 8;
+constexpr int R_misc = R_r0 + NX;           // 48: junk targets of the scatter [0,32), phase timers [32,48)
+constexpr int R_acc = R_misc + 48;          // 2 x 48: per-lane |lambda| sums and dual-residual maxima (lanes < 41)
+constexpr int R_park = R_acc + 96;          // 16: uniform scalars parked across the sweep calls
+constexpr int RIC_LDS_DOUBLES = R_park + 16;
+// used before the backward sweep / by the forward start only: they share the coupling phase's R_Et, R_Y (246 doubles)
+constexpr int R_dx = R_Et;
+constexpr int R_x1fix = R_dx + NX;
+constexpr int R_dzeta = R_x1fix + NX;       // 48 (forward start: packed 8 x 8 factor)
+constexpr int R_dy = R_dzeta + ZPAD;        // 48 (forward start: right-hand side)
+static_assert(R_dy + ZPAD <= R_Y + 3 * NZ, "forward-start scratch fits the coupling scratch");
+// 31.6 KB: five workgroups per CU (160 KB of LDS), i.e. 10 wavefronts = 2.5 per SIMD, which needs <= 168 VGPRs
+static_assert(RIC_LDS_DOUBLES * 8 <= 32768, "k_ric LDS: 5 workgroups per CU");
 
 // scatter table entry of one record field: pass (0 none, 1 store, 2 add, 3 add when hess_mode),
 // LDS offsets of the target and of its symmetric mirror (-1 = none)
@@ -210,16 +210,16 @@ BMPC_INL void ric_phase_load_impl(const PipeArgsH& A, LDSD* lds, int b, int lane
     const bool term = (k == N - 1);
     const size_t pi = pair_of(A, b, k);
     RPROF_START();
-    // ---- stage matrix from the record (natural coordinates) ----
+    // ---- stage matrix from the record (natural coordinates): the record's loads are in flight while W is cleared ----
+    GCD hrec_k = (GCD)(A.hrec + hrec_of(A, b, k));
+    double rv[NF];
+    BMPC_UNROLL
+    for (int i = 0; i < NF; i++) rv[i] = hrec_k[lane + NT * i];
     {
         const bmpc_v2d z2 = {0.0, 0.0};
         for (int e = lane; e < NZ * LDW / 2; e += NT) *(LDSV2*)(RL(R_W) + 2 * e) = z2;
     }
-    BMPC_ASYNC_WAIT();
     BMPC_SYNC();
-    double rv[NF];
-    BMPC_UNROLL
-    for (int i = 0; i < NF; i++) rv[i] = RL(R_stage)[lane + NT * i];
     BMPC_UNROLL
     for (int i = 0; i < NF; i++) {
         const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
@@ -246,7 +246,9 @@ BMPC_INL void ric_phase_load_impl(const PipeArgsH& A, LDSD* lds, int b, int lane
         BMPC_SYNC();
     }
     // every lane has consumed the staged record: fetch the next stage's behind the rest of this stage
-    if (k > 1) bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + hrec_of(A, b, k - 1)), RL(R_stage), lane);
+    // the next stage's record (5 KB): one dword per 128-byte line into the junk area by LDS-DMA (no register, nobody waits
+    // for it) so that its loads hit the L2 when that stage starts
+    if (k > 1 && lane < HREC / 16) BMPC_TOUCH_LINE((GCD)(A.hrec + hrec_of(A, b, k - 1)) + 16 * lane, RL(R_misc));
     RPROF(0);
     // ---- second-order term of the pi dynamics: multiplier lam_pi(k+1) times d2(dt w)/d(q,dq)2 ----
     if (hess_mode && !term) {
@@ -534,7 +536,7 @@ BMPC_INL bool ric_phase_factor_impl(const PipeArgsH& A, LDSD* lds, int b, int la
     // ---- adjoint multipliers + dual residual (gz now holds the Lagrangian gradient) ----
     if (lane < NZ) {
         double gl = RL(R_gz)[lane];
-        if (lane >= NX || (k == 1 && lane >= 24)) RL(R_acc)[128 + lane] = fmax(RL(R_acc)[128 + lane], fabs(gl));
+        if (lane >= NX || (k == 1 && lane >= 24)) RL(R_acc)[48 + lane] = fmax(RL(R_acc)[48 + lane], fabs(gl));
         if (lane < NX) { RL(R_lam)[lane] = gl; RL(R_acc)[lane] += fabs(gl); }
     }
     // ---- control block factorisation, gains, Schur complement ----
@@ -628,8 +630,8 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
     const DynC dc = make_dync(A.o.dt);
     bool ok = true;
     // per-lane accumulators of |lambda| and of the dual residual live in LDS (long live ranges in
-    // registers only get spilled): R_acc[lane], R_acc[128 + lane]
-    RL(R_acc)[lane] = 0.0; RL(R_acc)[128 + lane] = 0.0;
+    // registers only get spilled): R_acc[lane], R_acc[48 + lane] (lanes < 41 accumulate)
+    if (lane < 48) { RL(R_acc)[lane] = 0.0; RL(R_acc)[48 + lane] = 0.0; }
     if (lane < NX) { RL(R_lam)[lane] = 0; RL(R_pv0)[lane] = 0; RL(R_pv1)[lane] = 0; }
     constexpr int NF = HREC / NT;
     static_assert(HREC % NT == 0, "record loads are unconditional");
@@ -647,14 +649,26 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
     }
     constexpr int NE2 = (NZ * 9 + 27 + NT - 1) / NT;
     static_assert((NT == 64 || NT == 128) && HREC % 128 == 0, "record DMA: 1 KiB per wavefront instruction");
-    bmpc_async_copy<HREC / 128, NT>((GCD)(A.hrec + hrec_of(A, b, N - 1)), RL(R_stage), lane);
     for (int k = N - 1; k >= 1; k--) {
         const bool term = (k == N - 1);
         const size_t pi = pair_of(A, b, k);
         if constexpr (SPLIT) {
+#ifdef BMPC_RIC_CALLS
             ric_phase_load<NT>(A, lds, b, lane, k, hess_mode, tpk);
             if (!term) ric_phase_couple<NT>(A, lds, lane);
             if (!ric_phase_factor<NT>(A, lds, b, lane, k)) ok = false;
+#else
+            // the phases inline, each on a lane index the compiler cannot relate to the others': the per-lane offsets are
+            // recomputed per phase and stage (as with real calls) instead of being hoisted out of the stage loop, and no
+            // call sequence / callee-saved registers are involved
+            int l0 = lane, l1 = lane, l2 = lane;
+            BMPC_OPAQUE_I(l0);
+            ric_phase_load_impl<NT>(A, lds, b, l0, k, hess_mode, tpk);
+            BMPC_OPAQUE_I(l1);
+            if (!term) ric_phase_couple_impl<NT>(A, lds, l1);
+            BMPC_OPAQUE_I(l2);
+            if (!ric_phase_factor_impl<NT>(A, lds, b, l2, k)) ok = false;
+#endif
         } else {
             ric_phase_load_impl<NT>(A, lds, b, lane, k, hess_mode, tpk);
             if (!term) ric_phase_couple_impl<NT>(A, lds, lane);
@@ -664,10 +678,10 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
     // |lambda| sum (lanes < 32 contribute) and dual-residual maximum (lanes < 41), in lane order
     BMPC_SYNC();
     if (lane < 2) {
-        double v = RL(R_acc)[128 * lane];
+        double v = RL(R_acc)[48 * lane];
         const int n = lane ? NZ : NX;
 #pragma unroll 4
-        for (int i = 1; i < n; i++) { double x = RL(R_acc)[128 * lane + i]; v = lane ? fmax(v, x) : v + x; }
+        for (int i = 1; i < n; i++) { double x = RL(R_acc)[48 * lane + i]; v = lane ? fmax(v, x) : v + x; }
         RL(R_park)[9 + lane] = v;                         // results through LDS (see k_ric_body)
     }
     BMPC_SYNC();
@@ -676,7 +690,8 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
 
 // start of the forward recursion: step of x_1 for barrier parameter mu (pinned part = initial defect, free
 // part minimises the cost-to-go); false if the free part of the stage-1 value function is not positive definite
-template <int NT>
+// SPLIT: one instantiation per kernel variant, so that each is compiled under its kernel's register budget
+template <int NT, bool SPLIT>
 BMPC_NOINL bool ric_forward(const PipeArgsH& A, LDSD* lds, int b, int lane) {
     const double mu = lds[R_park + 11];
     bool ok = true;
@@ -819,7 +834,7 @@ template <int NT, bool SPLIT = true>
 BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
     const int count = A.L.cnt[0];
     if (blk >= count) return;
-    const int b = A.L.eval[blk];
+    const int b = BMPC_UNIFORM(A.L.eval[blk]);
     const int N = A.N, n_w = 44 * N + 6;
     const SolverOpts& o = A.o;
     InstState* st = A.st + b;
@@ -858,15 +873,18 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
 #ifdef BMPC_PROFILE
     if (lane < 16) RL(R_misc)[32 + lane] = 0.0;
 #endif
-    int hess_mode = st->hess_mode, it = st->it, tries = 0;
-    double hreg = st->hreg, mu = st->mu;
+    // uniform scalars that must survive the (non-inlined) sweeps: integers in scalar registers, mu and hreg in LDS
+    // (R_park[11], [12]) -- every vector register kept across the calls adds to the kernel's count
+    int hess_mode = BMPC_UNIFORM(st->hess_mode), tries = 0;
+    const int it = BMPC_UNIFORM(st->it);
+    if (lane == 0) { RL(R_park)[12] = st->hreg; RL(R_park)[11] = st->mu; }
     bool first = true;
     int status = -1;
     for (;;) {
-        if (lane == 0) RL(R_park)[12] = hreg;
         BMPC_SYNC();
         bool ok = ric_backward<NT, SPLIT>(A, lds, b, lane, hess_mode);
         const double lamsum = RL(R_park)[9], dual = RL(R_park)[10];
+        double mu = RL(R_park)[11];
         if (first) {
             first = false;
             const LDSD* pk = RL(R_park);
@@ -885,16 +903,23 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
                 emu = fmax(fmax(dual / sd, prim), fmax(cmax - mu, 0.0) / sc);
             }
         }
+        BMPC_SYNC();                                     // every lane has read mu before lane 0 replaces it
         if (lane == 0) RL(R_park)[11] = mu;
         BMPC_SYNC();
-        { RPROF_START(); if (ok) ok = ric_forward<NT>(A, lds, b, lane); RPROF(6); }
+        { RPROF_START(); if (ok) ok = ric_forward<NT, SPLIT>(A, lds, b, lane); RPROF(6); }
         if (ok) break;
         if (hess_mode) { hess_mode = 0; ++tries; }       // second-order terms not convex here: Gauss-Newton
         else {
+            double hreg = RL(R_park)[12];
             hreg = (hreg == 0.0) ? 1e-4 : hreg * 8;      // inertia correction (IPOPT delta_w)
+            BMPC_SYNC();
+            if (lane == 0) RL(R_park)[12] = hreg;
             if (++tries > 12) { status = 3; break; }
         }
     }
+    BMPC_SYNC();
+    double hreg = RL(R_park)[12];
+    const double mu = RL(R_park)[11];
 #ifdef BMPC_PROFILE
     BMPC_SYNC();
     if (lane < 16) atomicAdd(A.prof + lane, RL(R_misc)[32 + lane]);

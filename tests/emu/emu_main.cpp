@@ -17,6 +17,9 @@ static thread_local int t_lane = 0;
 #define BMPC_INL inline
 #define BMPC_KBODY inline
 #define BMPC_PIN(x) do {} while (0)
+#define BMPC_UNIFORM(x) (x)
+#define BMPC_OPAQUE_I(x) do {} while (0)
+#define BMPC_TOUCH_LINE(g, l) do {} while (0)
 #define BMPC_HD inline
 #define BMPC_NOINL
 typedef double LDSD;

@@ -16,7 +16,9 @@ SIZES = [256, 1024, 2048, 3072, 4096, 6144, 8192]
 def run():
     import numpy as np
     import torch  # noqa: F401  (HIP runtime first)
-    from boundplanner_amd import scenes
+    from boundplanner_amd import scenes, solver
+    if os.environ.get("BMPC_LIB"):          # A/B runs against another build of the library
+        solver.LIB_PATH = os.path.abspath(os.environ["BMPC_LIB"])
     from boundplanner_amd.solver import HipBoundMPC
     N = 20
     be = HipBoundMPC(N, max_iter=4)
