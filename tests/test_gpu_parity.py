@@ -355,6 +355,23 @@ def test_pool_streams_a_batch_through_fewer_slots(backends):
         pool.close()
 
 
+def test_pool_at_bench_horizon_is_bitwise_the_same(backends):
+    """The bench schedule in small: N = 20, 6000 instances streamed through a 2048-slot pool (every slot is reused about three
+    times, at different moments of its predecessors' solves) return bitwise what one slot per instance returns."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N, B = 20, 6000
+    be = backends(N)
+    batch = scenes.make_batch(B, N, [8192, 77], be.fk, randomize_sets=True)
+    full = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    pool = HipBoundMPC(N, pool_slots=2048)
+    r = pool.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    pool.close()
+    for k in ("x", "f", "iters", "status", "viol"):
+        assert np.array_equal(full[k], r[k]), k
+    assert (full["status"] == 0).mean() > 0.99 and full["iters"].max() > 60      # stragglers included
+
+
 def test_field_major_layout_is_bitwise_the_same(monkeypatch):
     """BMPC_LAYOUT=0 selects the field-major workspace of round 1 (kept for A/B measurements) when a handle is created; it
     only moves data: outputs are bitwise those of the slot-major default, also through a streaming pool."""
