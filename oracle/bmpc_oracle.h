@@ -39,6 +39,13 @@ typedef struct {
     int mu_strategy;  /* 0 LOQO adaptive, 1 monotone Fiacco-McCormick (default), 2 / 3 probing (Mehrotra) rule */
     double hess_switch; /* hess==2: use second-order terms once the KKT error is below this */
     double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule (IPOPT names) */
+    int inertia;      /* indefinite exact Hessian: 0 Gauss-Newton fallback (round 2), 1 delta_w inertia correction (IPOPT),
+                         2 (default) Gauss-Newton fallback while the previous error is above inertia_err and the error improved
+                         within the last stall_n iterations, delta_w otherwise */
+    double dw0;       /* first delta_w (IPOPT delta_w^0 = 1e-4) */
+    double inertia_err; /* 1e-2 */
+    int stall_n;      /* 8 */
+    double mu_floor_k; /* a barrier decrease stops at (scaled optimality error) / mu_floor_k; 0 = off (round 2); default 1e4 */
 } bmpc_oracle_opts;
 
 void bmpc_oracle_default_opts(bmpc_oracle_opts* o, int N);

@@ -68,6 +68,7 @@ typedef struct {
     double Jpose[NLOC][NZ];   /* d(local pose coords)/dy */
     double Jpt[6][4][NZ];     /* d(point, d_i)/dy */
     double costH[12 * 12], costg[12]; /* output-space cost model */
+    double costHx[6 * 6];             /* second-order part of the sigmoid-weighted error terms (pose block), hess mode only */
     double A[NX * NX], B[NX * NU], r[NX];
     double H[NZ * NZ], g[NZ], gdual[NZ];
     double P[NX * NX], pv[NX], K[NU * NX], kf[NU];
@@ -104,8 +105,9 @@ void bmpc_oracle_default_opts(bmpc_oracle_opts* o, int N) {
     o->verbose = 0;
     o->hess = 2;
     o->mu_strategy = 1;
-    o->hess_switch = 1e-1;
+    o->hess_switch = 1.0;
     o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
+    o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->mu_floor_k = 1e4;
 }
 
 /* ---------------------------------------------------------------- small dense helpers */
@@ -238,6 +240,23 @@ static void eval_stage(prob_t* pb, int k, int mode) {
     bmpc_pose_eval_fn(&sc, pose, v, pb->iw0, p[P_PHIMAX], &pe);
     double giw[3];
     double fv = bmpc_stage_cost_o(&sc, &pe, v, wts, p + P_XPHID, term, s->costg, giw, mode == 0 ? s->costH : NULL);
+    if (mode == 0) {
+        /* what the Gauss-Newton model of r = sig(phi) e leaves out of the Hessian of sig^2 (|e_r|^2 + |e_p|^2)
+         * (casadi_ocp_formulation.py:272-276): 2 sig [ sig'' |e|^2 dphi dphi^T + sig' (ge dphi^T + dphi ge^T) ],
+         * ge = De^T e; e is linear in the pose, phi = (p - p_ref) . dp */
+        double e2 = dot3(pe.er, pe.er) + dot3(pe.ep, pe.ep);
+        double d2sig = 60.0 * pe.dsig * (1.0 - 2.0 * pe.sig);
+        double ge[6], dph[6];
+        for (int b = 0; b < 6; b++) {
+            double sm = 0;
+            for (int a = 0; a < 3; a++) sm += pe.Der[a][b] * pe.er[a] + (b < 3 ? pe.Dep[a][b] * pe.ep[a] : 0.0);
+            ge[b] = sm;
+            dph[b] = b < 3 ? sc.dp[b] : 0.0;
+        }
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++)
+                s->costHx[6 * i + j] = 2 * pe.sig * (d2sig * e2 * dph[i] * dph[j] + pe.dsig * (ge[i] * dph[j] + dph[i] * ge[j]));
+    }
     for (int j = 2; j <= 4; j++) fv += wts[6] * y[Y_DQ + j] * y[Y_DQ + j];
     for (int j = 0; j < 7; j++) fv += wts[7] * y[Y_U + j] * y[Y_U + j];
     fv += wts[9] * y[Y_RS] * y[Y_RS] + wts[10] * y[Y_DRS] * y[Y_DRS] + wts[9] * y[Y_PS] * y[Y_PS] + wts[10] * y[Y_DPS] * y[Y_DPS];
@@ -472,6 +491,9 @@ static void assemble_stage(prob_t* pb, int k, double mu) {
         bzp[i] = s->costg[i];
         for (int j = 0; j < 12; j++) Mp[i * NLOC + j] = s->costH[i * 12 + j];
     }
+    if (pb->hess && !getenv("NO_A"))
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) Mp[i * NLOC + j] += s->costHx[6 * i + j];
     for (int i = 0; i < s->nrows; i++) {
         const row_t* r = &s->rows[i];
         double sg = pb->no_sigma ? 0.0 : s->z[i] / s->t[i];
@@ -1043,7 +1065,8 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
     int nfilt = 0;
     kkt_t kk;
     memset(&kk, 0, sizeof kk);
-    double reg = 1e-9, err_prev = 1e300;
+    double reg = 1e-9, err_prev = 1e300, dw_last = 0.0, err_best = 1e300;
+    int stall = 0;                   /* iterations since the optimality error last improved (by 10 %) */
     for (it = 0;; it++) {
         /* gdual needs current z: assemble with a provisional mu (only H,g depend on mu) */
         for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
@@ -1069,7 +1092,15 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
             double emu = fmax(fmax(kk.dual / kk.sd, kk.prim), kk.compl_mu / kk.sc);
             int changed = 0;
             while (emu <= o->kappa_eps * mu && mu > o->tol / 10.0) {
+                double mu_before = mu;
                 mu = fmax(o->tol / 10.0, fmin(o->kappa_mu * mu, pow(mu, o->theta_mu)));
+                /* not below the optimality error it was released at (scaled): a barrier parameter far below the error
+                 * jams the iterates against rows they have yet to identify as active */
+                if (o->mu_floor_k > 0) {
+                    double m2 = fmax(mu, fmin(emu / o->mu_floor_k, 0.1));
+                    if (m2 >= mu_before) { mu = mu_before; break; }
+                    mu = m2;
+                }
                 changed = 1;
                 emu = fmax(fmax(kk.dual / kk.sd, kk.prim), fmax(kk.compl - mu, 0) / kk.sc);
             }
@@ -1117,22 +1148,35 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
             }
             for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
         }
-        while (riccati_backward(&pb, reg) || riccati_forward(&pb)) {
-            if (o->hess == 2 && pb.hess == 1) {
-                pb.hess = 0;
+        /* inertia correction (Waechter & Biegler 2006, Algorithm IC): the Riccati recursion's control blocks are positive
+         * definite iff the Hessian is positive definite on the null space of the dynamics; when they are not, delta_w I is
+         * added to the Hessian and escalated (first trial max(dw_min, dw_last / 3) or dw_0 = 1e-4, then x 100 while there is
+         * no history, x 8 afterwards) */
+        {
+            double dw = 0.0;
+            pb.hreg = 0.0;
+            while (riccati_backward(&pb, reg) || riccati_forward(&pb)) {
+                /* far from a solution the Gauss-Newton model gives the better step (measured); close to one,
+                 * or when the error has not improved for stall_n iterations, the corrected exact Hessian */
+                int gn_fallback = o->inertia == 0 || (o->inertia == 2 && err_prev > o->inertia_err && stall < o->stall_n);
+                if (gn_fallback && o->hess == 2 && pb.hess == 1) {
+                    pb.hess = 0;
+                    for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
+                    tries++;
+                    continue;
+                }
+                if (dw == 0.0) dw = (dw_last == 0.0) ? o->dw0 : fmax(1e-20, dw_last / 3.0);
+                else dw *= (dw_last == 0.0) ? 100.0 : 8.0;
+                if (++tries > 14 || dw > 1e20) { st = 3; goto done; }
+                pb.hreg = dw;
                 for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
-                tries++;
-                continue;
             }
-            /* inertia correction (IPOPT delta_w): Levenberg term on every stage Hessian */
-            pb.hreg = (pb.hreg == 0.0) ? 1e-4 : pb.hreg * 8;
-            if (++tries > 12) { st = 3; goto done; }
-            for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
+            if (dw > 0.0) dw_last = dw;
         }
-        if (tries == 0) pb.hreg = (pb.hreg < 1e-8) ? 0.0 : pb.hreg / 3;
         /* row steps + fraction to boundary */
         double tau = fmax(0.99, 1 - mu), ap = 1, ad = 1, dphi_f = 0, dphi_bar = 0;
-        for (int k = 1; k < N; k++) {
+        int lim_k = -1, lim_i = -1;
+for (int k = 1; k < N; k++) {
             stage_t* s = &pb.st[k];
             double ad_[MAXROWS];
             row_dirs(&pb, s, ad_);
@@ -1140,12 +1184,10 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
                 double dti = -(s->h[i] + s->t[i]) - ad_[i];
                 double dzi = (mu - s->t[i] * s->z[i] - s->z[i] * dti) / s->t[i];
                 s->dt_[i] = dti; s->dz_[i] = dzi;
-                if (dti < 0) ap = fmin(ap, -tau * s->t[i] / dti);
+                if (dti < 0 && -tau * s->t[i] / dti < ap) { ap = -tau * s->t[i] / dti; lim_k = k; lim_i = i; }
                 if (dzi < 0) ad = fmin(ad, -tau * s->z[i] / dzi);
                 dphi_bar -= mu * dti / s->t[i];
             }
-            /* cost directional derivative: grad f . dzeta (gdual minus z-terms is awkward; use
-             * g with mu-terms removed: recompute from cost pieces) */
         }
         /* directional derivative of f along dzeta via gdual - sum z a  ==  use finite pieces:
          * grad_f . d = (gdual . d) - sum_i z_i (a_i . d) */
@@ -1218,6 +1260,21 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
             eval_stage(&pb, k, 0);
         }
         err_prev = kk.err;
+        if (kk.err < 0.9 * err_best) { err_best = kk.err; stall = 0; } else stall++;
+        if (o->verbose > 1 && lim_k > 0) {
+            const stage_t* s = &pb.st[lim_k]; const row_t* r = &s->rows[lim_i];
+            printf("      ftb row: stage %d kind %d gidx %d xidx %d t %.2e z %.2e dt %.2e h+t %.2e\n", lim_k, r->kind, r->gidx, r->xidx >= 0 ? r->xidx / N : -1, s->t[lim_i] - alpha * s->dt_[lim_i], s->z[lim_i], s->dt_[lim_i], 0.0);
+        }
+        if (o->verbose > 1) {
+            double mq = 0, mu_ = 0, mpi = 0, msl = 0;
+            for (int k = 1; k < N; k++) {
+                const stage_t* s = &pb.st[k];
+                for (int i = 0; i < 7; i++) { mq = fmax(mq, fabs(s->dzeta[Z_Q + i])); mu_ = fmax(mu_, fabs(s->dzeta[Z_U + i])); }
+                for (int i = 0; i < 3; i++) mpi = fmax(mpi, fabs(s->dzeta[Z_PI + i]));
+                msl = fmax(msl, fmax(fabs(s->dzeta[Z_RS]), fabs(s->dzeta[Z_PS])));
+            }
+            printf("      step: |dq| %.2e |du| %.2e |dpi| %.2e |dslack| %.2e\n", mq, mu_, mpi, msl);
+        }
         if (o->verbose > 1) printf("      alpha_p %.3g (ftb %.3g) alpha_d %.3g ls_ok %d nu %.2e D %.2e th %.2e hreg %.1e tries %d\n", alpha, ap, ad, ls_ok, nu, D, th0, pb.hreg, tries);
     }
 done:
