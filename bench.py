@@ -89,15 +89,12 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=HORIZON)
     ap.add_argument("--hess", type=int, default=None)
-    ap.add_argument("--wpi", type=int, default=None, help="wavefronts per instance (1, 2, 4)")
-    ap.add_argument("--bpc", type=int, default=None, help="resident workgroups per CU")
     ap.add_argument("--depth", type=int, default=None, help="solver calls in flight (the straggler tail of one overlaps the bulk of "
                     "the next); 1: one at a time.  Default 4 (with GPU_MAX_HW_QUEUES=8, set above)")
     ap.add_argument("--merge", type=int, default=2, help="--pool 0 only: batches handed to the solver per call (they are "
                     "independent: a larger launch amortises the straggler tail over more bulk work)")
     ap.add_argument("--gate", type=float, default=1.0, help="start the next solver call when the others have < gate * their instances "
                     "active (1.0: at once)")
-    ap.add_argument("--engine", type=int, default=None, help="0 pipeline (default), 1 persistent kernel")
     ap.add_argument("--pool", type=int, default=16384, help="bmpc_opts.pool_slots: workspace slots of a solver handle.  > 0 (default): "
                     "the timed batches are handed over in `depth` solver calls, each streaming its instances through the pool "
                     "(a slot whose instance has finished takes the next one: one straggler tail per call, hidden behind the "
@@ -149,12 +146,6 @@ def main():
     from boundplanner_amd.solver import HipBoundMPC
 
     kw = {} if args.hess is None else {"hess": args.hess}
-    if args.wpi is not None:
-        kw["waves_per_instance"] = args.wpi
-    if args.bpc is not None:
-        kw["blocks_per_cu"] = args.bpc
-    if args.engine is not None:
-        kw["engine"] = args.engine
     if args.pool > 0:
         kw["pool_slots"] = args.pool
     bes = [HipBoundMPC(N, device=local_rank, max_batch=min(M * B, args.pool) if args.pool > 0 else M * B, **kw) for _ in range(depth)]
@@ -275,7 +266,7 @@ def main():
                                "value_single_batch and value_pcie_inclusive are the SURVEY 8(d) one-batch figures",
                    "batch_per_gpu": B, "horizon": N, "distinct_batches": n_distinct,
                    "sharding": "contiguous shards, no data-path collective, RCCL all-gather of x" if world > 1 else "single GPU",
-                   "hess": int(be.opts.hess), "engine": int(be.opts.engine), "solver_handles_in_flight": depth,
+                   "hess": int(be.opts.hess), "solver_handles_in_flight": depth,
                    "batches_per_solver_call": M, "batches_in_flight": depth * M, "pool_slots": args.pool},
         "solver": {"iters_mean": mean_it, "iters_p50": float(np.median(it_np)), "iters_p99": float(np.percentile(it_np, 99)),
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),

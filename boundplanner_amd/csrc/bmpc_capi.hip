@@ -16,9 +16,6 @@
 
 using namespace bmpc;
 
-extern "C" hipError_t bmpc_launch_solve_nt64(const KernelArgs* A, int nblocks, hipStream_t st);
-extern "C" hipError_t bmpc_launch_solve_nt128(const KernelArgs* A, int nblocks, hipStream_t st);
-extern "C" hipError_t bmpc_launch_solve_nt256(const KernelArgs* A, int nblocks, hipStream_t st);
 extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
                                      double* ee_rot, double* col_pts, double* jac, double* dvdq, hipStream_t st);
 
@@ -38,11 +35,8 @@ struct bmpc_handle {
     int n_w, n_g, n_cu, nblocks_max;
     RobotConst* d_rc = nullptr;
     bmpc_robot robot;              // host copy of the robot table behind d_rc
-    double* d_ws = nullptr;
-    int* d_counter = nullptr;
     double* d_prof = nullptr;   // diagnostic builds only
-    size_t ws_blocks = 0;
-    // pipeline engine workspace (grown on demand to the largest batch seen)
+    // workspace (grown on demand to the largest batch seen)
     int pipe_cap = 0;
     // workspace layout (pipe_carve): slot-major; BMPC_LAYOUT=0 in the environment selects the field-major layout of round 1 (A/B runs)
     int slot_major = [] { const char* e = getenv("BMPC_LAYOUT"); return e ? atoi(e) : 1; }();
@@ -98,16 +92,16 @@ struct BusyGuard {
 
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
-    o->hess = 2; o->hess_switch = 0.1; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->max_batch = 0; o->blocks_per_cu = 0; o->waves_per_instance = 1; o->engine = 0; o->pool_slots = 0;
+    o->hess = 2; o->hess_switch = 1.0; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
+    o->mu_floor_k = 1e4; o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->gn_backoff = 2; o->slack_reset = 1;
+    o->max_batch = 0; o->pool_slots = 0;
 }
 
 extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     if (!o || !out) return 1;
     *out = nullptr;
     if (o->N < 3 || o->N > 64 || o->nr_segs != 4 || !(o->dt > 0)) return 1;
-    if (o->waves_per_instance != 1 && o->waves_per_instance != 2 && o->waves_per_instance != 4) return 1;
-    if (o->engine != 0 && o->engine != 1) return 1;
+    if (o->inertia < 0 || o->inertia > 2 || !(o->dw0 > 0) || o->mu_floor_k < 0) return 1;
     if (o->pool_slots < 0 || (o->pool_slots > 0 && o->pool_slots < 64)) return 1;
     bmpc_handle* h = new bmpc_handle();
     h->o = *o;
@@ -121,17 +115,12 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, o->device));
     h->n_cu = prop.multiProcessorCount;
-    int bpc = o->blocks_per_cu > 0 ? o->blocks_per_cu : 3;
-    h->nblocks_max = h->n_cu * bpc;
+    h->nblocks_max = h->n_cu * 3;      // rows of the diagnostic cycle counters
     RobotConst rc;
     robot_iiwa14(h->robot);
     fill_robot_const(rc, h->robot);
     HIPCHK(h, hipMalloc((void**)&h->d_rc, sizeof(RobotConst)));
     HIPCHK(h, hipMemcpy(h->d_rc, &rc, sizeof(RobotConst), hipMemcpyHostToDevice));
-    h->ws_blocks = (size_t)h->nblocks_max;
-    if (o->engine == 1)
-        HIPCHK(h, hipMalloc((void**)&h->d_ws, h->ws_blocks * (size_t)ws_doubles(o->N) * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_counter, sizeof(int)));
     HIPCHK(h, hipMalloc((void**)&h->d_prof, (size_t)h->nblocks_max * 16 * sizeof(double)));
     HIPCHK(h, hipMemset(h->d_prof, 0, (size_t)h->nblocks_max * 16 * sizeof(double)));
     {
@@ -144,7 +133,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
-    if (o->engine == 0 && o->max_batch > 0) return pipe_ensure(h, o->max_batch);   // workspace up front
+    if (o->max_batch > 0) return pipe_ensure(h, o->max_batch);   // workspace up front
     return 0;
 }
 
@@ -160,12 +149,11 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (h->n_loops.load() > 0) { h->destroy_pending = true; return; }     // deferred until the last loop is gone
     if (h->worker.joinable()) h->worker.join();
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    double* bufs[] = {h->d_x0, h->d_lbx, h->d_ubx, h->d_p, h->d_x, h->d_g, h->d_f, h->d_viol, h->d_ws};
+    double* bufs[] = {h->d_x0, h->d_lbx, h->d_ubx, h->d_p, h->d_x, h->d_g, h->d_f, h->d_viol};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_rc) (void)hipFree(h->d_rc);
-    if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_prof) (void)hipFree(h->d_prof);
     if (h->d_pipe) (void)hipFree(h->d_pipe);
     if (h->d_pipe_st) (void)hipFree(h->d_pipe_st);
@@ -197,6 +185,7 @@ extern "C" int bmpc_set_robot(bmpc_handle* h, const bmpc_robot* r) {
     if (!h || !r) return 1;
     int rc_ = bmpc_wait(h);
     if (rc_) return rc_;
+    BUSY_OR_FAIL(h, "bmpc_set_robot");
     for (int i = 0; i < 7; i++)
         if (!(r->q_lower[i] <= r->q_upper[i]) || !(r->dq_max[i] > 0) || !(r->col_joint_sizes[i] >= 0)) { h->err = "bmpc_set_robot: inconsistent limits"; return 1; }
     if (!(r->ddq_max > 0) || !(r->u_max > 0)) { h->err = "bmpc_set_robot: inconsistent limits"; return 1; }
@@ -238,7 +227,7 @@ extern "C" int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg) {
 }
 
 // ------------------------------------------------------------------------------------------
-// pipeline engine: workspace + launch sequence
+// workspace + launch sequence
 // ------------------------------------------------------------------------------------------
 // workspace for `B` slots; a handle created with pool_slots > 0 never holds more than that many (larger batches stream
 // through the pool, bmpc_opts.pool_slots)
@@ -269,7 +258,8 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     PipeArgsH A;
     A.B = B; A.N = N;
     A.o = SolverOpts{N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,
-                     h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps};
+                     h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps,
+                     h->o.mu_floor_k, h->o.dw0, h->o.inertia_err, h->o.inertia, h->o.stall_n, h->o.gn_backoff, h->o.slack_reset};
     A.rc = h->d_rc;
     A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
     A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
@@ -339,28 +329,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
 static int launch(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
                   const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
                   double* d_viol, hipStream_t st) {
-    if (h->o.engine == 0) return pipe_solve(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, st);
-    KernelArgs A;
-    A.B = B;
-    A.o = SolverOpts{h->o.N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,
-                     h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps};
-    A.rc = h->d_rc;
-    A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
-    A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
-    A.ws = h->d_ws;
-    A.counter = h->d_counter;
-    A.prof = h->d_prof;
-    int nblocks = B < h->nblocks_max ? B : h->nblocks_max;
-    if (nblocks < 1) return 0;
-    HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), st));
-    HIPCHK(h, hipEventRecord(h->ev0, st));
-    int wpi = h->o.waves_per_instance;
-    hipError_t le = (wpi == 4) ? bmpc_launch_solve_nt256(&A, nblocks, st)
-                  : (wpi == 2) ? bmpc_launch_solve_nt128(&A, nblocks, st) : bmpc_launch_solve_nt64(&A, nblocks, st);
-    HIPCHK(h, le);
-    HIPCHK(h, hipEventRecord(h->ev1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    return 0;
+    return pipe_solve(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, st);
 }
 
 extern "C" int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
@@ -384,7 +353,6 @@ extern "C" int bmpc_solve_dev_hooked(bmpc_handle* h, int B, const double* d_x0, 
                                      const double* d_p, double* d_x, double* d_f, int* d_iters, int* d_status, double* d_viol,
                                      void* stream, bmpc_retire_hook hook, void* hook_ctx, const int* d_cont) {
     if (!h || B <= 0 || !hook || !d_cont) return 1;
-    if (h->o.engine != 0) { h->err = "bmpc_loop_run_async needs the pipeline engine"; return 1; }
     int wrc = bmpc_wait(h);
     if (wrc) return wrc;
     BUSY_OR_FAIL(h, "bmpc_loop_run_async");
@@ -432,13 +400,12 @@ extern "C" int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, c
     return 0;
 }
 
-// Multipliers of the most recent solve on this handle (pipeline engine): its final iterate and row multipliers are still
+// Multipliers of the most recent solve on this handle: its final iterate and row multipliers are still
 // in the workspace.  d_lam_g [B][n_g], d_lam_x [B][n_w]: device pointers; enqueued on `stream` and waited for.
 extern "C" int bmpc_multipliers_dev(bmpc_handle* h, int B, double* d_lam_g, double* d_lam_x, void* stream) {
     if (!h || !d_lam_g || !d_lam_x) { if (h) h->err = "bmpc_multipliers_dev: null argument"; return 1; }
     int rc = bmpc_wait(h);
     if (rc) return rc;
-    if (h->o.engine != 0) { h->err = "bmpc_multipliers_dev: only the pipeline engine (engine 0) keeps the final iterate"; return 1; }
     if (!h->last_valid || h->last_args.B != B) { h->err = "bmpc_multipliers_dev: no finished solve of this batch size on the handle"; return 1; }
     HIPCHK(h, hipSetDevice(h->o.device));
     PipeArgsH A = h->last_args;
@@ -483,6 +450,12 @@ extern "C" int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double*
     int rc = bmpc_wait(h);         // an asynchronous solve in flight owns the workspace
     if (rc) return rc;
     BUSY_OR_FAIL(h, "bmpc_solve");
+    // multipliers need every instance's final iterate in its own workspace slot: refused up front (not after the solve) when the
+    // call would stream through a smaller pool
+    if ((lam_g || lam_x) && h->o.pool_slots > 0 && B > h->o.pool_slots) {
+        h->err = "bmpc_solve: lam_g / lam_x need B <= pool_slots (a streamed call keeps no final iterates)";
+        return 1;
+    }
     HIPCHK(h, hipSetDevice(h->o.device));
     rc = ensure_cap(h, B, g != nullptr);
     if (rc) return rc;

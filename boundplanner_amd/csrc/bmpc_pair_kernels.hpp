@@ -542,8 +542,10 @@ BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp
 
 // second-order kinematic terms of the Lagrangian Hessian for generalised forces Fp (on p_ee),
 // Fv (on v; WITHOUT the multiplier of the pi dynamics, which k_ric adds), Fc (on the 6 points)
+// sa, sbq, sbdq, sc1: the chained rank-2 curvature of the sigmoid-weighted error terms, c1 a a^T + b a^T + a b^T with
+// a on q only and b = (bq, bdq, bpi); its q x pi part is emitted by the caller
 BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double* dq, const double* Fp, const double* Fv,
-                             const double Fc[6][3], Emitter& E) {
+                             const double Fc[6][3], const double* sa, const double* sbq, const double* sbdq, double sc1, Emitter& E) {
     const int njc[6] = {2, 3, 4, 5, 6, 4};
     // q x q block: third derivatives of the kinematics contracted with forces and dq -- symmetric in (a, bq), so the upper
     // triangle is computed and both halves are emitted from it
@@ -585,7 +587,7 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
                 }
                 acc += dq[j] * (lin + ang);
             }
-            tri[sym7(a, bq)] = acc;
+            tri[sym7(a, bq)] = acc + (sc1 * sa[a] * sa[bq] + sbq[a] * sa[bq] + sa[a] * sbq[bq]);
         }
     BMPC_UNROLL
     for (int a = 0; a < 7; a++)
@@ -600,7 +602,7 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
             cross3r(K.zx[m], cM, zc);
             double acc = dot3(Fv, zc);
             if (i < j) { double zz[3]; cross3r(K.zx[i], K.zx[j], zz); acc += dot3(Fv + 3, zz); }
-            E.put(acc);
+            E.put(acc + sa[i] * sbdq[j]);
         }
 }
 
@@ -713,6 +715,19 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         for (int a = 0; a < 3; a++) F[(size_t)a * A.NP] = PO.bpz[a];
         BMPC_UNROLL
         for (int a = 0; a < 6; a++) F[(size_t)(3 + a) * A.NP] = g12[6 + a] + (a >= 3 ? hdt * PO.bpz[a] : 0.0);
+        // what the Gauss-Newton model of r = sig(phi) e leaves out of the Hessian of sig^2 (|e_r|^2 + |e_p|^2)
+        // (casadi_ocp_formulation.py:272-276): 2 sig [ sig'' |e|^2 dphi dphi^T + sig' (ge dphi^T + dphi ge^T) ], ge = De^T e
+        GD Sg = A.part + (size_t)PT_SIG * A.NP + m.pi;
+        const double c2 = 2 * S.C.sig * S.C.dsig;
+        Sg[0] = 2 * S.C.sig * (60.0 * S.C.dsig * (1.0 - 2.0 * S.C.sig)) * S.C.er2ep2;
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) Sg[(size_t)(1 + a) * A.NP] = S.C.dpp[a];
+        BMPC_UNROLL
+        for (int bb = 0; bb < 6; bb++) {
+            double ge = S.C.Der[0][bb] * S.C.er[0] + S.C.Der[1][bb] * S.C.er[1] + S.C.Der[2][bb] * S.C.er[2];
+            if (bb < 3) ge += S.C.Dep[0][bb] * S.C.ep[0] + S.C.Dep[1][bb] * S.C.ep[1] + S.C.Dep[2][bb] * S.C.ep[2];
+            Sg[(size_t)(4 + bb) * A.NP] = c2 * ge;
+        }
     }
     // ---- slack-column couplings + gradients + diagonal rows of the 17 chained positions ----
     {
@@ -892,7 +907,7 @@ BMPC_KBODY void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     PairMap m = pair_map(A, A.L.curv, count, wave, lane);
     const DynC dc = make_dync(A.o.dt);
     Emitter E;
-    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid, F_CQQ);
+    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid, F_CQP);
     BMPC_SYNC();
     double zeta[NZ], y[NZ];
     load_zeta(cur_zeta(A, A.st[m.b].flip), A.NP, m.pi, zeta);
@@ -911,7 +926,32 @@ BMPC_KBODY void k_curv_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     for (int c = 0; c < 6; c++)
         BMPC_UNROLL
         for (int a = 0; a < 3; a++) Fc[c][a] = F[(size_t)(9 + 3 * c + a) * A.NP];
-    curvature_emit(K, Jl, y + Z_DQ, Fp, Fv, Fc, E);
+    // exact curvature of the sigmoid-weighted error terms (scalars from k_eval), chained through d(pose)/d(q, dq, pi)
+    double sa[7], sbq[7], sbdq[7], sc1;
+    {
+        GCD Sg = A.part + (size_t)PT_SIG * A.NP + m.pi;
+        double dpp[3], gec[6];
+        sc1 = Sg[0];
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) dpp[a] = Sg[(size_t)(1 + a) * A.NP];
+        BMPC_UNROLL
+        for (int a = 0; a < 6; a++) gec[a] = Sg[(size_t)(4 + a) * A.NP];
+        double G[6][7];
+        kin_G(K, Jl, y + Z_DQ, G);
+        const double hdt = 0.5 * dc.dt;
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) {
+            sa[j] = dpp[0] * Jl[0][j] + dpp[1] * Jl[1][j] + dpp[2] * Jl[2][j];
+            sbq[j] = gec[0] * Jl[0][j] + gec[1] * Jl[1][j] + gec[2] * Jl[2][j]
+                     + hdt * (gec[3] * G[3][j] + gec[4] * G[4][j] + gec[5] * G[5][j]);
+            sbdq[j] = hdt * (gec[3] * K.zx[j][0] + gec[4] * K.zx[j][1] + gec[5] * K.zx[j][2]);
+        }
+        BMPC_UNROLL
+        for (int i = 0; i < 7; i++)
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) E.put(sa[i] * gec[3 + a]);
+    }
+    curvature_emit(K, Jl, y + Z_DQ, Fp, Fv, Fc, sa, sbq, sbdq, sc1, E);
     E.pad_to(HREC);
 }
 
@@ -968,7 +1008,10 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
         st->f0 = f1; st->th0 = th1; st->ls0 = ls1;      // merit pieces of the accepted point
         st->flip ^= 1;                                   // the trial copy of t / zeta is the iterate now (cur_t, cur_zeta)
         st->it += 1;
-        st->hess_mode = (A.o.hess == 2 && st->err_prev < A.o.hess_switch) ? 1 : 0;
+        // the exact Hessian close to a solution, or when the Gauss-Newton model has stopped making progress
+        int want = (A.o.hess == 2 && (st->err_prev < A.o.hess_switch || (A.o.inertia == 2 && st->stall >= A.o.stall_n))) ? 1 : 0;
+        if (A.o.gn_backoff > 0 && want && st->gn_skip > 0) { want = 0; st->gn_skip -= 1; }
+        st->hess_mode = want;
         st->state = ST_EVAL;
         int pos = BMPC_ATOMIC_INC(A.L.cnt + 3);
         A.L.eval_next[pos] = b;
@@ -1134,9 +1177,10 @@ struct TrialVisitor {
         for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gc[i] = A->dt[o]; }
     }
     BMPC_INL void fin(int s, double h) {
-        // trial slack t + alpha dt, its share of theta and of the barrier term; kept for the accept pass
+        // trial slack t + alpha dt (reset to -h where that is larger), its share of theta and of the barrier term; kept for the accept pass
         const double t = gt[s - row_group_base(s)];
-        const double tn = t + alpha * (gc[s - row_group_base(s)] - t);
+        double tn = t + alpha * (gc[s - row_group_base(s)] - t);
+        if (A->o.slack_reset) tn = fmax(tn, -h);      // slack reset: never below what closes the row at the trial point
         thr += fabs(h + tn);
         int e;
         lp = frexp(lp * tn, &e); le += e;

@@ -2,6 +2,7 @@
 // Device code: bmpc_stage.hpp / bmpc_pair_kernels.hpp / bmpc_ric_kernel.hpp.  Host sequencing:
 // bmpc_capi.hip (pipe_solve).
 #include "bmpc_platform_hip.hpp"
+#include <cstdlib>
 
 #define BMPC_NT 64
 #include "bmpc_pair_kernels.hpp"
@@ -113,7 +114,9 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
-    if (n_act < BMPC_RIC_LAT_BELOW) LAUNCH(bmpc_k_ric_lat, n_act, BMPC_RIC_NT);
+    // BMPC_RIC_LAT_BELOW in the environment (read once): A/B runs and the test that the two variants agree bitwise
+    static const int lat_below = [] { const char* e = getenv("BMPC_RIC_LAT_BELOW"); return e ? atoi(e) : BMPC_RIC_LAT_BELOW; }();
+    if (n_act < lat_below) LAUNCH(bmpc_k_ric_lat, n_act, BMPC_RIC_NT);
     else LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));

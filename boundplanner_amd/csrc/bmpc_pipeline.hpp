@@ -30,11 +30,12 @@ constexpr int F_EW = F_GZ2 + 6;         // G_ang[3][7], J_ang[3][7]
 constexpr int F_SUFZ = F_EW + 42;       // sufz[1..7][3] = sum_{j>=m} z_j dq_j
 constexpr int F_RDEF = F_SUFZ + 21;     // dynamics defect (32)
 constexpr int F_MAIN_END = F_RDEF + 32; // 506: written by k_eval (padded to 512)
-constexpr int F_CQQ = 528;              // written by k_curv: [a][b] second-order kinematic terms, q x q
+constexpr int F_CQP = 512;              // written by k_curv: [i][a] q_i x pi_a block of the sigmoid-weighted error terms' curvature
+constexpr int F_CQQ = F_CQP + 21;       // [a][b] second-order terms, q x q
 constexpr int F_CQD = F_CQQ + 49;       // [i][j] q_i x dq_j
 constexpr int F_END = F_CQD + 49;
 constexpr int HREC = 640;               // multiple of 64: k_ric reads it with 10 unconditional loads per lane
-static_assert(F_MAIN_END <= 512 && F_CQQ % 16 == 0 && F_END <= HREC && HREC % 64 == 0, "record layout");
+static_assert(F_MAIN_END <= F_CQP && F_CQP % 16 == 0 && F_END <= HREC && HREC % 64 == 0, "record layout");
 
 // DG order: q, dq, ddq, u, rs, drs, ps, dps, d, pi
 BMPC_HD int dg_pos(int i) {
@@ -56,12 +57,13 @@ constexpr int dg_pos_c(int i) {
 BMPC_HD int pos17(int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); }
 
 constexpr int KREC = 320;               // gains per pair: K (9x32) + kf (2x16)
-constexpr int NPART = 176;              // per-pair partial sums (16) + forces for k_curv (27) + point-group results (121)
+constexpr int NPART = 184;              // per-pair partial sums (16) + forces for k_curv (27) + point-group results (121) + PT_SIG (10)
 constexpr int PT_FORCE = 16;            // Fp[3], Fv[6], Fc[6][3]
+constexpr int PT_SIG = 169;             // k_eval -> k_curv: c1 = 2 sig sig'' |e|^2, dpp[3], 2 sig sig' De^T e [6] (exact curvature of sig^2 |e|^2)
 // results of the collision-point rows (k_points), read by k_eval where it needs them
 constexpr int PT_SIDE = 48, SD_CD = 0 /*[5][7]*/, SD_CD5 = 35 /*7*/, SD_HQQ = 42 /*28*/, SD_GQ = 70 /*[3][7]*/,
               SD_DD = 91 /*6*/, SD_GD = 97 /*[3][6]*/, SD_KKT = 115 /*cmax csum cmin zsum prim nrows*/, SD_END = 121;
-static_assert(PT_SIDE + SD_END <= NPART, "partials layout");
+static_assert(PT_SIDE + SD_END <= PT_SIG && PT_SIG + 10 <= NPART, "partials layout");
 enum { PT_CMAX = 0, PT_CSUM, PT_CMIN, PT_ZSUM, PT_PRIM, PT_THETA, PT_LOGS, PT_NROWS, PT_FVAL,
        PT_AP, PT_AD, PT_DBAR, PT_DPHIF, PT_F1, PT_TH1, PT_LS1 };
 
@@ -75,8 +77,10 @@ enum { ST_EVAL = 0, ST_STEP = 1, ST_TRIAL = 2, ST_DONE = 3 };
 // per-instance solver state (AoS, one per instance)
 struct InstState {
     int state, it, status, nfilt, hess_mode, bt, armijo, tries;
-    int flip, pad_;              // which copy of the double-buffered arrays (t / t_t, zeta / zeta_t) holds the iterate (cur_* below)
+    int flip, stall;             // stall: iterations since the KKT error last improved by 10 %; flip: which copy of the double-buffered arrays (t / t_t, zeta / zeta_t) holds the iterate (cur_* below)
     double mu, alpha, ad, ap, hreg, err_prev, filt_mu, theta_max, theta_min;
+    int gn_skip, gn_back;        // iterations for which the exact Hessian is not tried (after a Gauss-Newton fallback) / current back-off
+    double dw_last, err_best;    // last successful inertia correction delta_w (0 = none yet); best KKT error so far
     double f0, th0, ls0, D, phi0, fk;
     double filt_th[8], filt_phi[8];
 };

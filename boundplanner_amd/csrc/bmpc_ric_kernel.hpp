@@ -74,6 +74,8 @@ inline void build_scatter_table(int* tbl /* 3*HREC */) {
             set(F_CQQ + a * 7 + b, 3, Wo(Z_Q + a, Z_Q + b), -1);
             set(F_CQD + a * 7 + b, 3, Wo(Z_Q + a, Z_DQ + b), Wo(Z_DQ + b, Z_Q + a));
         }
+    for (int i = 0; i < 7; i++)
+        for (int a = 0; a < 3; a++) set(F_CQP + 3 * i + a, 3, Wo(Z_Q + i, Z_PI + a), Wo(Z_PI + a, Z_Q + i));
     for (int i = 0; i < 8; i++) set(F_DZ2 + i, 1, R_dz2 + i, -1);
     for (int i = 0; i < 42; i++) set(F_EW + i, 1, R_ew + i, -1);
     for (int i = 0; i < 21; i++) set(F_SUFZ + i, 1, R_sufz + i, -1);
@@ -621,7 +623,7 @@ template <int NT> BMPC_NOINL bool ric_phase_factor(const PipeArgsH& A, LDSD* lds
 // per stage: nothing is recomputed at the phase boundaries) for the straggler tail, where latency is all that counts.
 // Same arithmetic either way.
 template <int NT, bool SPLIT>
-BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int hess_mode) {
+BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int hess_mode, int may_abort) {
     // no floating-point arguments: an odd-aligned 64-bit argument pair that gets spilled trips a
     // register-alignment bug of this compiler; scalars travel through LDS (R_park)
     const double reg = 1e-9;      // fixed regularisation of the control block
@@ -674,6 +676,9 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
             if (!term) ric_phase_couple_impl<NT>(A, lds, lane);
             if (!ric_phase_factor_impl<NT>(A, lds, b, lane, k)) ok = false;
         }
+        // a retry pass (the KKT quantities of the iterate are known from the first one) stops at the first control block that
+        // is not positive definite; the verdict is uniform (read from LDS behind a barrier)
+        if (may_abort && !ok) break;
     }
     // |lambda| sum (lanes < 32 contribute) and dual-residual maximum (lanes < 41), in lane order
     BMPC_SYNC();
@@ -873,16 +878,20 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
 #ifdef BMPC_PROFILE
     if (lane < 16) RL(R_misc)[32 + lane] = 0.0;
 #endif
-    // uniform scalars that must survive the (non-inlined) sweeps: integers in scalar registers, mu and hreg in LDS
-    // (R_park[11], [12]) -- every vector register kept across the calls adds to the kernel's count
-    int hess_mode = BMPC_UNIFORM(st->hess_mode), tries = 0;
+    // uniform scalars that must survive the (non-inlined) sweeps: integers in scalar registers, mu, delta_w and the last
+    // successful delta_w in LDS (R_park[11], [12], [14]) -- every vector register kept across the calls adds to the kernel's count
+    int hess_mode = BMPC_UNIFORM(st->hess_mode), tries = 0, gn_fell = 0;
+    const int hess_mode_in = hess_mode;
     const int it = BMPC_UNIFORM(st->it);
-    if (lane == 0) { RL(R_park)[12] = st->hreg; RL(R_park)[11] = st->mu; }
+    // not positive definite with the exact Hessian: Gauss-Newton fallback while far from a solution and still improving,
+    // inertia correction otherwise (oracle/bmpc_solve.c, "inertia"); err_prev is still the previous iterate's error here
+    const int gn_ok = BMPC_UNIFORM((o.inertia == 0 || (o.inertia == 2 && st->err_prev > o.inertia_err && st->stall < o.stall_n)) ? 1 : 0);
+    if (lane == 0) { RL(R_park)[12] = 0.0; RL(R_park)[11] = st->mu; RL(R_park)[14] = st->dw_last; }
     bool first = true;
     int status = -1;
     for (;;) {
         BMPC_SYNC();
-        bool ok = ric_backward<NT, SPLIT>(A, lds, b, lane, hess_mode);
+        bool ok = ric_backward<NT, SPLIT>(A, lds, b, lane, hess_mode, first ? 0 : 1);
         const double lamsum = RL(R_park)[9], dual = RL(R_park)[10];
         double mu = RL(R_park)[11];
         if (first) {
@@ -893,13 +902,25 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
             double sd = fmax(100.0, (lamsum + zsum) / ((double)neq + nrows)) / 100.0;
             double sc = fmax(100.0, zsum / nrows) / 100.0;
             double err = fmax(fmax(dual / sd, prim), cmax / sc);
+#ifdef BMPC_EMU_TRACE
+            if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d] it %3d err %.6e (d %.6e p %.6e c %.6e) mu %.2e hess_mode %d gn_ok %d stall %d\n", A.src[b], it, err, dual, prim, cmax, mu, hess_mode, gn_ok, st->stall);
+#endif
             if (err <= o.tol && dual <= 1.0 && prim <= 1e-4 && cmax <= 1e-4) { status = 0; break; }
             if (it >= o.max_iter) { status = 1; break; }
-            if (lane == 0) st->err_prev = err;
-            // monotone Fiacco-McCormick barrier update
+            if (lane == 0) {
+                st->err_prev = err;
+                if (err < 0.9 * st->err_best) { st->err_best = err; st->stall = 0; } else st->stall += 1;
+            }
+            // monotone Fiacco-McCormick barrier update; a decrease stops at (scaled error) / mu_floor_k
             double emu = fmax(fmax(dual / sd, prim), fmax(fabs(cmax - mu), fabs(cmin - mu)) / sc);
             while (emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+                const double mu_before = mu;
                 mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                if (o.mu_floor_k > 0) {
+                    const double m2 = fmax(mu, fmin(emu / o.mu_floor_k, 0.1));
+                    if (m2 >= mu_before) { mu = mu_before; break; }
+                    mu = m2;
+                }
                 emu = fmax(fmax(dual / sd, prim), fmax(cmax - mu, 0.0) / sc);
             }
         }
@@ -908,17 +929,28 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
         BMPC_SYNC();
         { RPROF_START(); if (ok) ok = ric_forward<NT, SPLIT>(A, lds, b, lane); RPROF(6); }
         if (ok) break;
-        if (hess_mode) { hess_mode = 0; ++tries; }       // second-order terms not convex here: Gauss-Newton
+        if (hess_mode && gn_ok) {                        // second-order terms not convex here: Gauss-Newton
+            hess_mode = 0; ++tries; gn_fell = 1;
+#ifdef BMPC_EMU_TRACE
+            if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d]      GN fallback\n", A.src[b]);
+#endif
+        }
         else {
-            double hreg = RL(R_park)[12];
-            hreg = (hreg == 0.0) ? 1e-4 : hreg * 8;      // inertia correction (IPOPT delta_w)
+            // inertia correction (Waechter & Biegler 2006, Algorithm IC): delta_w I on the Hessian, natural coordinates
+            double dw = RL(R_park)[12];
+            const double dwl = RL(R_park)[14];
+            if (dw == 0.0) dw = (dwl == 0.0) ? o.dw0 : fmax(1e-20, dwl / 3.0);
+            else dw *= (dwl == 0.0) ? 100.0 : 8.0;
             BMPC_SYNC();
-            if (lane == 0) RL(R_park)[12] = hreg;
-            if (++tries > 12) { status = 3; break; }
+            if (lane == 0) RL(R_park)[12] = dw;
+#ifdef BMPC_EMU_TRACE
+            if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d]      dw %.3e tries %d\n", A.src[b], dw, tries + 1);
+#endif
+            if (++tries > 14 || dw > 1e20) { status = 3; break; }
         }
     }
     BMPC_SYNC();
-    double hreg = RL(R_park)[12];
+    const double dw = RL(R_park)[12];
     const double mu = RL(R_park)[11];
 #ifdef BMPC_PROFILE
     BMPC_SYNC();
@@ -931,8 +963,13 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
             int pos = BMPC_ATOMIC_INC(A.L.cnt + 8);      // to be retired (outputs written, slot refilled)
             A.L.done[pos] = b;
         } else {
-            if (tries == 0) hreg = (hreg < 1e-8) ? 0.0 : hreg / 3;
-            st->hreg = hreg; st->mu = mu; st->tries = tries; st->state = ST_STEP;
+            if (dw > 0.0) st->dw_last = dw;
+            // after a Gauss-Newton fallback the exact Hessian is tried again after 1, 2, ... gn_backoff iterations (k_accept)
+            if (gn_fell && o.gn_backoff > 0) {
+                const int gb = st->gn_back ? (2 * st->gn_back < o.gn_backoff ? 2 * st->gn_back : o.gn_backoff) : 1;
+                st->gn_back = gb; st->gn_skip = gb;
+            } else if (tries == 0 && hess_mode_in) st->gn_back = 0;
+            st->hreg = dw; st->mu = mu; st->tries = tries; st->state = ST_STEP;
             int pos = BMPC_ATOMIC_INC(A.L.cnt + 1);
             A.L.step[pos] = b;
         }
@@ -945,7 +982,7 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
 BMPC_INL void inst_reset(const PipeArgs& A, int slot) {
     GST st = A.st + slot;
     st->state = ST_EVAL; st->it = 0; st->status = 1; st->nfilt = 0; st->hess_mode = 0; st->bt = 0; st->armijo = 0; st->tries = 0;
-    st->flip = 0; st->pad_ = 0;
+    st->flip = 0; st->stall = 0; st->dw_last = 0; st->err_best = 1e300; st->gn_skip = 0; st->gn_back = 0;
     st->mu = A.o.mu_init; st->alpha = 0; st->ad = 0; st->ap = 0; st->hreg = 0; st->err_prev = 1e300; st->filt_mu = -1;
     st->theta_max = 1e300; st->theta_min = 0; st->fk = 0;
 }

@@ -21,8 +21,9 @@ class BmpcOpts(ctypes.Structure):
                 ("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("device", ctypes.c_int),
                 ("hess", ctypes.c_int), ("hess_switch", ctypes.c_double), ("mu_init", ctypes.c_double),
                 ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
-                ("max_batch", ctypes.c_int), ("blocks_per_cu", ctypes.c_int), ("waves_per_instance", ctypes.c_int),
-                ("engine", ctypes.c_int), ("pool_slots", ctypes.c_int)]
+                ("mu_floor_k", ctypes.c_double), ("inertia", ctypes.c_int), ("dw0", ctypes.c_double),
+                ("inertia_err", ctypes.c_double), ("stall_n", ctypes.c_int), ("slack_reset", ctypes.c_int), ("gn_backoff", ctypes.c_int),
+                ("max_batch", ctypes.c_int), ("pool_slots", ctypes.c_int)]
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
@@ -226,7 +227,7 @@ class HipNlpSolver:
     def __call__(self, x0, lbx, ubx, p, lbg=None, ubg=None, **_):
         inf2big = lambda a: np.nan_to_num(np.asarray(a, float), posinf=1e20, neginf=-1e20)
         r = self.backend.solve_batch(np.asarray(x0, float)[None], inf2big(lbx)[None], inf2big(ubx)[None],
-                                     np.asarray(p, float)[None], want_g=True, want_lam=self.backend.opts.engine == 0)
+                                     np.asarray(p, float)[None], want_g=True, want_lam=True)
         st = int(r["status"][0])
         self._stats = {"iter_count": int(r["iters"][0]), "success": st == 0,
                        "return_status": ["Solve_Succeeded", "Maximum_Iterations_Exceeded",
@@ -234,7 +235,7 @@ class HipNlpSolver:
                        "g_viol": float(r["viol"][0]), "t_kernel_ms": self.backend.last_kernel_ms()}
         n_w, n_g = self.backend.n_w, self.backend.n_g
         return {"x": _DM(r["x"][0]), "g": _DM(r["g"][0]), "f": _DM(r["f"][0]),
-                "lam_g": _DM(r["lam_g"][0] if r["lam_g"] is not None else np.zeros(n_g)),      # (engine 1 keeps no multipliers)
+                "lam_g": _DM(r["lam_g"][0] if r["lam_g"] is not None else np.zeros(n_g)),
                 "lam_x": _DM(r["lam_x"][0] if r["lam_x"] is not None else np.zeros(n_w))}
 
     def stats(self):

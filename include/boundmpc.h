@@ -35,14 +35,23 @@ typedef struct {
     int max_iter;       /* IPOPT "max_iter": 100 (BoundMPC.py:204) */
     int device;         /* HIP device ordinal */
     int hess;           /* 0 Gauss-Newton Hessian, 2 hybrid (second-order kinematic terms) */
-    double hess_switch; /* hess==2: KKT error below which second-order terms are used */
+    double hess_switch; /* hess==2: the exact Lagrangian Hessian (second-order kinematic and sigmoid terms) is tried once the KKT
+                           error of the previous iterate is below this (default 1.0) */
     double mu_init, kappa_mu, theta_mu, kappa_eps; /* monotone barrier schedule */
+    double mu_floor_k;  /* a barrier decrease stops at (scaled KKT error) / mu_floor_k (default 1e4; 0 = no floor) */
+    int inertia;        /* exact Hessian not positive definite on the null space of the dynamics: 0 Gauss-Newton fallback,
+                           1 IPOPT's inertia correction (delta_w I added, escalated), 2 (default) Gauss-Newton fallback while
+                           the previous KKT error is above inertia_err and the error improved within the last stall_n
+                           iterations, inertia correction otherwise */
+    double dw0;         /* first delta_w (IPOPT delta_w^0 = 1e-4) */
+    double inertia_err; /* 1e-2 */
+    int stall_n;        /* 8 */
+    int slack_reset;    /* 1 (default): a trial slack is never below the value that closes its row at the trial point,
+                           t <- max(t + alpha dt, -h(trial)) (Byrd-Hribar-Nocedal slack reset); 0: off */
+    int gn_backoff;     /* 2: after a Gauss-Newton fallback the exact Hessian is tried again after 1, then 2 iterations
+                           (a failed attempt costs a Riccati sweep); 0: every iteration */
     int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
-    int blocks_per_cu;  /* resident workgroups per CU (0 = default 3) */
-    int waves_per_instance; /* engine 1 only: 1, 2 or 4 wavefronts sharing one LDS image */
-    int engine;         /* 0 (default) batch-synchronous pipeline: thread-per-(instance,stage) evaluation kernels +
-                           wavefront-per-instance LDS Riccati kernel; 1 persistent one-wavefront-per-instance kernel */
-    int pool_slots;     /* engine 0: 0 (default) = every instance of a call has its own workspace slot; > 0 = the workspace
+    int pool_slots;     /* 0 (default) = every instance of a call has its own workspace slot; > 0 = the workspace
                            holds this many instances and a call with more of them STREAMS them through it: a slot whose
                            instance has finished takes the next one, so a long call keeps the GPU on ~pool_slots instances
                            and pays a single straggler tail.  Results do not depend on it (bitwise). */
@@ -92,7 +101,9 @@ int bmpc_gbounds(const bmpc_handle* h, double* lbg, double* ubg);
  * x0/lbx/ubx/x: [B][n_w]; p: [B][875]; g: [B][n_g] or NULL; lam_g: [B][n_g] or NULL; lam_x: [B][n_w] or
  * NULL -- sol["lam_g"], sol["lam_x"] (BoundMPC.py:638-645) in CasADi's convention: grad f + J_g^T lam_g + lam_x = 0,
  * positive at an active upper bound, negative at an active lower bound; the entries of the variables that are fixed
- * by lbx == ubx follow from stationarity (IPOPT fixed_variable_treatment=make_parameter).  Engine 0 only.
+ * by lbx == ubx follow from stationarity (IPOPT fixed_variable_treatment=make_parameter).  On a handle created with
+ * pool_slots > 0 the multipliers need B <= pool_slots (a streamed call keeps no final iterates): otherwise the call is refused
+ * up front with return code 1.
  * f/viol: [B]; iters/status: [B].
  * status: 0 converged, 1 max_iter, 2 stalled, 3 numerical.  viol = sum of constraint
  * violations exactly as BoundMPC.py:613-615, so the caller reproduces
@@ -104,7 +115,7 @@ int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double* lbx, const
 
 /* Same with DEVICE pointers; all work is enqueued on `stream` (a hipStream_t).  The call returns
  * when the batch is solved: the interior-point iteration count is data dependent, so the host
- * polls the number of unfinished instances between bursts of launches (engine 0).  On return `stream`
+ * polls the number of unfinished instances between bursts of launches.  On return `stream`
  * has been synchronised: the outputs are complete and the handle's workspace is free for the next call
  * (on any stream).  A solve started with bmpc_solve_dev_async is waited for first. */
 int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx,
@@ -112,7 +123,7 @@ int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const double* d_lb
                    int* d_iters, int* d_status, double* d_viol, void* stream);
 
 /* Multipliers lam_g [B][n_g], lam_x [B][n_w] (device pointers) of the most recent finished solve on this handle (any
- * entry point, pipeline engine): the final iterate stays in the handle's workspace until the next solve.  Enqueued on
+ * entry point): the final iterate stays in the handle's workspace until the next solve.  Enqueued on
  * `stream` and waited for. */
 int bmpc_multipliers_dev(bmpc_handle* h, int B, double* d_lam_g, double* d_lam_x, void* stream);
 

@@ -45,6 +45,8 @@ typedef struct {
     double dw0;       /* first delta_w (IPOPT delta_w^0 = 1e-4) */
     double inertia_err; /* 1e-2 */
     int stall_n;      /* 8 */
+    int gn_backoff;   /* 2: after a Gauss-Newton fallback the exact Hessian is tried again after 1, then 2 iterations (0: every iteration) */
+    int slack_reset;  /* 1: trial slacks t <- max(t + alpha dt, -h(trial point)) (0: round 2) */
     double mu_floor_k; /* a barrier decrease stops at (scaled optimality error) / mu_floor_k; 0 = off (round 2); default 1e4 */
 } bmpc_oracle_opts;
 

@@ -32,6 +32,7 @@
 #include "bmpc_internal.h"
 
 static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+long bmpc_dbg_iters = 0, bmpc_dbg_sweeps = 0, bmpc_dbg_retry_iters = 0;   /* diagnostics (not thread-exact) */
 
 #define NX 32
 #define NU 9
@@ -107,7 +108,7 @@ void bmpc_oracle_default_opts(bmpc_oracle_opts* o, int N) {
     o->mu_strategy = 1;
     o->hess_switch = 1.0;
     o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->mu_floor_k = 1e4;
+    o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->mu_floor_k = 1e4; o->gn_backoff = 2; o->slack_reset = 1;
 }
 
 /* ---------------------------------------------------------------- small dense helpers */
@@ -491,7 +492,7 @@ static void assemble_stage(prob_t* pb, int k, double mu) {
         bzp[i] = s->costg[i];
         for (int j = 0; j < 12; j++) Mp[i * NLOC + j] = s->costH[i * 12 + j];
     }
-    if (pb->hess && !getenv("NO_A"))
+    if (pb->hess)
         for (int i = 0; i < 6; i++)
             for (int j = 0; j < 6; j++) Mp[i * NLOC + j] += s->costHx[6 * i + j];
     for (int i = 0; i < s->nrows; i++) {
@@ -1066,6 +1067,7 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
     kkt_t kk;
     memset(&kk, 0, sizeof kk);
     double reg = 1e-9, err_prev = 1e300, dw_last = 0.0, err_best = 1e300;
+    int gn_skip = 0, gn_back = 0;
     int stall = 0;                   /* iterations since the optimality error last improved (by 10 %) */
     for (it = 0;; it++) {
         /* gdual needs current z: assemble with a provisional mu (only H,g depend on mu) */
@@ -1111,7 +1113,11 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
         if (o->hess == 2) {
             /* hybrid: Gauss-Newton far from the solution, second-order kinematic terms once the
              * optimality error is small; fall back to Gauss-Newton when that is not convex */
-            int want = (err_prev < o->hess_switch);   /* error of the PREVIOUS iterate (fused-sweep friendly) */
+            /* the exact Hessian close to a solution, or when the Gauss-Newton model has stopped making progress */
+            int want = (err_prev < o->hess_switch) || (o->inertia == 2 && stall >= o->stall_n);   /* (error of the PREVIOUS iterate: fused-sweep friendly) */
+            /* after a Gauss-Newton fallback the exact Hessian is not tried again for 1, 2, ... gn_backoff iterations (a
+             * failed attempt costs a backward sweep); an exact step that goes through resets the back-off */
+            if (o->gn_backoff > 0 && want && gn_skip > 0) { want = 0; gn_skip--; }
             if (want != pb.hess) {
                 pb.hess = want;
                 for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
@@ -1153,8 +1159,7 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
          * added to the Hessian and escalated (first trial max(dw_min, dw_last / 3) or dw_0 = 1e-4, then x 100 while there is
          * no history, x 8 afterwards) */
         {
-            double dw = 0.0;
-            pb.hreg = 0.0;
+            double dw = 0.0;                 /* (pb.hreg is 0 here: reset at the end of every iteration) */
             while (riccati_backward(&pb, reg) || riccati_forward(&pb)) {
                 /* far from a solution the Gauss-Newton model gives the better step (measured); close to one,
                  * or when the error has not improved for stall_n iterations, the corrected exact Hessian */
@@ -1163,6 +1168,7 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
                     pb.hess = 0;
                     for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
                     tries++;
+                    if (o->gn_backoff > 0) { gn_back = gn_back ? (2 * gn_back < o->gn_backoff ? 2 * gn_back : o->gn_backoff) : 1; gn_skip = gn_back; }
                     continue;
                 }
                 if (dw == 0.0) dw = (dw_last == 0.0) ? o->dw0 : fmax(1e-20, dw_last / 3.0);
@@ -1172,6 +1178,8 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
                 for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
             }
             if (dw > 0.0) dw_last = dw;
+            if (tries == 0 && pb.hess == 1) gn_back = 0;
+            bmpc_dbg_iters++; bmpc_dbg_sweeps += 1 + tries; bmpc_dbg_retry_iters += tries > 0;
         }
         /* row steps + fraction to boundary */
         double tau = fmax(0.99, 1 - mu), ap = 1, ad = 1, dphi_f = 0, dphi_bar = 0;
@@ -1224,6 +1232,15 @@ for (int k = 1; k < N; k++) {
             }
             for (int i = 0; i < 24; i++) pb.r0[i] = pb.x1fix[i] - pb.st[1].zeta[i];
             for (int k = N - 1; k >= 1; k--) eval_stage(&pb, k, 1);
+            /* slack reset (Byrd, Hribar & Nocedal's interior-point method; KNITRO): a trial slack is never smaller than
+             * the value that closes its row at the trial point, t <- max(t + alpha dt, -h(x + alpha dx)) -- it lowers the
+             * infeasibility theta and the barrier term, and keeps the nonlinearity of the kinematic rows out of theta */
+            if (o->slack_reset)
+                for (int k = 1; k < N; k++) {
+                    stage_t* s = &pb.st[k];
+                    for (int i = 0; i < s->nrows; i++)
+                        if (-s->h[i] > s->t[i]) s->t[i] = -s->h[i];
+                }
             double f1, th1, ls1;
             merit_parts(&pb, &f1, &th1, &ls1);
             double phi1 = f1 - mu * ls1;
@@ -1260,6 +1277,7 @@ for (int k = 1; k < N; k++) {
             eval_stage(&pb, k, 0);
         }
         err_prev = kk.err;
+        pb.hreg = 0.0;                       /* the next iteration's model starts without a correction */
         if (kk.err < 0.9 * err_best) { err_best = kk.err; stall = 0; } else stall++;
         if (o->verbose > 1 && lim_k > 0) {
             const stage_t* s = &pb.st[lim_k]; const row_t* r = &s->rows[lim_i];

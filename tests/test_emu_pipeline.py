@@ -25,7 +25,7 @@ def test_emulated_pipeline_matches_oracle():
         # multipliers (k_mult, k_mult_sweep): every entry written, equal to the oracle's, closing the full-space KKT conditions
         rs = O.solve(N, batch["x0"][i], batch["lbx"][i], batch["ubx"][i], batch["p"][i])
         assert np.isfinite(r["lam_g"][i]).all() and np.isfinite(r["lam_x"][i]).all()
-        assert np.abs(r["lam_g"][i] - rs["lam_g"]).max() < 1e-6 and np.abs(r["lam_x"][i] - rs["lam_x"]).max() < 1e-6
+        assert np.abs(r["lam_g"][i] - rs["lam_g"]).max() < 1e-5 and np.abs(r["lam_x"][i] - rs["lam_x"]).max() < 1e-5
         _, _, gr, J = O.nlp_eval(N, r["x"][i], batch["p"][i])
         assert np.abs(gr + J.T @ r["lam_g"][i] + r["lam_x"][i]).max() < 1e-4
 

@@ -77,7 +77,10 @@ def bridge_check(name, d, solve):
         else:
             assert bool(d["has_polish"][i]), (name, i, "different local solutions and no confirmation run in the fixture")
             assert f < float(d["f"][i])                                           # ours is the better local solution
-            assert np.abs(x - d["x_ip"][i]).max() < 1e-5                           # the point the confirmation run started from
+            # the point the confirmation run started from (an interior-point solution at tol 1e-8 of an earlier build): two
+            # tol-1e-8 points of one local solution are up to 3e-5 apart in the weakly determined joint-space directions
+            # (tests/diag/diag_parity_tol.py), their objectives agree (next but one line)
+            assert np.abs(x - d["x_ip"][i]).max() < 5e-5
             moved = np.abs(d["x_polish"][i] - d["x_ip"][i])
             assert moved[:7 * N].max() < 1e-5 and moved[28 * N:40 * N].max() < 1e-5, (name, i)
             assert abs(float(d["f_polish"][i]) - f) <= 1e-6 * abs(f)

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--scene", choices=["free", "example"], default="free", help="free: configs[4] (no obstacles); example: the 12 "
                     "boxes of the reference's example scene, starts scattered around its start configuration, its goal pose")
     ap.add_argument("--async", dest="async_", action="store_true", help="rollouts do not wait for each other (bmpc_loop_run_async); one group")
+    ap.add_argument("--dump-failing", default=None, help="one group only: .npz with the inputs (x0, lbx, ubx, p) of the last step's solves that did not converge, "
+                    "and the per-rollout counts of failed solves")
     ap.add_argument("--diagnose", default=None, help="write a JSON with the classification of the rollouts that did not reach the path end")
     ap.add_argument("--groups", type=int, default=3, help="rollout groups stepped concurrently (own solver handle and stream "
                     "each): the straggler tail of one group's solve overlaps the bulk of another's")
@@ -128,6 +130,15 @@ def main():
         "reached_end_frac": float((reached_at > 0).mean()),
         "steps_to_end_median": float(np.median(reached_at[reached_at > 0])) if (reached_at > 0).any() else None,
     }
+    if args.dump_failing and G == 1:
+        sol = loop.solution()
+        x0_, lbx_, ubx_, p_ = loop.problem()
+        bad = np.nonzero(sol["status"] != 0)[0]
+        nfail = np.concatenate(fails).sum(axis=0)
+        order = np.argsort(-nfail)[:16]
+        np.savez(args.dump_failing, rows=bad, x0=x0_[bad], lbx=lbx_[bad], ubx=ubx_[bad], p=p_[bad], iters=sol["iters"][bad], status=sol["status"][bad],
+                 fail_counts=nfail, worst=order, worst_counts=nfail[order], N=N)
+        print(f"failed solves per rollout: worst {list(zip(order.tolist(), nfail[order].tolist()))}; last step not converged: {bad.tolist()}", file=sys.stderr)
     if args.diagnose:
         from boundplanner_amd.params import Q_LIM_LOWER, Q_LIM_UPPER
         H = np.concatenate(hist)                   # [steps][R][7 + 7]
