@@ -121,6 +121,11 @@ BMPC_INL void lp_euler_zyx(const double* M, double* e) {
     e[1] = asin(s);
     e[0] = atan2(-M[1], M[0]);
     e[2] = atan2(-M[5], M[8]);
+    // a half turn comes out as +pi or -pi depending on the SIGN OF A ZERO in M (structural zeros of the padded segments'
+    // bases): made deterministic -- +pi -- here and in so3.compute_initial_rot_errors, where the reference's value is a coin flip
+    const double PI = 3.14159265358979323846;
+    if (fabs(fabs(e[0]) - PI) < 1e-12) e[0] = PI;
+    if (fabs(fabs(e[2]) - PI) < 1e-12) e[2] = PI;
 }
 
 BMPC_INL void lp_mat3T(const double* A, double* T) {

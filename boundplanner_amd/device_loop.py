@@ -184,6 +184,29 @@ class DeviceLoop:
         self.state[r] = pack_state(self.lay, mpc, q, V["dq"].copy(), V["ddq"].copy(), V["jerk"].copy(), q, V["v"].copy(),
                                    V["p_lie"].copy())
 
+    def horizon_points(self, r):
+        """End-effector positions of rollout r's last accepted solution, stage by stage: the `p_horizon` argument of
+        BoundPlanner.plan_convex_set_path(replanning=True) (BoundPlanner.py:231-276).  Call download() first."""
+        N = self.N
+        x = self.prev[r]
+        return [x[28 * N + np.arange(3) * N + k].copy() for k in range(N)]
+
+    def plan_and_replan(self, r, mpc, planner, goal_p, goal_r, replanning=True, new_obs=False):
+        """Plan from rollout r's CURRENT pose to the goal pose with `planner` (boundplanner_amd.bound_planner.BoundPlanner) --
+        when replanning, along the MPC horizon of its last solution -- and hand the plan to replan().  Returns the plan
+        (p_via, r_via, bp1_list, sets_via).  Call download() first, upload() afterwards."""
+        from scipy.spatial.transform import Rotation as Rot
+        V = state_view(self.lay, self.state[r])
+        p_lie = V["p_lie"].copy()
+        has_prev = V["has_prev"][0] != 0
+        kw = dict(replanning=True, p_horizon=self.horizon_points(r), new_obs=new_obs) if (replanning and has_prev) else {}
+        p_via, r_via, bp1, sets = planner.plan_convex_set_path(p_lie[:3], np.asarray(goal_p, float), Rot.from_rotvec(p_lie[3:]).as_matrix(),
+                                                               np.asarray(goal_r, float), **kw)
+        n = len(bp1)
+        erb = [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(n)]        # boundplanner_with_mpc_example.py:132-133
+        self.replan(r, mpc, p_via, r_via, bp1, [np.array([0, 0, 1.0])] * n, erb, [s_[0] for s_ in sets], [s_[1] for s_ in sets])
+        return p_via, r_via, bp1, sets
+
     # ---- stepping
     def run(self, nsteps, log=True):
         out = np.zeros((nsteps, self.R, self.logw)) if log else None

@@ -57,6 +57,11 @@ def compute_initial_rot_errors(pr, pr_ref, dp_normed_ref, br1, br2):
     r01 = np.column_stack((br2, dp_normed_ref, br1))
     dtau_01 = r01.T @ R.from_rotvec(dtau_init).as_matrix() @ r01
     eul = R.from_matrix(dtau_01).as_euler("zyx")
+    # a half turn comes out as +pi or -pi depending on the sign of a floating-point zero in dtau_01 (structural zeros of the
+    # padded segments' bases): made deterministic (+pi) here and on the device (csrc/bmpc_loop.hpp lp_euler_zyx)
+    for i in (0, 2):
+        if abs(abs(eul[i]) - np.pi) < 1e-12:
+            eul[i] = np.pi
     return [dtau_init, eul[1] * dp_normed_ref, eul[0] * br1, eul[2] * br2]
 
 

@@ -1,10 +1,8 @@
 #!/usr/bin/env python3
-"""Track phase of the reference's example (/root/reference/boundplanner_with_mpc_example.py:19-166) on the
-MI355X solver: default iiwa14 start configuration, MPCNode start-up + warm-up solve (:21-29), a via path
-handed to `update_reference` (:134) and the hot loop `while phi < phi_max - 0.001: mpc_node.step()` (:140-157).
-
-The plan phase (BoundPlanner.plan_convex_set_path, :102-115) is outside this build's scope;
-the via path below is hand-authored inside two large box sets, like the golden closed-loop fixture.
+"""The reference's example (/root/reference/boundplanner_with_mpc_example.py:19-166) as plan-then-track on the MI355X
+solver: default iiwa14 start configuration, MPCNode start-up + warm-up solve (:21-29), BoundPlanner.plan_convex_set_path
+on the 12-box scene (:102-115; boundplanner_amd.bound_planner, host), the plan handed to `update_reference` (:134) and the
+hot loop `while phi < phi_max - 0.001: mpc_node.step()` (:140-157).
 BASELINE.json configs[0] ("single instance plumbing"): one instance, N = 15 (the reference default).
 
     python examples/mpc_example.py            # needs an MI355X (no CPU fallback)
@@ -25,9 +23,18 @@ from boundplanner_amd.robot_model import RobotModel       # noqa: E402
 from boundplanner_amd.solver import HipBoundMPC, HipNlpSolver   # noqa: E402
 
 
-def box_set(lo, hi):
-    a = np.vstack((np.eye(3), -np.eye(3), np.zeros((9, 3))))
-    return a, np.concatenate((np.asarray(hi, float), -np.asarray(lo, float), 10.0 * np.ones(9)))
+def plan(p0, r0):
+    """Example :102-115: sets, via points and orientation schedule from the start pose to the example's goal pose."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.bound_planner import BoundPlanner
+    boxes, _, goal_p, goal_r = scenes.example_scene()
+    planner = BoundPlanner(e_p_max=0.5, obstacles=boxes, workspace_max=[1.0, 0.38, 1.0], workspace_min=[-0.14, -1.0, 0.0], seed=0)
+    t0 = time.perf_counter()
+    p_via, r_via, bp1_list, sets_via = planner.plan_convex_set_path(p0, goal_p, r0, goal_r)
+    print(f"Path planning took {time.perf_counter() - t0:.2f}s: {len(p_via)} via points through {len(sets_via)} of {planner.nr_sets} sets")
+    n = len(bp1_list)
+    erb = [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(n)]
+    return p_via, r_via, bp1_list, [np.array([0, 0, 1.0])] * n, erb, [s[0] for s in sets_via], [s[1] for s in sets_via], boxes
 
 
 def main_device():
@@ -48,13 +55,8 @@ def main_device():
     loop.run(1, log=False)                                     # warm-up solve, example :29
     V = loop.download()
     p0 = V["p_lie"][0].copy()
-    R0 = R.from_rotvec(p0[3:]).as_matrix()
-    p_via = [p0[:3].copy(), p0[:3] + np.array([0.05, -0.25, 0.10]), goal_p.copy()]
-    r_via = [R0, R0 @ R.from_euler("xyz", [20, 0, 10], degrees=True).as_matrix(),
-             R0 @ R.from_euler("xyz", [20, 25, 10], degrees=True).as_matrix()]
-    sets = [box_set([-0.14, -1.0, 0.0], [1.0, 0.38, 1.0])] * 2
-    loop.replan(0, seed.mpcs[0], p_via, r_via, [np.array([0.0, 0, 1])] * 2, [np.array([0.0, 0, 1])] * 2,
-                [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(2)], [s[0] for s in sets], [s[1] for s in sets])
+    p_via, r_via, bp1, br1, erb, a_sets, b_sets, _ = plan(p0[:3], R.from_rotvec(p0[3:]).as_matrix())
+    loop.replan(0, seed.mpcs[0], p_via, r_via, bp1, br1, erb, a_sets, b_sets)
     loop.upload()
     L, t0, steps, iters = loop.LOG, time.perf_counter(), 0, []
     while steps < 300:
@@ -80,14 +82,10 @@ def main():
     node = MPCNode(q0, RobotModel(be.fk), lambda n, dt: HipNlpSolver(n, dt, backend=be))
     node.step()                                                              # warm-up solve, example :29
     p0 = node.p_lie
-    R0 = R.from_rotvec(p0[3:]).as_matrix()
-    p_via = [p0[:3].copy(), p0[:3] + np.array([0.05, -0.25, 0.10]), np.array([0.45, -0.5, 0.2])]   # goal of the example
-    r_via = [R0, R0 @ R.from_euler("xyz", [20, 0, 10], degrees=True).as_matrix(),
-             R0 @ R.from_euler("xyz", [20, 25, 10], degrees=True).as_matrix()]
-    sets = [box_set([-0.14, -1.0, 0.0], [1.0, 0.38, 1.0])] * 2               # workspace of the example (:97-100)
-    node.update_reference(p_via, r_via, [np.array([0.0, 0, 1])] * 2, [np.array([0.0, 0, 1])] * 2,
-                          [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(2)],
-                          [s[0] for s in sets], [s[1] for s in sets], [])
+    p_via, r_via, bp1, br1, erb, a_sets, b_sets, boxes = plan(p0[:3], R.from_rotvec(p0[3:]).as_matrix())
+    from boundplanner_amd import scenes
+    node.mpc.set_obstacle_sets(*scenes.boxes_to_sets(boxes))                 # per-step collision sets (BoundMPC.py:480-493)
+    node.update_reference(p_via, r_via, bp1, br1, erb, a_sets, b_sets, [])
     t0, steps = time.perf_counter(), 0
     while node.mpc.phi_current[0] < node.mpc.phi_max[0] - 0.001 and steps < 300:
         node.step()

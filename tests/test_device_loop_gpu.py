@@ -379,3 +379,54 @@ def test_async_closed_loop_equals_lock_step():
         L = loop.LOG
         assert len(set(logs[0][:, :, L["iters"]].ravel().tolist())) > 3          # the solves do take different numbers of iterations
         assert np.array_equal(logs[0], logs[1])
+
+
+def test_config0_plan_then_track_with_replanning_on_the_device_loop(golden_dir):
+    """BASELINE configs[0] as the reference runs it (boundplanner_with_mpc_example.py:102-157): BoundPlanner.plan_convex_set_path
+    on the 12-box scene -> update_reference -> track, on the device-resident loop with per-step collision sets; halfway the
+    rollout is replanned through the planner (replanning=True, p_horizon = the MPC horizon of its last solution, BoundPlanner.py:
+    231-276, 706-729) and must still arrive.  The first plan equals the fixture produced by the reference's planner logic."""
+    from scipy.spatial.transform import Rotation as Rot
+    from boundplanner_amd import scenes
+    from boundplanner_amd.batch_node import BatchMPCNode
+    from boundplanner_amd.bound_planner import BoundPlanner
+    from boundplanner_amd.device_loop import DeviceLoop
+    from boundplanner_amd.solver import HipBoundMPC
+    boxes, q0, goal_p, goal_r = scenes.example_scene()
+    base = get_default_params()
+    N = 15
+    params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
+    be = HipBoundMPC(N)
+    seed = BatchMPCNode(be, q0[None], params)
+    loop = DeviceLoop(be, 1)
+    loop.set_obstacles(*scenes.boxes_to_sets(boxes))
+    loop.set_rollout(0, seed.mpcs[0], seed.q[0], seed.dq[0], seed.ddq[0], seed.jerk[0], seed.qf[0], seed.v[0], seed.p_lie[0])
+    loop.upload()
+    loop.run(1, log=False)
+    loop.download()
+    planner = BoundPlanner(e_p_max=0.5, obstacles=boxes, workspace_max=[1.0, 0.38, 1.0], workspace_min=[-0.14, -1.0, 0.0], seed=7)
+    p_via, r_via, bp1, sets = loop.plan_and_replan(0, seed.mpcs[0], planner, goal_p, goal_r, replanning=False)
+    fx = np.load(os.path.join(golden_dir, "plan.npz"))
+    assert np.abs(np.array(p_via) - fx["example_p_via"]).max() < 1e-5      # (the start pose is the GPU's FK of q0: 1e-12 from the fixture's)
+    loop.upload()
+    L = loop.LOG
+    log = loop.run(25)
+    assert (log[:, 0, L["error_count"]] == 0).all()
+    phi_mid, phi_max0 = log[-1, 0, L["phi"]], log[-1, 0, L["phi_max"]]
+    assert 0.05 < phi_mid < phi_max0 - 0.01                                 # under way, not there yet
+    loop.download()
+    p2, _, _, sets2 = loop.plan_and_replan(0, seed.mpcs[0], planner, goal_p, goal_r, replanning=True)
+    assert planner.replanning and planner.replanning_phi >= 0.0 and np.abs(p2[-1] - goal_p).max() < 1e-9
+    loop.upload()
+    arrived, steps, fails = False, 0, 0
+    while steps < 300 and not arrived:
+        log = loop.run(10)
+        steps += 10
+        fails += int((log[:, 0, L["error_count"]] > 0).sum())
+        arrived = bool((log[:, 0, L["phi"]] >= log[:, 0, L["phi_max"]] - 0.001).any())
+    assert arrived and fails <= 2
+    p_end = log[-1, 0, L["p_lie"]][:3]
+    assert np.linalg.norm(p_end - goal_p) < 0.02
+    # the tracked path stays clear of the obstacles themselves
+    for bx in boxes:
+        assert not ((p_end >= bx[:3]) & (p_end <= bx[3:])).all()

@@ -31,7 +31,8 @@ def kkt_residual(N, x, p, lbx, ubx, act_tol=1e-3):
             lo.append(-np.inf if (fixed or dn) else 0.0)
             hi.append(np.inf if (fixed or up) else 0.0)
     A = np.array(cols).T
-    res = lsq_linear(A, -gr, bounds=(np.array(lo), np.array(hi)), tol=1e-14, max_iter=400)
+    # (bvls: the active-set method; trf's iterations stall on some of these 270 x 240 problems -- status 0 with a residual of 1e4)
+    res = lsq_linear(A, -gr, bounds=(np.array(lo), np.array(hi)), tol=1e-14, max_iter=2000, method="bvls")
     return np.abs(A @ res.x + gr).max(), g, lbg, ubg
 
 
