@@ -204,7 +204,8 @@ class DeviceLoop:
                                                                np.asarray(goal_r, float), **kw)
         n = len(bp1)
         erb = [np.array([90, 90, 90, -90, -90, -90]) * np.pi / 180 for _ in range(n)]        # boundplanner_with_mpc_example.py:132-133
-        self.replan(r, mpc, p_via, r_via, bp1, [np.array([0, 0, 1.0])] * n, erb, [s_[0] for s_ in sets], [s_[1] for s_ in sets])
+        # (copies: ReferencePath appends its padded segments to the lists it is given, ReferencePath.py:43-46 -- Q15)
+        self.replan(r, mpc, list(p_via), list(r_via), list(bp1), [np.array([0, 0, 1.0])] * n, erb, [s_[0] for s_ in sets], [s_[1] for s_ in sets])
         return p_via, r_via, bp1, sets
 
     # ---- stepping

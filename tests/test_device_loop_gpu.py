@@ -410,7 +410,7 @@ def test_config0_plan_then_track_with_replanning_on_the_device_loop(golden_dir):
     assert np.abs(np.array(p_via) - fx["example_p_via"]).max() < 1e-5      # (the start pose is the GPU's FK of q0: 1e-12 from the fixture's)
     loop.upload()
     L = loop.LOG
-    log = loop.run(25)
+    log = loop.run(10)
     assert (log[:, 0, L["error_count"]] == 0).all()
     phi_mid, phi_max0 = log[-1, 0, L["phi"]], log[-1, 0, L["phi_max"]]
     assert 0.05 < phi_mid < phi_max0 - 0.01                                 # under way, not there yet
