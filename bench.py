@@ -64,11 +64,34 @@ def block_diffs(N, xa, xb):
     return {k: float(d[:, a:b].max()) if d.size else None for k, (a, b) in blocks.items()}
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT touching the HIP runtime (the launcher must not initialise the GPU before it starts
+    its ranks): the KFD topology nodes that have SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        nodes = []
+    for node in nodes:
+        try:                                  # (a container sees only its own GPUs' nodes; the others are not readable)
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
     """`--gpus N` without a launcher: start N ranks as a child torch.distributed.run (a child process, before this
     process has touched the GPU -- never a re-exec) and return its exit code."""
-    import torch
-    have = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    have = visible_gpus()
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to print a line for fewer ranks",
               file=sys.stderr)
@@ -245,11 +268,12 @@ def main():
 
     # HBM bytes of one batch from the PMC passes of tools/profile_round.sh (separate rocprofv3 --pmc runs of one
     # synchronous batch of this same workload), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-    traffic, traffic_note = None, None
+    traffic, traffic_note, fetch_raw, write_raw = None, None, None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj) and (B, N) == (BATCH_PER_GPU, HORIZON):
         t = json.load(open(tj))
-        traffic = 2.0 * t["fetch_bytes_raw"] + t["write_bytes"]
+        fetch_raw, write_raw = t["fetch_bytes_raw"], t["write_bytes"]
+        traffic = 2.0 * fetch_raw + write_raw
         traffic_note = (f"profiles/pmc_traffic.json ({t.get('build', 'round-1 build')}): 2 x FETCH_SIZE {t['fetch_bytes_raw'] / 1e9:.1f} GB (gfx950 "
                         f"correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE {t['write_bytes'] / 1e9:.1f} GB per batch, all kernels")
 
@@ -272,7 +296,12 @@ def main():
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
                    "accepted_frac": float(ok.mean()), "gen_s": t_gen, "stats_of": "the step-0 batch solved alone"},
         "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": "bmpc_k_ric (+ bmpc_k_eval, k_step, k_trial): one batch",
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                     # measured HBM bytes of a batch over the per-batch time of THIS run: what the memory system actually sustains
+                     "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                     "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "fetch_size_raw_bytes": fetch_raw, "write_size_bytes": write_raw,
+                     "kernel": "bmpc_k_ric (+ bmpc_k_eval, k_step, k_trial): one batch",
                      "kernel_ms": k_ms, "event_ms_per_batch": event_ms, "alg_bytes_per_solve": alg_bytes_per_solve(N),
                      "note": "not HBM- or MFMA-bound: latency/VALU/LDS-bound small-matrix IP loop (DESIGN.md); "
                              "the meaningful limiter is FP64 VALU, reported in valu_fp64"},
@@ -296,6 +325,27 @@ def main():
         out["value_pcie_inclusive"] = B / (time.perf_counter() - t1)
         out["pcie_note"] = "bmpc_solve with pageable host arrays: 3 x 58 MB + 57 MB H2D, 58 MB D2H per batch inside the timed call"
         assert np.array_equal(rh["x"], x.cpu().numpy()), "host-pointer and device-pointer entries disagree"
+
+    if rank == 0 and not args.no_extra and args.pool > 0:
+        # ... and the same pipelined schedule as `value` WITH its transfers: inputs from pinned host memory by asynchronous copies
+        # on the handles' streams, outputs back to pinned host memory; 231 MB in, 58 MB out per batch
+        from boundplanner_amd.batch_stream import HostBatchStream
+        nd_h = min(n_distinct, depth * M)
+        pinned = {k: torch.empty((nd_h * B, v.shape[1]), dtype=torch.float64, pin_memory=True) for k, v in d.items()}
+        for k, v in d.items():
+            pinned[k].copy_(v[:nd_h * B])
+        torch.cuda.synchronize(dev)
+        hs = HostBatchStream(bes, pinned, B, M, dev)
+        hs.run(depth * M)                                    # warm-up: staging buffers touched, pools allocated
+        t1 = time.perf_counter()
+        hs.run(args.steps)
+        torch.cuda.synchronize(dev)
+        out["value_pcie_inclusive_pipelined"] = args.steps * B / (time.perf_counter() - t1)
+        out["pcie_pipelined_note"] = (f"{depth} solver calls in flight, each: hipMemcpyAsync of x0, lbx, ubx, p for {M} batches from pinned host memory on the "
+                                      "handle's stream -> streaming solve -> x, f, iters, status, viol back to pinned host memory")
+        same = all(bool(torch.equal(hs.h_out[0][k][:B], outs[0][k][:B].cpu())) for k in ("x", "iters", "status")) if nd_h >= 1 and args.steps % (depth * M) == 0 else None
+        out["pcie_pipelined_first_batch_equals_device_resident"] = same
+        del hs, pinned
 
     if rank == 0 and not args.no_cpu_baseline:
         import oracle_lib as O               # cpu_baseline leg only

@@ -86,3 +86,59 @@ class BatchStream:
     def drain(self):
         for q in range(self.depth):
             self.retire((self.calls + q) % self.depth)
+
+
+class HostBatchStream:
+    """The same schedule with the transfers inside ("incl. H2D of inputs and D2H of x, iters, status"): every
+    solver call's x0, lbx, ubx, p come from PINNED host memory with asynchronous copies on the handle's own stream, its x, f,
+    iters, status, viol go back to pinned host memory when the call has retired; the copies of one handle run beside the
+    kernels of the others.  torch provides the pinned buffers and wraps the handles' streams (plumbing only)."""
+
+    def __init__(self, backends, host_inputs, B, merge, dev):
+        import torch
+        self.torch, self.be, self.B, self.M, self.dev = torch, backends, B, merge, dev
+        self.depth = len(backends)
+        self.src = host_inputs                               # pinned [nd * B, .] tensors
+        self.nd = host_inputs["x0"].shape[0] // B
+        n = merge * B
+        n_w, n_p = host_inputs["x0"].shape[1], host_inputs["p"].shape[1]
+        f64, i32 = torch.float64, torch.int32
+        self.streams = [torch.cuda.ExternalStream(b.stream(), device=dev) for b in backends]
+        self.d_in = [{k: torch.empty((n, n_p if k == "p" else n_w), dtype=f64, device=dev) for k in ("x0", "lbx", "ubx", "p")} for _ in backends]
+        self.d_out = [dict(x=torch.empty((n, n_w), dtype=f64, device=dev), f=torch.empty(n, dtype=f64, device=dev), viol=torch.empty(n, dtype=f64, device=dev),
+                           iters=torch.empty(n, dtype=i32, device=dev), status=torch.empty(n, dtype=i32, device=dev)) for _ in backends]
+        self.h_out = [{k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in o.items()} for o in self.d_out]
+        self.busy = [0] * self.depth
+        self.calls = 0
+
+    def _retire(self, j):
+        if not self.busy[j]:
+            return
+        self.be[j].wait()                                    # every kernel of the call has been enqueued and has finished
+        n = self.busy[j] * self.B
+        with self.torch.cuda.stream(self.streams[j]):
+            for k, v in self.d_out[j].items():
+                self.h_out[j][k][:n].copy_(v[:n], non_blocking=True)
+        self.busy[j] = 0
+
+    def run(self, nbatches):
+        left = nbatches
+        while left > 0:
+            m = min(self.M, left)
+            j = self.calls % self.depth
+            self._retire(j)
+            s = (self.calls * self.M) % self.nd
+            n = m * self.B
+            with self.torch.cuda.stream(self.streams[j]):       # (behind the D2H of the previous call on this stream)
+                for k, v in self.d_in[j].items():
+                    v[:n].copy_(self.src[k][s * self.B:s * self.B + n], non_blocking=True)
+            i, o = self.d_in[j], self.d_out[j]
+            self.be[j].solve_dev_async(n, i["x0"].data_ptr(), i["lbx"].data_ptr(), i["ubx"].data_ptr(), i["p"].data_ptr(), o["x"].data_ptr(),
+                                       o["f"].data_ptr(), o["iters"].data_ptr(), o["status"].data_ptr(), o["viol"].data_ptr())
+            self.busy[j] = m
+            self.calls += 1
+            left -= m
+        for q in range(self.depth):
+            self._retire((self.calls + q) % self.depth)
+        for st in self.streams:
+            st.synchronize()

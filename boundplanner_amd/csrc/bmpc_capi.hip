@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,6 +19,8 @@ using namespace bmpc;
 
 extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* q, const double* dq, double* ee_pos,
                                      double* ee_rot, double* col_pts, double* jac, double* dvdq, hipStream_t st);
+
+extern "C" hipError_t bmpc_launch_spin(int ms, hipStream_t st);
 
 extern "C" hipError_t bmpc_pipe_launch_init(const PipeArgsH* A, int n0, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_retire_out(const PipeArgsH* A, int n_max, hipStream_t st);
@@ -61,7 +64,8 @@ struct bmpc_handle {
     int cap = 0;
     bool cap_g = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
+    bool wedged = false;           // a wait ran into the watchdog: the stream may still be busy, the handle refuses further work
     float last_ms = 0.f;
     std::atomic<bool> busy{false}; // a solve is running on this handle (a handle serves one host thread at a time)
     std::atomic<int> n_loops{0};   // device loops borrowing this handle (bmpc_loop_create / bmpc_loop_destroy)
@@ -80,6 +84,31 @@ struct bmpc_handle {
 
 static int pipe_ensure(bmpc_handle* h, int B);
 
+// Wait for everything enqueued on `st` so far.  With bmpc_opts.watchdog_ms > 0 the wait polls an event and gives up after that
+// long: a kernel that does not return then costs the caller an error code -- rc 5, bmpc_last_error() --
+// instead of a host thread stuck in hipStreamSynchronize for ever.  The handle is unusable afterwards (its stream may never
+// drain): destroy it, or end the process when it does not come back.
+static int wait_stream(bmpc_handle* h, hipStream_t st) {
+    if (h->o.watchdog_ms <= 0) { HIPCHK(h, hipStreamSynchronize(st)); return 0; }
+    HIPCHK(h, hipEventRecord(h->ev_wait, st));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; spins++) {
+        const hipError_t q = hipEventQuery(h->ev_wait);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { h->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return 2; }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > h->o.watchdog_ms) {
+            h->wedged = true;
+            h->err = "watchdog: the GPU did not finish the enqueued work within " + std::to_string(h->o.watchdog_ms) +
+                     " ms (bmpc_opts.watchdog_ms); the handle is unusable, destroy it";
+            return 5;
+        }
+        if (ms < 2.0) std::this_thread::yield();            // a burst of super-steps takes a few ms: stay responsive
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+#define WEDGED_FAIL(h) if ((h)->wedged) { (h)->err = "the handle ran into its watchdog earlier and is unusable"; return 5; }
+
 // one solve at a time per handle: a second host thread entering gets an error instead of a corrupted workspace
 struct BusyGuard {
     bmpc_handle* h; bool ok;
@@ -94,7 +123,7 @@ extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
     o->hess = 2; o->hess_switch = 1.0; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
     o->mu_floor_k = 1e4; o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->gn_backoff = 2; o->slack_reset = 1;
-    o->max_batch = 0; o->pool_slots = 0;
+    o->max_batch = 0; o->pool_slots = 0; o->watchdog_ms = 30000;
 }
 
 extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
@@ -133,6 +162,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming));
     if (o->max_batch > 0) return pipe_ensure(h, o->max_batch);   // workspace up front
     return 0;
 }
@@ -164,6 +194,7 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (h->h_cnt) (void)hipHostFree(h->h_cnt);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -252,6 +283,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
                       const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
                       double* d_viol, hipStream_t st, bmpc_retire_hook hook = nullptr, void* hook_ctx = nullptr,
                       const int* d_cont = nullptr) {
+    WEDGED_FAIL(h);
     int rc = pipe_ensure(h, B);
     if (rc) return rc;
     const int N = h->o.N, cap = h->pipe_cap;
@@ -309,7 +341,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
         }
         if (int r = retire(rows_left ? cap : n_act, rows_left ? 1 : 0)) return r;
         HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
+        if (int r = wait_stream(h, st)) return r;
         retired = h->h_cnt[7];
         next_row = h->h_cnt[6] < B ? h->h_cnt[6] : B;
         n_act = next_row - retired;
@@ -319,7 +351,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     h->last_steps = steps;
     HIPCHK(h, hipEventRecord(h->ev1, st));
     // the outputs are complete and the per-handle workspace is free when the call returns (the loop above synchronised)
-    HIPCHK(h, hipStreamSynchronize(st));
+    if (int r = wait_stream(h, st)) return r;
     if (retired < B) { h->err = "pipeline did not drain (internal error)"; return 3; }
     h->last_args = A; h->last_valid = !streaming;      // multipliers need every instance's final iterate in its slot
     h->last_args.cont = nullptr;
@@ -392,7 +424,7 @@ extern "C" int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, c
         int r = 0;
         if (hipSetDevice(h->o.device) != hipSuccess) { h->err = "hipSetDevice failed in the worker"; r = 2; }
         if (r == 0) r = launch(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, d_g, d_f, d_iters, d_status, d_viol, h->stream);
-        if (r == 0 && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed in the worker"; r = 2; }
+        if (r == 0) r = wait_stream(h, h->stream);
         h->worker_rc = r;
         if (r != 0) h->n_active.store(0);        // a failed solve is not "active" for ever; bmpc_wait reports the code
         h->busy.store(false);
@@ -412,7 +444,7 @@ extern "C" int bmpc_multipliers_dev(bmpc_handle* h, int B, double* d_lam_g, doub
     A.lam_g = d_lam_g; A.lam_x = d_lam_x;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(h, bmpc_pipe_launch_mult(&A, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    if (int r = wait_stream(h, st)) return r;
     return 0;
 }
 
@@ -474,7 +506,7 @@ extern "C" int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double*
     HIPCHK(h, hipMemcpyAsync(viol, h->d_viol, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipMemcpyAsync(iters, h->d_iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipMemcpyAsync(status, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    if (int r = wait_stream(h, st)) return r;
     HIPCHK(h, hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
     if (lam_g || lam_x) {
         if (B > h->cap_lam) {
@@ -541,5 +573,13 @@ extern "C" int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16) {
     for (int i = 0; i < 16; i++) out16[i] = 0;
     for (int b = 0; b < h->nblocks_max; b++) for (int i = 0; i < 16; i++) out16[i] += buf[(size_t)b * 16 + i];
     HIPCHK(h, hipMemset(h->d_prof, 0, buf.size() * sizeof(double)));
+    return 0;
+}
+
+// diagnostic: keep the handle's stream busy for `ms` milliseconds (at most 10 s) -- lets a test exercise the watchdog
+extern "C" int bmpc_debug_spin(bmpc_handle* h, int ms) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->o.device));
+    HIPCHK(h, bmpc_launch_spin(ms, h->stream));
     return 0;
 }

@@ -27,3 +27,16 @@ extern "C" hipError_t bmpc_launch_fk(int B, const RobotConst* rc, const double* 
     hipLaunchKernelGGL(bmpc_fk_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, rc, q, dq, ee_pos, ee_rot, col_pts, jac, dvdq);
     return hipGetLastError();
 }
+
+// Diagnostic: occupies the stream for `ms` milliseconds (at most 10 s, then it ends by itself -- every wave reaches the exit) so
+// that the watchdog of the solve entry points can be tested without a kernel that really hangs.
+__global__ void bmpc_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();                    // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" hipError_t bmpc_launch_spin(int ms, hipStream_t st) {
+    if (ms > 10000) ms = 10000;
+    if (ms < 0) ms = 0;
+    hipLaunchKernelGGL(bmpc_spin_kernel, dim3(1), dim3(64), 0, st, (long long)ms * 100000LL);
+    return hipGetLastError();
+}

@@ -363,6 +363,7 @@ extern "C" int bmpc_solve_dev_hooked(bmpc_handle* h, int B, const double* d_x0, 
 static int loop_retire_hook(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream) {
     bmpc_loop* L = (bmpc_loop*)ctx;
     hipStream_t st = (hipStream_t)stream;
+    if (n_max > L->R) n_max = L->R;          // the solver's slot count may exceed the rollouts (workspace sized by max_batch)
     if (int rc = launch_finish(L, st, n_max, L->async_log, d_done, d_n_done, L->d_steps_left, L->d_cont, L->async_nsteps)) return rc;
     return launch_prepare(L, st, n_max, d_done, d_n_done);
 }

@@ -23,13 +23,13 @@ class BmpcOpts(ctypes.Structure):
                 ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
                 ("mu_floor_k", ctypes.c_double), ("inertia", ctypes.c_int), ("dw0", ctypes.c_double),
                 ("inertia_err", ctypes.c_double), ("stall_n", ctypes.c_int), ("slack_reset", ctypes.c_int), ("gn_backoff", ctypes.c_int),
-                ("max_batch", ctypes.c_int), ("pool_slots", ctypes.c_int)]
+                ("watchdog_ms", ctypes.c_int), ("max_batch", ctypes.c_int), ("pool_slots", ctypes.c_int)]
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
            "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_solve_dev_async", "bmpc_multipliers_dev", "bmpc_wait", "bmpc_active", "bmpc_fk",
            "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream", "bmpc_robot_iiwa14", "bmpc_robot_gen3", "bmpc_set_robot", "bmpc_get_robot",
-           "bmpc_debug_phase_cycles",
+           "bmpc_debug_phase_cycles", "bmpc_debug_spin",
            "bmpc_loop_state_doubles", "bmpc_loop_log_doubles", "bmpc_loop_field", "bmpc_loop_create", "bmpc_loop_destroy",
            "bmpc_loop_last_error", "bmpc_loop_set_obstacles", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_run_async", "bmpc_loop_prepare",
            "bmpc_loop_solve", "bmpc_loop_finish", "bmpc_loop_problem", "bmpc_loop_solution", "bmpc_loop_set_solution"]
@@ -85,6 +85,7 @@ def load_library():
         lib.bmpc_loop_problem.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp]
         lib.bmpc_loop_solution.argtypes = [ctypes.c_void_p, _dp, _ip, _ip, _dp]
         lib.bmpc_loop_set_solution.argtypes = [ctypes.c_void_p, _dp, _ip, _ip, _dp]
+        lib.bmpc_debug_spin.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _lib = lib
     return _lib
 
@@ -158,6 +159,14 @@ class HipBoundMPC:
                                  iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip), _P(viol))
         self._chk(rc, "bmpc_solve")
         return dict(x=x, g=g, f=f, iters=iters, status=status, viol=viol, lam_g=lam_g, lam_x=lam_x)
+
+    def stream(self):
+        """The handle's own HIP stream as an integer (hipStream_t): the one bmpc_solve and bmpc_solve_dev_async run on."""
+        return int(self.lib.bmpc_stream(self._h) or 0)
+
+    def debug_spin(self, ms):
+        """Diagnostic: occupy the handle's stream for `ms` milliseconds (bmpc_debug_spin)."""
+        self._chk(self.lib.bmpc_debug_spin(self._h, int(ms)), "bmpc_debug_spin")
 
     def multipliers_dev(self, B, d_lam_g, d_lam_x, stream=0):
         """lam_g, lam_x (raw device pointers) of the most recent finished solve on this handle."""

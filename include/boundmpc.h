@@ -50,6 +50,8 @@ typedef struct {
                            t <- max(t + alpha dt, -h(trial)) (Byrd-Hribar-Nocedal slack reset); 0: off */
     int gn_backoff;     /* 2: after a Gauss-Newton fallback the exact Hessian is tried again after 1, then 2 iterations
                            (a failed attempt costs a Riccati sweep); 0: every iteration */
+    int watchdog_ms;    /* > 0 (default 30000): a wait for the GPU gives up after this long and the call returns 5 with a message
+                           (the handle is unusable afterwards); 0: plain hipStreamSynchronize */
     int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
     int pool_slots;     /* 0 (default) = every instance of a call has its own workspace slot; > 0 = the workspace
                            holds this many instances and a call with more of them STREAMS them through it: a slot whose
@@ -150,6 +152,9 @@ int bmpc_last_kernel_ms(bmpc_handle* h, float* ms);
 
 /* Diagnostic builds (-DBMPC_PROFILE) only: per-phase shader-cycle sums of the last launches. */
 int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16);
+/* Diagnostic: keeps the handle's stream busy for `ms` milliseconds (at most 10 s, then the kernel ends by itself), so that the
+ * watchdog (bmpc_opts.watchdog_ms) can be exercised without a kernel that really hangs. */
+int bmpc_debug_spin(bmpc_handle* h, int ms);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident closed loop: R rollouts advanced in lock step, one batched solve per MPC step,

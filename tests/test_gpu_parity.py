@@ -555,3 +555,45 @@ def test_one_handle_from_two_threads_is_refused():
     t.join()
     assert errs and all("in use by another thread" in e for e in errs)
     assert np.array_equal(out["r"]["x"], ref["x"]) and np.array_equal(out["r"]["status"], ref["status"])
+
+
+def test_watchdog_turns_a_stuck_stream_into_an_error():
+    """A kernel that does not return must cost the caller an error code, not a host thread stuck in hipStreamSynchronize
+    (DESIGN.md section 7).  bmpc_debug_spin occupies the handle's stream for 3 s (a bounded spin: it ends by itself); with
+    watchdog_ms = 300 the solve behind it returns rc 5 and a message after ~0.3 s, from the synchronous entry and from the
+    worker thread of the asynchronous one; the handle then refuses further work, a fresh handle is unaffected."""
+    import time
+    import torch
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N, B = 10, 8
+    ok = HipBoundMPC(N)
+    batch = scenes.make_batch(B, N, 3, ok.fk, randomize_sets=True)
+    ref = ok.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    be = HipBoundMPC(N, watchdog_ms=300)
+    be.debug_spin(3000)
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="watchdog"):
+        be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    assert 0.25 < time.perf_counter() - t0 < 2.0
+    with pytest.raises(RuntimeError, match="unusable"):
+        be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    # asynchronous entry: the worker thread gives up the same way, bmpc_wait reports it
+    dev = torch.device("cuda", 0)
+    big = lambda a: np.nan_to_num(a, posinf=1e20, neginf=-1e20)
+    d = {k: torch.from_numpy(big(batch[k])).to(dev) for k in ("x0", "lbx", "ubx", "p")}
+    x = torch.empty((B, ok.n_w), dtype=torch.float64, device=dev)
+    f = torch.empty(B, dtype=torch.float64, device=dev); viol = torch.empty(B, dtype=torch.float64, device=dev)
+    it = torch.empty(B, dtype=torch.int32, device=dev); st = torch.empty(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    be2 = HipBoundMPC(N, watchdog_ms=300, max_batch=B)
+    be2.debug_spin(3000)
+    be2.solve_dev_async(B, d["x0"].data_ptr(), d["lbx"].data_ptr(), d["ubx"].data_ptr(), d["p"].data_ptr(), x.data_ptr(),
+                        f.data_ptr(), it.data_ptr(), st.data_ptr(), viol.data_ptr())
+    with pytest.raises(RuntimeError, match="watchdog"):
+        be2.wait()
+    time.sleep(3.2)                                   # the spin kernels end by themselves
+    torch.cuda.synchronize(dev)
+    again = ok.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    assert np.array_equal(again["x"], ref["x"])
+    be.close(); be2.close()
