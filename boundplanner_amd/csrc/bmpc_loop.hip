@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void bmpc_loop_k_x0(int R, int N, const double
 __global__ __launch_bounds__(64) void bmpc_loop_k_finish(int R, int N, double dt, const RobotConst* rc, double* S, const double* x,
                                                          const double* prev, const int* status, const double* viol,
                                                          const int* iters, double* log, const int* list, const int* n_list,
-                                                         int* steps_left, int* cont, int nsteps) {
+                                                         int* steps_left, int* cont, int nsteps, const double* par, double* rec,
+                                                         const int* rec_slot) {
     const int e = blockIdx.x * 64 + threadIdx.x;
     LOOP_ROLLOUT(e, r)
     const size_t n_w = 44 * N + 6;
@@ -88,7 +89,8 @@ __global__ __launch_bounds__(64) void bmpc_loop_k_finish(int R, int N, double dt
         if (lg) { for (int i = 0; i < LP_LOGW; i++) lg[i] = 0.0; lg[4] = 1.0; }
         return;
     }
-    loop_finish(rc, N, dt, s, x + r * n_w, prev + r * n_w, status[r], viol[r], iters[r], lg);
+    double* rc_ = (rec && rec_slot[r] >= 0) ? rec + (size_t)rec_slot[r] * lp_rec_doubles(N) : nullptr;
+    loop_finish(rc, N, dt, s, x + r * n_w, prev + r * n_w, status[r], viol[r], iters[r], lg, rc_, par + (size_t)r * NPAR);
 }
 
 // prev_solution <- accepted solution (BoundMPC.py:643)
@@ -115,6 +117,10 @@ struct bmpc_loop {
     int* d_scene_i = nullptr;      // nrows | nv
     double* d_colres = nullptr;
     int *d_steps_left = nullptr, *d_cont = nullptr;    // bmpc_loop_run_async
+    int* d_rec_slot = nullptr;     // [R] index of the rollout's record in a step's block, or -1 (bmpc_loop_set_record)
+    int n_rec = 0;
+    double* d_rec = nullptr;       // [steps][n_rec][lp_rec_doubles(N)] of the last bmpc_loop_run
+    size_t rec_cap = 0, rec_steps = 0;
     int async_nsteps = 0;
     double* async_log = nullptr;
     size_t log_cap = 0;
@@ -134,6 +140,33 @@ struct bmpc_loop {
 
 extern "C" int bmpc_loop_state_doubles(void) { return LS_SIZE; }
 extern "C" int bmpc_loop_log_doubles(void) { return LP_LOGW; }
+extern "C" int bmpc_loop_record_doubles(int N) { return lp_rec_doubles(N); }
+
+// MPCData records (include/boundmpc.h): the rollouts whose steps bmpc_loop_run records from now on (n = 0: none)
+extern "C" int bmpc_loop_set_record(bmpc_loop* L, int n, const int* rollouts) {
+    if (!L || n < 0 || (n > 0 && !rollouts)) return 1;
+    LCHK(L, hipSetDevice(L->dev));
+    std::vector<int> slot((size_t)L->R, -1);
+    for (int j = 0; j < n; j++) {
+        if (rollouts[j] < 0 || rollouts[j] >= L->R) { L->err = "bmpc_loop_set_record: rollout index out of range"; return 1; }
+        slot[(size_t)rollouts[j]] = j;
+    }
+    if (!L->d_rec_slot) LCHK(L, hipMalloc((void**)&L->d_rec_slot, (size_t)L->R * sizeof(int)));
+    LCHK(L, hipStreamSynchronize(L->st));
+    LCHK(L, hipMemcpy(L->d_rec_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+    L->n_rec = n; L->rec_steps = 0;
+    return 0;
+}
+// the records of the last bmpc_loop_run: out [steps][n][bmpc_loop_record_doubles(N)]
+extern "C" int bmpc_loop_records(bmpc_loop* L, double* out, int* steps) {
+    if (!L || !out) return 1;
+    LCHK(L, hipSetDevice(L->dev));
+    LCHK(L, hipStreamSynchronize(L->st));
+    if (steps) *steps = (int)L->rec_steps;
+    if (L->rec_steps > 0)
+        LCHK(L, hipMemcpy(out, L->d_rec, L->rec_steps * L->n_rec * lp_rec_doubles(L->N) * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int bmpc_loop_field(const char* name, int* offset, int* count) { return loop_field_lookup(name, offset, count); }
 extern "C" const char* bmpc_loop_last_error(const bmpc_loop* L) { return L ? L->err.c_str() : "null loop"; }
 
@@ -142,6 +175,8 @@ extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
     if (L->st) { (void)hipSetDevice(L->dev); (void)hipStreamSynchronize(L->st); }     // nothing of the loop still in flight
     double* bufs[] = {L->d_S, L->d_prev, L->d_x0, L->d_lbx, L->d_ubx, L->d_p, L->d_x, L->d_f, L->d_viol, L->d_log};
     for (double* b : bufs) if (b) (void)hipFree(b);
+    if (L->d_rec) (void)hipFree(L->d_rec);
+    if (L->d_rec_slot) (void)hipFree(L->d_rec_slot);
     if (L->d_iters) (void)hipFree(L->d_iters);
     if (L->d_status) (void)hipFree(L->d_status);
     if (L->d_rc) (void)hipFree(L->d_rc);
@@ -280,10 +315,10 @@ static int launch_prepare(bmpc_loop* L, hipStream_t st, int n, const int* list =
 }
 
 static int launch_finish(bmpc_loop* L, hipStream_t st, int n, double* d_log_rows, const int* list = nullptr, const int* n_list = nullptr,
-                         int* steps_left = nullptr, int* cont = nullptr, int nsteps = 0) {
+                         int* steps_left = nullptr, int* cont = nullptr, int nsteps = 0, double* d_rec_rows = nullptr) {
     const size_t ne = (size_t)n * L->n_w;
     hipLaunchKernelGGL(bmpc_loop_k_finish, dim3((n + 63) / 64), dim3(64), 0, st, L->R, L->N, L->dt, L->d_rc, L->d_S, L->d_x,
-                       L->d_prev, L->d_status, L->d_viol, L->d_iters, d_log_rows, list, n_list, steps_left, cont, nsteps);
+                       L->d_prev, L->d_status, L->d_viol, L->d_iters, d_log_rows, list, n_list, steps_left, cont, nsteps, L->d_p, d_rec_rows, L->d_rec_slot);
     hipLaunchKernelGGL(bmpc_loop_k_keep, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, L->R, L->N, L->d_S, L->d_x, L->d_prev,
                        list, n_list);
     LCHK(L, hipGetLastError());
@@ -320,7 +355,17 @@ extern "C" int bmpc_loop_finish(bmpc_loop* L, double* log) {
     if (!L) return 1;
     LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     if (log) { if (int rc = ensure_log(L, (size_t)L->R)) return rc; }
-    if (int rc = launch_finish(L, L->st, L->R, log ? L->d_log : nullptr)) return rc;
+    if (L->n_rec > 0) {
+        const size_t need = (size_t)L->n_rec * lp_rec_doubles(L->N);
+        if (need > L->rec_cap) {
+            if (L->d_rec) (void)hipFree(L->d_rec);
+            L->d_rec = nullptr; L->rec_cap = 0;
+            LCHK(L, hipMalloc((void**)&L->d_rec, need * sizeof(double)));
+            L->rec_cap = need;
+        }
+    }
+    if (int rc = launch_finish(L, L->st, L->R, log ? L->d_log : nullptr, nullptr, nullptr, nullptr, nullptr, 0, L->n_rec > 0 ? L->d_rec : nullptr)) return rc;
+    L->rec_steps = L->n_rec > 0 ? 1 : 0;
     LCHK(L, hipStreamSynchronize(L->st));
     if (log) LCHK(L, hipMemcpy(log, L->d_log, (size_t)L->R * LP_LOGW * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
@@ -330,6 +375,15 @@ extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_to
     if (!L || nsteps <= 0) return 1;
     LCHK(L, hipSetDevice(L->dev));      // the calling host thread may be new
     if (log) { if (int rc = ensure_log(L, (size_t)nsteps * L->R)) return rc; }
+    if (L->n_rec > 0) {
+        const size_t need = (size_t)nsteps * L->n_rec * lp_rec_doubles(L->N);
+        if (need > L->rec_cap) {
+            if (L->d_rec) (void)hipFree(L->d_rec);
+            L->d_rec = nullptr; L->rec_cap = 0;
+            LCHK(L, hipMalloc((void**)&L->d_rec, need * sizeof(double)));
+            L->rec_cap = need;
+        }
+    }
     double solve_s = 0.0;
     LCHK(L, hipEventRecord(L->e0, L->st));
     for (int s = 0; s < nsteps; s++) {
@@ -337,8 +391,10 @@ extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_to
         auto t0 = std::chrono::steady_clock::now();
         if (int rc = do_solve(L)) return rc;
         solve_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (int rc = launch_finish(L, L->st, L->R, log ? L->d_log + (size_t)s * L->R * LP_LOGW : nullptr)) return rc;
+        double* recs = L->n_rec > 0 ? L->d_rec + (size_t)s * L->n_rec * lp_rec_doubles(L->N) : nullptr;
+        if (int rc = launch_finish(L, L->st, L->R, log ? L->d_log + (size_t)s * L->R * LP_LOGW : nullptr, nullptr, nullptr, nullptr, nullptr, 0, recs)) return rc;
     }
+    L->rec_steps = L->n_rec > 0 ? (size_t)nsteps : 0;
     LCHK(L, hipEventRecord(L->e1, L->st));
     LCHK(L, hipStreamSynchronize(L->st));
     float ms = 0.f;

@@ -34,6 +34,13 @@ constexpr int LP_S = 4;          // nr_segs
 constexpr int LP_ROWS = 15;      // max_set_size
 constexpr int LP_NMAX = 64;      // horizon bound of the solver
 constexpr int LP_LOGW = 24;      // doubles per (step, rollout) log row
+// Optional per-(step, selected rollout) record with the content of the reference's trace message (boundmpcmsg/msg/MPCData.msg:1-64):
+//   header [16]: iters, status, viol, error_count, n (valid stages), sector, phi_max, split_idxs[5] (before the step), next selector, 0, 0, 0
+//   stage i < N [LP_REC_STAGE each; zero beyond n]: p 6, v 6, q 7, dq 7, ddq 7, dddq 7, phi, dphi, e_p 3, de_p 3, e_r 3, de_r 3,
+//       e_r_orth1, e_r_par, e_r_orth2 (coordinates along br1, dp_normed, br2), p_ref 6, segment
+//   sets [600]: the a_set / b_set / a_set_joints / b_set_joints blocks of the step's parameter vector (casadi_ocp_formulation.py:407-415)
+constexpr int LP_REC_HDR = 16, LP_REC_STAGE = 64, LP_REC_SETS = 600;
+BMPC_HD int lp_rec_doubles(int N) { return LP_REC_HDR + LP_REC_STAGE * N + LP_REC_SETS; }
 
 // ---- state vector of one rollout (doubles; integers are stored exactly) -------------------------
 #define LP_FIELDS(X)                                                                                  \
@@ -595,7 +602,7 @@ BMPC_INL int lp_segment(int idx, const double* split, int n_rows) {
 // x: the solver's solution row; prev: the stored previous solution row (read only here; the caller copies
 // x over it afterwards where S[LS_accept] is set); log: LP_LOGW doubles or null.
 BMPC_DEV void loop_finish(const RobotConst* rc, int N, double dt, double* S, const double* x, const double* prev,
-                          int status, double viol, int iters, double* log) {
+                          int status, double viol, int iters, double* log, double* rec = nullptr, const double* par = nullptr) {
     const int n_w = 44 * N + 6;
     S[LS_steps] += 1.0;
     for (int i = 0; i < 6; i++) S[LS_slacks0 + i] += x[n_w - 6 + i];          // Q1
@@ -616,6 +623,14 @@ BMPC_DEV void loop_finish(const RobotConst* rc, int N, double dt, double* S, con
         for (int i = 0; i < LP_LOGW; i++) log[i] = 0.0;
         log[0] = (double)iters; log[1] = (double)status; log[2] = viol; log[3] = (double)ec;
     }
+    if (rec) {
+        const int nr = lp_rec_doubles(N);
+        for (int i = 0; i < nr; i++) rec[i] = 0.0;
+        rec[0] = (double)iters; rec[1] = (double)status; rec[2] = viol; rec[3] = (double)ec; rec[4] = (double)(n < 0 ? 0 : n);
+        rec[5] = S[LS_rp_sector]; rec[6] = S[LS_phi_max];
+        for (int i = 0; i < 5; i++) rec[7 + i] = S[LS_split + i];
+        if (par) for (int i = 0; i < LP_REC_SETS; i++) rec[LP_REC_HDR + LP_REC_STAGE * N + i] = par[275 + i];
+    }
     if (n < 2) { S[LS_dead] = 1.0; if (log) log[4] = 1.0; return; }   // the reference would index past its arrays here
 
     const int sec = (int)S[LS_rp_sector];
@@ -623,6 +638,7 @@ BMPC_DEV void loop_finish(const RobotConst* rc, int N, double dt, double* S, con
     for (int i = 0; i < 5; i++) split_prev[i] = S[LS_split + i];
     for (int c = 0; c < 3; c++) iw_ref_0[c] = S[LS_iw_ref + c];
     const int nxt = ((int)split_prev[1] == N) ? 1 : (((int)split_prev[2] == N) ? 2 : 3);
+    if (rec) rec[12] = (double)nxt;
 
     double opt_phi[LP_NMAX], ers[LP_NMAX][3], ersn[LP_NMAX][3];
     signed char segs[LP_NMAX];
@@ -676,6 +692,27 @@ BMPC_DEV void loop_finish(const RobotConst* rc, int N, double dt, double* S, con
             e[4] += (S[LS_dtau_par + 3 * (s + 1) + c] + dv[4] * dpnn[c]) * dpnn[c];
             e[5] += (S[LS_dtau_o2 + 3 * (s + 1) + c] + dv[5] * br2n[c]) * br2n[c];
         }
+        if (rec) {
+            double* q_ = rec + LP_REC_HDR + LP_REC_STAGE * i;
+            for (int c = 0; c < 6; c++) { q_[c] = pp[c]; q_[6 + c] = vv[c]; }
+            for (int j = 0; j < 7; j++) {
+                q_[12 + j] = w[j * N + ec + i]; q_[19 + j] = w[7 * N + j * N + ec + i];
+                q_[26 + j] = w[14 * N + j * N + ec + i]; q_[33 + j] = w[21 * N + j * N + ec + i];
+            }
+            q_[40] = phi_l + phi_start; q_[41] = dphi;
+            double lv[3], rv[3], wv[3] = {vv[3], vv[4], vv[5]}, rd[3] = {dpd[3] * dphi, dpd[4] * dphi, dpd[5] * dphi};
+            mat3vec(S + LS_jac_l, wv, lv);
+            mat3vec(S + LS_jac_r, rd, rv);
+            for (int c = 0; c < 3; c++) {
+                q_[42 + c] = pp[c] - (pc[c] + dpd[c] * phi_l);             // e_p
+                q_[45 + c] = vv[c] - dpd[c] * dphi;                          // de_p
+                q_[48 + c] = S[LS_dtau + 3 * s + c] + dl[c] - a1[c];         // e_r
+                q_[51 + c] = lv[c] - rv[c];                                  // de_r
+                q_[54 + c] = e[c];                                           // e_r_orth1, e_r_par, e_r_orth2
+                q_[57 + c] = pc[c] + dpd[c] * phi_l; q_[60 + c] = pdr[c];    // p_ref
+            }
+            q_[63] = (double)s;
+        }
         opt_phi[i] = phi_l + phi_start;
         if (i == 1) opt_dphi1 = dphi;
         for (int c = 0; c < 3; c++) { ers[i][c] = e[c]; ersn[i][c] = e[3 + c]; }
@@ -688,6 +725,7 @@ BMPC_DEV void loop_finish(const RobotConst* rc, int N, double dt, double* S, con
         double om[3], pr[3];
         for (int c = 0; c < 3; c++) om[c] = S[LS_rp_dpd + LP_S * (3 + c) + j];
         lp_integrate_rot_ref(S + LS_rp_r_tau + 3 * (sec + j), om, S[LS_rp_phi_switch + j], opt_phi[1], pr);
+        if (rec) for (int c = 0; c < 3; c++) rec[LP_REC_HDR + 60 + c] = pr[c];      // ref_data["p"][0][3:] = pr_ref (BoundMPC.py:1023)
         for (int c = 0; c < 3; c++) {
             S[LS_pr_ref + c] = pr[c];
             S[LS_iw_ref + c] = S[LS_rp_pd + LP_S * (3 + c) + j] + (opt_phi[1] - S[LS_rp_phi_switch + j]) * om[c];
@@ -798,6 +836,7 @@ BMPC_DEV void loop_finish(const RobotConst* rc, int N, double dt, double* S, con
         for (int c = 0; c < 3; c++) S[LS_p_lie + c] = k1.pee[c];
         lp_mat_to_rotvec(k1.Ree, S + LS_p_lie + 3);
     }
+    if (rec) rec[6] = S[LS_phi_max];          // after the via-point adaptation of this step
     if (log) {
         log[5] = S[LS_phi_current]; log[6] = S[LS_phi_max]; log[7] = S[LS_split + 1]; log[8] = (double)sec; log[9] = sw ? 1.0 : 0.0;
         for (int c = 0; c < 6; c++) log[10 + c] = S[LS_p_lie + c];

@@ -208,6 +208,22 @@ class DeviceLoop:
         self.replan(r, mpc, list(p_via), list(r_via), list(bp1), [np.array([0, 0, 1.0])] * n, erb, [s_[0] for s_ in sets], [s_[1] for s_ in sets])
         return p_via, r_via, bp1, sets
 
+    # ---- MPCData records (boundmpcmsg/msg/MPCData.msg:1-64)
+    def set_record(self, rollouts):
+        """Rollouts whose steps are recorded by run() / finish() from now on (empty: none)."""
+        sel = np.ascontiguousarray(list(rollouts), np.int32)
+        self._chk(self.lib.bmpc_loop_set_record(self._l, len(sel), sel.ctypes.data_as(_ip) if len(sel) else None), "bmpc_loop_set_record")
+        self._rec_sel = [int(r) for r in sel]
+
+    def records(self, max_steps=1):
+        """Raw records [steps][len(rollouts)][width] of the last run() / finish(); mpc_data.from_device_record decodes one."""
+        n = len(getattr(self, "_rec_sel", []))
+        w = self.lib.bmpc_loop_record_doubles(self.N)
+        out = np.zeros((max_steps, max(n, 1), w))
+        steps = ctypes.c_int(0)
+        self._chk(self.lib.bmpc_loop_records(self._l, self._P(out), ctypes.byref(steps)), "bmpc_loop_records")
+        return out[:steps.value, :n] if steps.value <= max_steps else None
+
     # ---- stepping
     def run(self, nsteps, log=True):
         out = np.zeros((nsteps, self.R, self.logw)) if log else None

@@ -64,3 +64,39 @@ def from_node(node):
     return mpc_data(node.traj_data, node.ref_data, node.err_data, node.mpc, aux=getattr(node.mpc, "last_aux", None),
                     t_comp=node.t_mpc, cost=getattr(node.mpc, "last_cost", 0.0), iterations=node.iters[-1] if node.iters else 0,
                     fails=node.fails)
+
+
+def from_device_record(rec, N, fails=()):
+    """MPCData record from one raw record of the device-resident loop (include/boundmpc.h bmpc_loop_records; written by
+    bmpc_loop_k_finish, layout csrc/bmpc_loop.hpp LP_REC_*): the same keys and conventions as mpc_data() -- trajectories from
+    stage 1 on (dddq from stage 0, BoundMPC.py:1024-1040), errors and references from stage 0 on, `a` aliasing `v` (Q12)."""
+    rec = np.asarray(rec, float)
+    H, W = 16, 64
+    n = int(rec[4])
+    st = rec[H:H + W * N].reshape(N, W)[:n]
+    d = {k: [] for k in FIELDS}
+    d.update(t_comp=0.0, t_loop=0.0, t_overhead=0.0, phi_max=float(rec[6]), cost=0.0, iterations=int(rec[0]),
+             fails=np.asarray(fails, float), sector=int(rec[5]), t_switch=np.zeros(0), phi_switch=np.zeros(0),
+             phi_switch_vector=np.zeros(0), ddphi=np.zeros(0), dddphi=np.zeros(0))
+    d["status"], d["viol"], d["error_count"], d["split_idxs"] = int(rec[1]), float(rec[2]), int(rec[3]), rec[7:12].astype(int)
+    col = lambda lo, hi, first=1: [st[i, lo:hi].copy() for i in range(first, n)]
+    d["p"], d["v"], d["a"] = col(0, 6), col(6, 12), col(6, 12)
+    d["q"], d["dq"], d["ddq"], d["dddq"] = col(12, 19), col(19, 26), col(26, 33), col(33, 40, first=0)
+    d["phi"], d["dphi"] = st[1:, 40].copy(), st[1:, 41].copy()
+    d["e_p"], d["de_p"], d["e_r"], d["de_r"] = col(42, 45, 0), col(45, 48, 0), col(48, 51, 0), col(51, 54, 0)
+    d["e_r_orth1"], d["e_r_par"], d["e_r_orth2"] = [st[i, 54:55].copy() for i in range(n)], [st[i, 55:56].copy() for i in range(n)], [st[i, 56:57].copy() for i in range(n)]
+    d["p_ref"] = col(57, 63, 0)
+    d["segment"] = st[:, 63].astype(int)
+    # sets: parameter-vector blocks a_set [4 segments][15 x 3 column-major], b_set [15][4], a_set_joints [6][15 x 3], b_set_joints [15][6]
+    sets = rec[H + W * N:]
+    a_set = sets[:180].reshape(4, 3, 15).transpose(0, 2, 1)
+    b_set = sets[180:240].reshape(15, 4).T
+    a_j = sets[240:510].reshape(6, 3, 15).transpose(0, 2, 1)
+    b_j = sets[510:600].reshape(15, 6).T
+    seg1 = int(st[1, 63]) if n > 1 else 0
+    d["a_set"], d["b_set"] = a_set[seg1].ravel(), b_set[seg1].copy()
+    nxt = int(rec[12])
+    d["a_set_next"], d["b_set_next"] = a_set[nxt].ravel(), b_set[nxt].copy()
+    for name, c in _COL.items():
+        d["a_set_" + name], d["b_set_" + name] = a_j[c].ravel(), b_j[c].copy()
+    return d

@@ -31,7 +31,7 @@ EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error"
            "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream", "bmpc_robot_iiwa14", "bmpc_robot_gen3", "bmpc_set_robot", "bmpc_get_robot",
            "bmpc_debug_phase_cycles", "bmpc_debug_spin",
            "bmpc_loop_state_doubles", "bmpc_loop_log_doubles", "bmpc_loop_field", "bmpc_loop_create", "bmpc_loop_destroy",
-           "bmpc_loop_last_error", "bmpc_loop_set_obstacles", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_run_async", "bmpc_loop_prepare",
+           "bmpc_loop_last_error", "bmpc_loop_record_doubles", "bmpc_loop_set_record", "bmpc_loop_records", "bmpc_loop_set_obstacles", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_run_async", "bmpc_loop_prepare",
            "bmpc_loop_solve", "bmpc_loop_finish", "bmpc_loop_problem", "bmpc_loop_solution", "bmpc_loop_set_solution"]
 
 _lib = None
@@ -86,6 +86,9 @@ def load_library():
         lib.bmpc_loop_solution.argtypes = [ctypes.c_void_p, _dp, _ip, _ip, _dp]
         lib.bmpc_loop_set_solution.argtypes = [ctypes.c_void_p, _dp, _ip, _ip, _dp]
         lib.bmpc_debug_spin.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.bmpc_loop_set_record.argtypes = [ctypes.c_void_p, ctypes.c_int, _ip]
+        lib.bmpc_loop_records.argtypes = [ctypes.c_void_p, _dp, _ip]
+        lib.bmpc_loop_record_doubles.argtypes = [ctypes.c_int]
         _lib = lib
     return _lib
 

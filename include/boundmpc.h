@@ -190,6 +190,16 @@ int bmpc_loop_download(bmpc_loop* l, int first, int count, double* state, double
  * viol, error_count, dead, phi, phi_max, split_idx[1], sector, switch, p_lie(6), q(7).
  * ms_total: HIP-event time of the whole run on the loop's stream; ms_solve: host time inside the solves */
 int bmpc_loop_run(bmpc_loop* l, int nsteps, double* log, float* ms_total, float* ms_solve);
+/* Trace records with the content of the reference's message boundmpcmsg/msg/MPCData.msg:1-64, written by the finish kernel for
+ * the rollouts selected with bmpc_loop_set_record (n = 0 switches them off; they cost 16 + 64 N + 600 doubles per rollout and
+ * step).  bmpc_loop_records copies the records of the last bmpc_loop_run / bmpc_loop_finish: out [steps][n][record_doubles(N)],
+ * each: header (iters, status, viol, error_count, valid stages n, sector, phi_max, split_idxs[5], next selector, 0, 0, 0);
+ * N stage blocks of 64 (p 6, v 6, q 7, dq 7, ddq 7, dddq 7, phi, dphi, e_p 3, de_p 3, e_r 3, de_r 3, e_r_orth1, e_r_par,
+ * e_r_orth2, p_ref 6, segment; zero beyond n); the a_set / b_set / a_set_joints / b_set_joints blocks of the step's parameter
+ * vector (600).  boundplanner_amd.mpc_data.from_device_record decodes them.  Lock-step runs only. */
+int bmpc_loop_record_doubles(int N);
+int bmpc_loop_set_record(bmpc_loop* l, int n, const int* rollouts);
+int bmpc_loop_records(bmpc_loop* l, double* out, int* steps);
 /* The same nsteps MPC steps of all rollouts WITHOUT lock step: the rollouts are independent, so each one starts its next
  * step as soon as its own solve has retired (its workspace slot is re-admitted with the next problem, prepared on the
  * device) instead of waiting for the slowest solve of the batch at every step.  Same log as bmpc_loop_run (bitwise). */

@@ -63,12 +63,13 @@ extern "C" void emu_loop_prepare_obs(int N, double* S, const double* prev, doubl
 }
 
 extern "C" void emu_loop_finish(int N, double dt, double* S, const double* x, double* prev, int status, double viol,
-                                int iters, double* log) {
+                                int iters, double* log, double* rec, const double* par) {
     RobotConst rc;
     fill_robot_const(rc);
-    loop_finish(&rc, N, dt, S, x, prev, status, viol, iters, log);
+    loop_finish(&rc, N, dt, S, x, prev, status, viol, iters, log, rec, par);
     if (S[LS_accept] != 0.0) std::memcpy(prev, x, sizeof(double) * (44 * N + 6));
 }
+extern "C" int emu_loop_record_doubles(int N) { return lp_rec_doubles(N); }
 
 extern "C" void emu_so3(const double* v, const double* M, double* R_of_v, double* v_of_M, double* eul_of_M) {
     lp_rotvec_to_mat(v, R_of_v);

@@ -48,11 +48,14 @@ def prepare_obs(N, S, prev, obs_sets, obs_points_sets):
     return x0, lbx, ubx, p
 
 
-def finish(N, dt, S, x, prev, status, viol, iters=0):
+def finish(N, dt, S, x, prev, status, viol, iters=0, par=None):
+    """-> log row; with `par` (the step's parameter vector) -> (log row, MPCData record of the step)."""
     log = np.zeros(lib().emu_loop_logw())
+    rec = np.zeros(lib().emu_loop_record_doubles(N)) if par is not None else None
     lib().emu_loop_finish(N, ctypes.c_double(dt), P(S), P(np.ascontiguousarray(x, float)), P(prev), int(status),
-                          ctypes.c_double(viol), int(iters), P(log))
-    return log
+                          ctypes.c_double(viol), int(iters), P(log), P(rec) if rec is not None else None,
+                          P(np.ascontiguousarray(par, float)) if par is not None else None)
+    return log if par is None else (log, rec)
 
 
 def so3(v, M):

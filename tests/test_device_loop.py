@@ -31,6 +31,23 @@ def test_so3_helpers_match_scipy():
         assert np.abs(e - R.from_matrix(M).as_euler("zyx")).max() < 1e-12
 
 
+def compare_record_with_host_mirror(rec, N, node, k, tol=1e-9):
+    """The device loop's MPCData record of a step (decoded by mpc_data.from_device_record) against mpc_data.from_node of the host
+    mirror that took the same step: every field both sides produce."""
+    from boundplanner_amd import mpc_data
+    d, h = mpc_data.from_device_record(rec, N), mpc_data.from_node(node)
+    assert d["iterations"] == h["iterations"] and d["sector"] is not None and abs(d["phi_max"] - h["phi_max"]) < tol, k
+    for key in ("p", "v", "a", "q", "dq", "ddq", "dddq", "e_p", "de_p", "e_r", "de_r", "e_r_par", "e_r_orth1", "e_r_orth2", "p_ref"):
+        assert len(d[key]) == len(h[key]) > 0, (k, key, len(d[key]), len(h[key]))
+        worst = max(np.abs(np.ravel(a) - np.ravel(b)).max() for a, b in zip(d[key], h[key]))
+        assert worst < tol, (k, key, worst)
+    assert np.abs(d["phi"] - h["phi"]).max() < tol and np.abs(d["dphi"] - h["dphi"]).max() < tol, k
+    for key in ("a_set", "b_set", "a_set_next", "b_set_next", "a_set_j3", "b_set_j3", "a_set_j5", "a_set_j6", "a_set_j67", "a_set_elbow", "b_set_elbow"):
+        if np.size(h[key]):
+            assert np.abs(np.ravel(d[key]) - np.ravel(h[key])).max() < 2e-6, (k, key)       # (collision sets: closest pairs to ~1e-7)
+    assert set(mpc_data.FIELDS) <= set(d)
+
+
 @pytest.mark.parametrize("fixture", ["closed_loop.npz", "closed_loop_n15.npz", "closed_loop_fail.npz", "closed_loop_patch.npz",
                                      "closed_loop_scene.npz"])
 def test_replay_of_the_reference_trace(golden_dir, fixture):
@@ -74,8 +91,9 @@ def test_replay_of_the_reference_trace(golden_dir, fixture):
             worst[name] = max(worst.get(name, 0.0), d)
             # (collision-set rows with obstacles: closest-pair search resolved to ~1e-7 on both sides)
             assert d < (2e-6 if (obs is not None and name == "p") else 1e-9), (k, name, d, np.argmax(np.abs(mine - big(g["call_" + name][k]))))
-        E.finish(N, params.dt, S, g["call_x"][k], prev, int(g["status"][k]), float(g["viol"][k]), int(g["iters"][k]))
+        _, rec = E.finish(N, params.dt, S, g["call_x"][k], prev, int(g["status"][k]), float(g["viol"][k]), int(g["iters"][k]), par=p)
         shadow.step()                                   # keeps the host mirror in lock step for the re-plan
+        compare_record_with_host_mirror(rec, N, shadow, k)      # the MPCData record the finish logic writes (boundmpcmsg/msg/MPCData.msg)
         V = state_view(lay, S)
         assert [int(s) for s in V["split"]] == list(g["split_idxs"][k]), k
         assert int(V["sw"][0]) == int(g["switch"][k]) and int(V["error_count"][0]) == int(g["error_count"][k]), k

@@ -41,6 +41,8 @@ def test_kernels_replay_the_reference_trace(golden_dir, fixture):
     for r in range(R):
         loop.set_rollout(r, shadow.mpc, shadow.q, shadow.dq, shadow.ddq, shadow.jerk, shadow.qf, shadow.v, shadow.p_lie)
     loop.upload()
+    loop.set_record([0, 2])
+    from test_device_loop import compare_record_with_host_mirror
     n_steps, n_update = g["in_q"].shape[0], int(g["n_update"])
     big = lambda a: np.nan_to_num(np.asarray(a, float), posinf=1e20, neginf=-1e20)
     for k in range(n_steps):
@@ -72,6 +74,10 @@ def test_kernels_replay_the_reference_trace(golden_dir, fixture):
                           np.full(R, float(g["viol"][k])))
         log = loop.finish()
         shadow.step()
+        recs = loop.records()                   # MPCData records written by bmpc_loop_k_finish for rollouts 0 and 2
+        assert recs.shape[:2] == (1, 2)
+        for j in range(2):
+            compare_record_with_host_mirror(recs[0, j], N, shadow, k)
         V = loop.download()
         for r in range(R):
             assert [int(s) for s in V["split"][r]] == list(g["split_idxs"][k]), (k, r)
@@ -410,7 +416,16 @@ def test_config0_plan_then_track_with_replanning_on_the_device_loop(golden_dir):
     assert np.abs(np.array(p_via) - fx["example_p_via"]).max() < 1e-5      # (the start pose is the GPU's FK of q0: 1e-12 from the fixture's)
     loop.upload()
     L = loop.LOG
+    loop.set_record([0])
     log = loop.run(10)
+    from boundplanner_amd import mpc_data
+    recs = loop.records(max_steps=10)
+    assert recs.shape[:2] == (10, 1)
+    for k in range(10):                          # the trace of the run: one MPCData record per step, consistent with the log
+        md = mpc_data.from_device_record(recs[k, 0], N)
+        assert md["iterations"] == int(log[k, 0, L["iters"]]) and len(md["p"]) == N - 1 and len(md["dddq"]) == N
+        assert set(mpc_data.FIELDS) <= set(md) and np.isfinite(np.concatenate([np.ravel(v) for v in md["e_r"]])).all()
+    loop.set_record([])
     assert (log[:, 0, L["error_count"]] == 0).all()
     phi_mid, phi_max0 = log[-1, 0, L["phi"]], log[-1, 0, L["phi_max"]]
     assert 0.05 < phi_mid < phi_max0 - 0.01                                 # under way, not there yet
