@@ -122,6 +122,7 @@ def main():
                     "the timed batches are handed over in `depth` solver calls, each streaming its instances through the pool "
                     "(a slot whose instance has finished takes the next one: one straggler tail per call, hidden behind the "
                     "other call).  0: every call holds all its instances (`merge` batches), `depth` calls in flight")
+    ap.add_argument("--opt", action="append", default=[], help="solver option key=value (bmpc_opts field), A/B runs")
     ap.add_argument("--same-batch", action="store_true", help="every step solves the seed-8192 batch (profiling passes)")
     ap.add_argument("--gen-workers", type=int, default=None, help="processes building problem instances (0: in this process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -169,6 +170,9 @@ def main():
     from boundplanner_amd.solver import HipBoundMPC
 
     kw = {} if args.hess is None else {"hess": args.hess}
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        kw[k_] = float(v_) if ("." in v_ or "e" in v_) else int(v_)
     if args.pool > 0:
         kw["pool_slots"] = args.pool
     bes = [HipBoundMPC(N, device=local_rank, max_batch=min(M * B, args.pool) if args.pool > 0 else M * B, **kw) for _ in range(depth)]

@@ -122,7 +122,7 @@ struct BusyGuard {
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
     o->hess = 2; o->hess_switch = 1.0; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->mu_floor_k = 1e4; o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->gn_backoff = 2; o->slack_reset = 1;
+    o->mu_floor_k = 1e4; o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->gn_backoff = 2; o->slack_reset = 1; o->ls_alpha_mem = 0.0;
     o->max_batch = 0; o->pool_slots = 0; o->watchdog_ms = 30000;
 }
 
@@ -291,7 +291,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.B = B; A.N = N;
     A.o = SolverOpts{N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,
                      h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps,
-                     h->o.mu_floor_k, h->o.dw0, h->o.inertia_err, h->o.inertia, h->o.stall_n, h->o.gn_backoff, h->o.slack_reset};
+                     h->o.mu_floor_k, h->o.dw0, h->o.inertia_err, h->o.ls_alpha_mem, h->o.inertia, h->o.stall_n, h->o.gn_backoff, h->o.slack_reset};
     A.rc = h->d_rc;
     A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
     A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;

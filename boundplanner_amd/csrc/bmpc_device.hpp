@@ -44,7 +44,7 @@ struct SolverOpts {
     int max_iter;
     int hess;                 // 0 Gauss-Newton, 2 hybrid (second-order kinematic terms when convex)
     double hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps;
-    double mu_floor_k, dw0, inertia_err;     // include/boundmpc.h bmpc_opts
+    double mu_floor_k, dw0, inertia_err, ls_alpha_mem;     // include/boundmpc.h bmpc_opts
     int inertia, stall_n, gn_backoff, slack_reset;
 };
 

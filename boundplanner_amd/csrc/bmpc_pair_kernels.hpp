@@ -971,7 +971,9 @@ BMPC_INL void ls0_instance(const PipeArgs& A, int b) {
     st->phi0 = st->f0 - st->mu * st->ls0;
     if (st->it == 0) { st->theta_max = 1e4 * fmax(1.0, st->th0); st->theta_min = 1e-4 * fmax(1.0, st->th0); }
     if (st->mu != st->filt_mu) { st->nfilt = 0; st->filt_mu = st->mu; }
-    st->alpha = ap; st->bt = 0; st->armijo = 0;
+    // the search starts at ls_alpha_mem times the step length the previous iteration ended with (still in st->alpha)
+    st->alpha = (A.o.ls_alpha_mem > 0 && st->it > 0) ? fmin(ap, A.o.ls_alpha_mem * st->alpha) : ap;
+    st->bt = 0; st->armijo = 0;
     st->state = ST_TRIAL;
     int pos = BMPC_ATOMIC_INC(A.L.cnt + 2);
     A.L.trial[pos] = b;
@@ -1006,6 +1008,7 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
             st->nfilt = nf + 1;
         }
         st->f0 = f1; st->th0 = th1; st->ls0 = ls1;      // merit pieces of the accepted point
+        if (!acc) st->alpha = 1e300;                     // no acceptable step found (the last trial is kept): no step-length memory
         st->flip ^= 1;                                   // the trial copy of t / zeta is the iterate now (cur_t, cur_zeta)
         st->it += 1;
         // the exact Hessian close to a solution, or when the Gauss-Newton model has stopped making progress

@@ -47,6 +47,7 @@ typedef struct {
     int stall_n;      /* 8 */
     int gn_backoff;   /* 2: after a Gauss-Newton fallback the exact Hessian is tried again after 1, then 2 iterations (0: every iteration) */
     int slack_reset;  /* 1: trial slacks t <- max(t + alpha dt, -h(trial point)) (0: round 2) */
+    double ls_alpha_mem; /* m > 0: the line search starts at min(fraction-to-boundary length, m x the previous iteration's step length); 0 (default): off */
     double mu_floor_k; /* a barrier decrease stops at (scaled optimality error) / mu_floor_k; 0 = off (round 2); default 1e4 */
 } bmpc_oracle_opts;
 

@@ -32,7 +32,7 @@
 #include "bmpc_internal.h"
 
 static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-long bmpc_dbg_iters = 0, bmpc_dbg_sweeps = 0, bmpc_dbg_retry_iters = 0;   /* diagnostics (not thread-exact) */
+long bmpc_dbg_iters = 0, bmpc_dbg_sweeps = 0, bmpc_dbg_retry_iters = 0, bmpc_dbg_trials = 0;   /* diagnostics (not thread-exact) */
 
 #define NX 32
 #define NU 9
@@ -108,7 +108,7 @@ void bmpc_oracle_default_opts(bmpc_oracle_opts* o, int N) {
     o->mu_strategy = 1;
     o->hess_switch = 1.0;
     o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->mu_floor_k = 1e4; o->gn_backoff = 2; o->slack_reset = 1;
+    o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->mu_floor_k = 1e4; o->gn_backoff = 2; o->slack_reset = 1; o->ls_alpha_mem = 0.0;
 }
 
 /* ---------------------------------------------------------------- small dense helpers */
@@ -1068,6 +1068,7 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
     memset(&kk, 0, sizeof kk);
     double reg = 1e-9, err_prev = 1e300, dw_last = 0.0, err_best = 1e300;
     int gn_skip = 0, gn_back = 0;
+    double alpha_last = 1e300;
     int stall = 0;                   /* iterations since the optimality error last improved (by 10 %) */
     for (it = 0;; it++) {
         /* gdual needs current z: assemble with a provisional mu (only H,g depend on mu) */
@@ -1217,6 +1218,10 @@ for (int k = 1; k < N; k++) {
         if (mu != filt_mu) { nfilt = 0; filt_mu = mu; }   /* the barrier objective changed */
         /* filter line search (Waechter & Biegler 2006, Sec. 2.3, without SOC/restoration) */
         double alpha = ap;
+        /* the line search starts at ls_alpha_mem times the step length the previous iteration ended with (capped by the
+         * fraction-to-boundary length): an iterate that needed six halvings is unlikely to take a full step next time, and every
+         * rejected trial is an evaluation pass (a super-step on the GPU).  0: always from the fraction-to-boundary length (IPOPT) */
+        if (o->ls_alpha_mem > 0 && it > 0) alpha = fmin(ap, o->ls_alpha_mem * alpha_last);
         int ls_ok = 0, armijo_case = 0;
         double* save = (double*)malloc(sizeof(double) * N * (NZ + MAXROWS));
         for (int k = 1; k < N; k++) {
@@ -1224,11 +1229,28 @@ for (int k = 1; k < N; k++) {
             memcpy(save + k * (NZ + MAXROWS) + NZ, pb.st[k].t, sizeof(double) * MAXROWS);
         }
         for (int bt = 0; bt < 10; bt++) {
+            bmpc_dbg_trials++;
             for (int k = 1; k < N; k++) {
                 stage_t* s = &pb.st[k];
                 const double* sv = save + k * (NZ + MAXROWS);
                 for (int i = 0; i < NZ; i++) s->zeta[i] = sv[i] + alpha * s->dzeta[i];
                 for (int i = 0; i < s->nrows; i++) s->t[i] = sv[NZ + i] + alpha * s->dt_[i];
+            }
+            if (getenv("PI_SHOOT")) {
+                /* the rotation-integral state follows its (nonlinear) dynamics exactly at every trial point: pi_{k+1} = pi_k + dt w(q_k, dq_k) */
+                for (int k = 1; k < N - 1; k++) {
+                    stage_t* s = &pb.st[k];
+                    double y[NZ], J[6][7];
+                    bmpc_kin kin;
+                    zeta_to_y(&pb, s->zeta, y);
+                    bmpc_kin_eval(y + Y_Q, &kin);
+                    bmpc_kin_jac(&kin, J);
+                    for (int a = 0; a < 3; a++) {
+                        double om = 0;
+                        for (int j = 0; j < 7; j++) om += J[3 + a][j] * y[Y_DQ + j];
+                        pb.st[k + 1].zeta[Z_PI + a] = s->zeta[Z_PI + a] + dt * om;
+                    }
+                }
             }
             for (int i = 0; i < 24; i++) pb.r0[i] = pb.x1fix[i] - pb.st[1].zeta[i];
             for (int k = N - 1; k >= 1; k--) eval_stage(&pb, k, 1);
@@ -1260,6 +1282,7 @@ for (int k = 1; k < N; k++) {
             alpha *= 0.5;
         }
         free(save);
+        if (!ls_ok) alpha *= 2.0;                /* (the last trial, which is kept) */
         if (!armijo_case) { /* augment the filter with the current point */
             if (nfilt == MAXFILT) { memmove(filt_th, filt_th + 1, sizeof(double) * (MAXFILT - 1)); memmove(filt_phi, filt_phi + 1, sizeof(double) * (MAXFILT - 1)); nfilt--; }
             filt_th[nfilt] = (1 - 1e-5) * th0;
@@ -1277,6 +1300,7 @@ for (int k = 1; k < N; k++) {
             eval_stage(&pb, k, 0);
         }
         err_prev = kk.err;
+        alpha_last = ls_ok ? alpha : 1e300;      /* a search that found no acceptable step leaves no memory */
         pb.hreg = 0.0;                       /* the next iteration's model starts without a correction */
         if (kk.err < 0.9 * err_best) { err_best = kk.err; stall = 0; } else stall++;
         if (o->verbose > 1 && lim_k > 0) {
