@@ -49,6 +49,10 @@ typedef struct {
     int slack_reset;  /* 1: trial slacks t <- max(t + alpha dt, -h(trial point)) (0: round 2) */
     double ls_alpha_mem; /* m > 0: the line search starts at min(fraction-to-boundary length, m x the previous iteration's step length); 0 (default): off */
     double mu_floor_k; /* a barrier decrease stops at (scaled optimality error) / mu_floor_k; 0 = off (round 2); default 1e4 */
+    /* oracle-only experiment switches (measured in DESIGN.md 2.2, no gain, so the kernels do not mirror them); all default 0 */
+    int soc;           /* second-order corrections per iteration after a rejected first trial that raised theta (IPOPT: 4) */
+    int soc_after;     /* ... only from this iteration on */
+    int pi_shoot;      /* 1: the rotation-integral state follows its nonlinear dynamics exactly at every trial point */
 } bmpc_oracle_opts;
 
 void bmpc_oracle_default_opts(bmpc_oracle_opts* o, int N);

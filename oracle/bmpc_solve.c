@@ -32,6 +32,8 @@
 #include "bmpc_internal.h"
 
 static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+/* diagnostic counters over all solves of the process (not thread-exact): the pass counts quoted in DESIGN.md 2.2 */
+long bmpc_dbg_soc_try = 0, bmpc_dbg_soc_acc = 0, bmpc_dbg_soc_pass = 0;
 long bmpc_dbg_iters = 0, bmpc_dbg_sweeps = 0, bmpc_dbg_retry_iters = 0, bmpc_dbg_trials = 0;   /* diagnostics (not thread-exact) */
 
 #define NX 32
@@ -109,6 +111,7 @@ void bmpc_oracle_default_opts(bmpc_oracle_opts* o, int N) {
     o->hess_switch = 1.0;
     o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
     o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->mu_floor_k = 1e4; o->gn_backoff = 2; o->slack_reset = 1; o->ls_alpha_mem = 0.0;
+    o->soc = 0; o->soc_after = 0; o->pi_shoot = 0;
 }
 
 /* ---------------------------------------------------------------- small dense helpers */
@@ -1223,6 +1226,7 @@ for (int k = 1; k < N; k++) {
          * rejected trial is an evaluation pass (a super-step on the GPU).  0: always from the fraction-to-boundary length (IPOPT) */
         if (o->ls_alpha_mem > 0 && it > 0) alpha = fmin(ap, o->ls_alpha_mem * alpha_last);
         int ls_ok = 0, armijo_case = 0;
+        const int soc_on = o->soc, soc_after = o->soc_after;
         double* save = (double*)malloc(sizeof(double) * N * (NZ + MAXROWS));
         for (int k = 1; k < N; k++) {
             memcpy(save + k * (NZ + MAXROWS), pb.st[k].zeta, sizeof(double) * NZ);
@@ -1236,7 +1240,7 @@ for (int k = 1; k < N; k++) {
                 for (int i = 0; i < NZ; i++) s->zeta[i] = sv[i] + alpha * s->dzeta[i];
                 for (int i = 0; i < s->nrows; i++) s->t[i] = sv[NZ + i] + alpha * s->dt_[i];
             }
-            if (getenv("PI_SHOOT")) {
+            if (o->pi_shoot) {
                 /* the rotation-integral state follows its (nonlinear) dynamics exactly at every trial point: pi_{k+1} = pi_k + dt w(q_k, dq_k) */
                 for (int k = 1; k < N - 1; k++) {
                     stage_t* s = &pb.st[k];
@@ -1279,6 +1283,116 @@ for (int k = 1; k < N; k++) {
                 }
             }
             if (ok) { ls_ok = 1; break; }
+            if (bt == 0 && soc_on && th1 >= th0 && it >= soc_after) {
+                /* second-order correction (Waechter & Biegler 2006, Sec. 2.4 / Algorithm A-5.7-5.9) */
+                const int W = NZ + 2 * MAXROWS;
+                double* dsave = (double*)malloc(sizeof(double) * N * W);
+                double* cs = (double*)malloc(sizeof(double) * N * (MAXROWS + NX));
+                double r0s[24], ad_save = ad;
+                for (int k = 1; k < N; k++) {
+                    stage_t* s = &pb.st[k];
+                    memcpy(dsave + k * W, s->dzeta, sizeof(double) * NZ);
+                    memcpy(dsave + k * W + NZ, s->dt_, sizeof(double) * MAXROWS);
+                    memcpy(dsave + k * W + NZ + MAXROWS, s->dz_, sizeof(double) * MAXROWS);
+                }
+                /* c(x_k): re-linearise at x_k */
+                #define RESTORE_AND_LIN() do { \
+                    for (int k = 1; k < N; k++) { stage_t* s = &pb.st[k]; const double* sv = save + k * (NZ + MAXROWS); \
+                        memcpy(s->zeta, sv, sizeof(double) * NZ); memcpy(s->t, sv + NZ, sizeof(double) * MAXROWS); } \
+                    for (int i = 0; i < 24; i++) pb.r0[i] = pb.x1fix[i] - pb.st[1].zeta[i]; \
+                    for (int k = N - 1; k >= 1; k--) eval_stage(&pb, k, 0); } while (0)
+                /* trial residuals first (the state is at the trial point now) */
+                for (int k = 1; k < N; k++) {
+                    stage_t* s = &pb.st[k];
+                    for (int i = 0; i < s->nrows; i++) cs[k * (MAXROWS + NX) + i] = s->h[i] + s->t[i];
+                    for (int i = 0; i < NX; i++) cs[k * (MAXROWS + NX) + MAXROWS + i] = (k < N - 1) ? s->r[i] : 0.0;
+                }
+                for (int i = 0; i < 24; i++) r0s[i] = pb.r0[i];
+                RESTORE_AND_LIN();
+                for (int k = 1; k < N; k++) {
+                    stage_t* s = &pb.st[k];
+                    for (int i = 0; i < s->nrows; i++) cs[k * (MAXROWS + NX) + i] += alpha * (s->h[i] + s->t[i]);
+                    for (int i = 0; i < NX; i++) cs[k * (MAXROWS + NX) + MAXROWS + i] += (k < N - 1) ? alpha * s->r[i] : 0.0;
+                }
+                for (int i = 0; i < 24; i++) r0s[i] += alpha * pb.r0[i];
+                double th_prev = th0, a_soc = alpha;
+                int accepted = 0;
+                bmpc_dbg_soc_try++;
+                for (int ps = 0; ps < soc_on; ps++) {
+                    bmpc_dbg_soc_pass++;
+                    /* inject c_soc as the residuals of the linearisation at x_k */
+                    for (int k = 1; k < N; k++) {
+                        stage_t* s = &pb.st[k];
+                        for (int i = 0; i < s->nrows; i++) s->h[i] = cs[k * (MAXROWS + NX) + i] - s->t[i];
+                        if (k < N - 1) for (int i = 0; i < NX; i++) s->r[i] = cs[k * (MAXROWS + NX) + MAXROWS + i];
+                    }
+                    for (int i = 0; i < 24; i++) pb.r0[i] = r0s[i];
+                    for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
+                    if (riccati_backward(&pb, reg) || riccati_forward(&pb)) break;
+                    double aps = 1, ads = 1;
+                    for (int k = 1; k < N; k++) {
+                        stage_t* s = &pb.st[k];
+                        double ad_[MAXROWS];
+                        row_dirs(&pb, s, ad_);
+                        for (int i = 0; i < s->nrows; i++) {
+                            double dti = -(s->h[i] + s->t[i]) - ad_[i];
+                            double dzi = (mu - s->t[i] * s->z[i] - s->z[i] * dti) / s->t[i];
+                            s->dt_[i] = dti; s->dz_[i] = dzi;
+                            if (dti < 0) aps = fmin(aps, -tau * s->t[i] / dti);
+                            if (dzi < 0) ads = fmin(ads, -tau * s->z[i] / dzi);
+                        }
+                    }
+                    a_soc = aps;
+                    for (int k = 1; k < N; k++) {
+                        stage_t* s = &pb.st[k];
+                        const double* sv = save + k * (NZ + MAXROWS);
+                        for (int i = 0; i < NZ; i++) s->zeta[i] = sv[i] + a_soc * s->dzeta[i];
+                        for (int i = 0; i < s->nrows; i++) s->t[i] = sv[NZ + i] + a_soc * s->dt_[i];
+                    }
+                    for (int i = 0; i < 24; i++) pb.r0[i] = pb.x1fix[i] - pb.st[1].zeta[i];
+                    for (int k = N - 1; k >= 1; k--) eval_stage(&pb, k, 1);
+                    if (o->slack_reset)
+                        for (int k = 1; k < N; k++) {
+                            stage_t* s = &pb.st[k];
+                            for (int i = 0; i < s->nrows; i++)
+                                if (-s->h[i] > s->t[i]) s->t[i] = -s->h[i];
+                        }
+                    double f2, th2, ls2;
+                    merit_parts(&pb, &f2, &th2, &ls2);
+                    double phi2 = f2 - mu * ls2;
+                    int ok2 = (th2 <= theta_max);
+                    for (int j = 0; ok2 && j < nfilt; j++)
+                        if (th2 >= filt_th[j] && phi2 >= filt_phi[j]) ok2 = 0;
+                    if (ok2) {
+                        int sw = (th0 <= theta_min) && (D < 0) && (alpha * pow(-D, 2.3) > pow(th0, 1.1));
+                        if (sw) { ok2 = (phi2 <= phi0 + 1e-4 * alpha * D + 1e-12 * fabs(phi0)); if (ok2) armijo_case = 1; }
+                        else ok2 = (th2 <= (1 - 1e-5) * th0) || (phi2 <= phi0 - 1e-5 * th0);
+                    }
+                    if (o->verbose) printf("      soc %d: a_soc %.3g th %.3e -> %.3e (th0 %.3e) phi %.6e vs %.6e ok %d\n", ps, a_soc, th_prev, th2, th0, phi2, phi0, ok2);
+                    if (ok2) { accepted = 1; ad = ads; break; }
+                    if (th2 > 0.99 * th_prev) break;
+                    th_prev = th2;
+                    /* next correction: c_soc <- a_soc c_soc + c(x_k + a_soc d_soc) */
+                    for (int k = 1; k < N; k++) {
+                        stage_t* s = &pb.st[k];
+                        for (int i = 0; i < s->nrows; i++) cs[k * (MAXROWS + NX) + i] = a_soc * cs[k * (MAXROWS + NX) + i] + s->h[i] + s->t[i];
+                        if (k < N - 1) for (int i = 0; i < NX; i++) cs[k * (MAXROWS + NX) + MAXROWS + i] = a_soc * cs[k * (MAXROWS + NX) + MAXROWS + i] + s->r[i];
+                    }
+                    for (int i = 0; i < 24; i++) r0s[i] = a_soc * r0s[i] + pb.r0[i];
+                    RESTORE_AND_LIN();
+                }
+                if (!accepted) {
+                    for (int k = 1; k < N; k++) {
+                        stage_t* s = &pb.st[k];
+                        memcpy(s->dzeta, dsave + k * W, sizeof(double) * NZ);
+                        memcpy(s->dt_, dsave + k * W + NZ, sizeof(double) * MAXROWS);
+                        memcpy(s->dz_, dsave + k * W + NZ + MAXROWS, sizeof(double) * MAXROWS);
+                    }
+                    ad = ad_save;
+                }
+                free(dsave); free(cs);
+                if (accepted) { ls_ok = 1; bmpc_dbg_soc_acc++; alpha = a_soc; break; }
+            }
             alpha *= 0.5;
         }
         free(save);

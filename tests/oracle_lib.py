@@ -17,7 +17,8 @@ class Opts(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int), ("dt", ctypes.c_double), ("tol", ctypes.c_double),
                 ("max_iter", ctypes.c_int), ("verbose", ctypes.c_int), ("hess", ctypes.c_int), ("mu_strategy", ctypes.c_int), ("hess_switch", ctypes.c_double), ("mu_init", ctypes.c_double), ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
                 ("inertia", ctypes.c_int), ("dw0", ctypes.c_double), ("inertia_err", ctypes.c_double), ("stall_n", ctypes.c_int),
-                ("gn_backoff", ctypes.c_int), ("slack_reset", ctypes.c_int), ("ls_alpha_mem", ctypes.c_double), ("mu_floor_k", ctypes.c_double)]
+                ("gn_backoff", ctypes.c_int), ("slack_reset", ctypes.c_int), ("ls_alpha_mem", ctypes.c_double), ("mu_floor_k", ctypes.c_double),
+                ("soc", ctypes.c_int), ("soc_after", ctypes.c_int), ("pi_shoot", ctypes.c_int)]
 
 
 def _P(a):
@@ -80,9 +81,9 @@ def gbounds(N):
     return lb, ub
 
 
-def solve(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, verbose=0, hess=2, mu_strategy=1, hess_switch=1.0, mu_init=0.1, kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, inertia=2, dw0=1e-4, inertia_err=1e-2, stall_n=8, mu_floor_k=1e4, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0):
+def solve(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, verbose=0, hess=2, mu_strategy=1, hess_switch=1.0, mu_init=0.1, kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, inertia=2, dw0=1e-4, inertia_err=1e-2, stall_n=8, mu_floor_k=1e4, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0, soc=0, soc_after=0, pi_shoot=0):
     n_w, n_g = 44 * N + 6, 147 * (N - 1) + 21
-    o = Opts(N, dt, tol, max_iter, verbose, hess, mu_strategy, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps, inertia, dw0, inertia_err, stall_n, gn_backoff, slack_reset, ls_alpha_mem, mu_floor_k)
+    o = Opts(N, dt, tol, max_iter, verbose, hess, mu_strategy, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps, inertia, dw0, inertia_err, stall_n, gn_backoff, slack_reset, ls_alpha_mem, mu_floor_k, soc, soc_after, pi_shoot)
     lbx = np.where(np.isinf(lbx), -1e20, lbx); ubx = np.where(np.isinf(ubx), 1e20, ubx)
     x0, lbx, ubx, p = (np.ascontiguousarray(a, float) for a in (x0, lbx, ubx, p))
     x = np.zeros(n_w); g = np.zeros(n_g); lg = np.zeros(n_g); lx = np.zeros(n_w)
@@ -92,9 +93,9 @@ def solve(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, verbose=0, hess=2,
     return dict(x=x, g=g, lam_g=lg, lam_x=lx, f=f.value, iters=it.value, status=st.value, viol=viol.value)
 
 
-def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, nthreads=0, hess=2, mu_strategy=1, hess_switch=1.0, mu_init=0.1, kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, inertia=2, dw0=1e-4, inertia_err=1e-2, stall_n=8, mu_floor_k=1e4, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0):
+def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, nthreads=0, hess=2, mu_strategy=1, hess_switch=1.0, mu_init=0.1, kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, inertia=2, dw0=1e-4, inertia_err=1e-2, stall_n=8, mu_floor_k=1e4, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0, soc=0, soc_after=0, pi_shoot=0):
     B = x0.shape[0]
-    o = Opts(N, dt, tol, max_iter, 0, hess, mu_strategy, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps, inertia, dw0, inertia_err, stall_n, gn_backoff, slack_reset, ls_alpha_mem, mu_floor_k)
+    o = Opts(N, dt, tol, max_iter, 0, hess, mu_strategy, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps, inertia, dw0, inertia_err, stall_n, gn_backoff, slack_reset, ls_alpha_mem, mu_floor_k, soc, soc_after, pi_shoot)
     lbx = np.where(np.isinf(lbx), -1e20, lbx); ubx = np.where(np.isinf(ubx), 1e20, ubx)
     x0, lbx, ubx, p = (np.ascontiguousarray(a, float) for a in (x0, lbx, ubx, p))
     x = np.zeros_like(x0); f = np.zeros(B); viol = np.zeros(B)

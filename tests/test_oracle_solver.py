@@ -57,6 +57,20 @@ def test_batch_statistics_N20():
     assert r["viol"].max() < 1e-4
 
 
+def test_second_order_correction_reaches_the_same_points():
+    """The oracle-only second-order correction of the filter line search (Waechter & Biegler 2006, Sec. 2.4; measured without gain,
+    DESIGN.md 2.2, so the kernels do not mirror it) changes the path, not the destination: same minimisers at a tight tolerance."""
+    N = 10
+    b = scenes.make_batch(12, N, 8192, O.fk_batch, randomize_sets=True)
+    r0 = O.solve_batch(N, b["x0"], b["lbx"], b["ubx"], b["p"], nthreads=4, tol=1e-9, max_iter=200)
+    r1 = O.solve_batch(N, b["x0"], b["lbx"], b["ubx"], b["p"], nthreads=4, tol=1e-9, max_iter=200, soc=4)
+    ok = (r0["status"] == 0) & (r1["status"] == 0)
+    assert ok.sum() >= 11
+    assert (r0["iters"] != r1["iters"]).any()        # the correction was taken somewhere
+    assert np.abs(r0["f"][ok] - r1["f"][ok]).max() < 1e-8 * max(1.0, np.abs(r0["f"][ok]).max())
+    assert np.abs(r0["x"][ok][:, : 21 * N] - r1["x"][ok][:, : 21 * N]).max() < 1e-5
+
+
 def test_warm_start_is_cheaper():
     N = 10
     b = scenes.make_batch(2, N, 1024, O.fk_batch)
