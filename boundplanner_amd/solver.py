@@ -23,7 +23,7 @@ class BmpcOpts(ctypes.Structure):
                 ("kappa_mu", ctypes.c_double), ("theta_mu", ctypes.c_double), ("kappa_eps", ctypes.c_double),
                 ("mu_floor_k", ctypes.c_double), ("inertia", ctypes.c_int), ("dw0", ctypes.c_double),
                 ("inertia_err", ctypes.c_double), ("stall_n", ctypes.c_int), ("slack_reset", ctypes.c_int), ("ls_alpha_mem", ctypes.c_double), ("gn_backoff", ctypes.c_int),
-                ("watchdog_ms", ctypes.c_int), ("max_batch", ctypes.c_int), ("pool_slots", ctypes.c_int)]
+                ("trial_repeats", ctypes.c_int), ("watchdog_ms", ctypes.c_int), ("max_batch", ctypes.c_int), ("pool_slots", ctypes.c_int)]
 
 
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",

@@ -463,6 +463,27 @@ def test_ric_variants_agree_bitwise(tmp_path):
     assert out[0]["iters"].max() > 40       # stragglers included
 
 
+def test_trial_repeats_are_scheduling_only():
+    """bmpc_opts.trial_repeats: rejected line-search trials are repeated inside the super-step that rejected them (0: one trial per
+    super-step, as in rounds 1-2).  Every instance sees the same sequence of trials, so the results are bitwise the same -- with a
+    slot per instance and with the rows streaming through a small pool."""
+    from boundplanner_amd import scenes
+    from boundplanner_amd.solver import HipBoundMPC
+    N, B = 20, 600
+    ref = None
+    for kw in (dict(trial_repeats=0), dict(trial_repeats=4), dict(trial_repeats=9), dict(trial_repeats=3, pool_slots=128)):
+        be = HipBoundMPC(N, **kw)
+        if ref is None:
+            batch = scenes.make_batch(B, N, 8192, be.fk, randomize_sets=True)
+        r = be.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+        if ref is None:
+            ref = r
+            assert r["iters"].max() > 40       # stragglers included
+            continue
+        for k in ("x", "f", "iters", "status", "viol"):
+            assert np.array_equal(ref[k], r[k]), (kw, k)
+
+
 def test_longest_horizon(backends):
     """N = 64, the longest horizon the handle accepts (one instance per wavefront in the thread-per-pair kernels, 63
     Riccati stages): instances that converge on both sides agree with the oracle; one of the six wanders to max_iter on
