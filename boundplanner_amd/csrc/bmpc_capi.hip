@@ -28,7 +28,7 @@ extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_ma
 // closed loop: called between the two halves of a retirement with the list of slots whose instances have just retired
 // (device pointers: list, its length); enqueues the caller's post-processing / next-problem kernels on the stream
 typedef int (*bmpc_retire_hook)(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream);
-extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, int trial_repeats, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_mult(const PipeArgsH* A, hipStream_t st);
 extern "C" void bmpc_pipe_build_table(int* tbl);
 extern "C" size_t bmpc_pipe_state_bytes(void);
@@ -122,7 +122,7 @@ struct BusyGuard {
 extern "C" void bmpc_default_opts(bmpc_opts* o, int N) {
     o->N = N; o->nr_segs = 4; o->dt = 0.1; o->tol = 1e-5; o->max_iter = 100; o->device = 0;
     o->hess = 2; o->hess_switch = 1.0; o->mu_init = 0.1; o->kappa_mu = 0.1; o->theta_mu = 2.0; o->kappa_eps = 1000.0;
-    o->mu_floor_k = 1e4; o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->gn_backoff = 2; o->slack_reset = 1; o->ls_alpha_mem = 0.0; o->trial_repeats = 4;
+    o->mu_floor_k = 1e4; o->inertia = 2; o->dw0 = 1e-4; o->inertia_err = 1e-2; o->stall_n = 8; o->gn_backoff = 2; o->slack_reset = 1; o->ls_alpha_mem = 0.0; o->trial_repeats = 9;
     o->max_batch = 0; o->pool_slots = 0; o->watchdog_ms = 30000;
 }
 
@@ -292,7 +292,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.B = B; A.N = N;
     A.o = SolverOpts{N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,
                      h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps,
-                     h->o.mu_floor_k, h->o.dw0, h->o.inertia_err, h->o.ls_alpha_mem, h->o.inertia, h->o.stall_n, h->o.gn_backoff, h->o.slack_reset};
+                     h->o.mu_floor_k, h->o.dw0, h->o.inertia_err, h->o.ls_alpha_mem, h->o.inertia, h->o.stall_n, h->o.gn_backoff, h->o.slack_reset, h->o.trial_repeats};
     A.rc = h->d_rc;
     A.x0 = d_x0; A.lbx = d_lbx; A.ubx = d_ubx; A.p = d_p;
     A.x = d_x; A.f = d_f; A.viol = d_viol; A.g = d_g; A.iters = d_iters; A.status = d_status;
@@ -338,7 +338,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
         const bool rows_left = streaming && (hook ? retired < B : next_row < B);
         for (int i = 0; i < burst; i++, steps++) {
             if (rows_left && i > 0) { if (int r = retire(cap, 1)) return r; }
-            HIPCHK(h, bmpc_pipe_launch_step(&A, rows_left ? cap : n_act, h->o.trial_repeats, st));
+            HIPCHK(h, bmpc_pipe_launch_step(&A, rows_left ? cap : n_act, st));
         }
         if (int r = retire(rows_left ? cap : n_act, rows_left ? 1 : 0)) return r;
         HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -46,6 +46,7 @@ struct SolverOpts {
     double hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps;
     double mu_floor_k, dw0, inertia_err, ls_alpha_mem;     // include/boundmpc.h bmpc_opts
     int inertia, stall_n, gn_backoff, slack_reset;
+    int trial_repeats;   // a rejected line-search trial is repeated (half the step length) up to this many times inside k_trial
 };
 
 struct RobotConst {           // chain constants of the handle's robot (include/boundmpc.h bmpc_robot), rotations precomputed on the host

@@ -980,8 +980,9 @@ BMPC_INL void ls0_instance(const PipeArgs& A, int b) {
 }
 
 // filter acceptance test of one instance's trial point (Waechter & Biegler 2006, Sec. 2.3) from the per-pair partials of
-// k_trial; returns true when the trial becomes the iterate
-BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
+// k_trial; returns true when the trial becomes the iterate.  A rejected instance goes to the next super-step's trial list
+// only when k_trial does not try again itself (`requeue`)
+BMPC_INL bool ls_instance(const PipeArgs& A, int b, bool requeue) {
     const int N = A.N;
     GST st = A.st + b;
     GCD P = A.part + pair_of(A, b, 1);
@@ -1021,8 +1022,10 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b) {
         return true;
     }
     st->alpha = 0.5 * alpha; st->bt += 1;
-    int pos = BMPC_ATOMIC_INC(A.L.cnt + 4);
-    A.L.trial_next[pos] = b;
+    if (requeue) {
+        int pos = BMPC_ATOMIC_INC(A.L.cnt + 4);
+        A.L.trial_next[pos] = b;
+    }
     return false;
 }
 
@@ -1201,57 +1204,81 @@ struct TrialVisitor {
 BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[2], N = A.N;
     if (wave * ipw_of(N) >= count) return;
-    PairMap m = pair_map(A, A.L.trial, count, wave, lane);
-    const int k = m.k, n_w = 44 * N + 6;
-    const bool term = (k == N - 1);
+    const PairMap m = pair_map(A, A.L.trial, count, wave, lane);
+    const int n_w = 44 * N + 6, ipw = ipw_of(N);
     const DynC dc = make_dync(A.o.dt);
-    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
-    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
-    PGP pg = stage_params(A, A.L.trial, count, wave, lane, m, lds_par);
-    const double alpha = A.st[m.b].alpha;
-    double iw0[3];
-    BMPC_UNROLL
-    for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
-    StagePoint S;
-    const int flip = A.st[m.b].flip;
-    GCD zc = cur_zeta(A, flip);
-    GD zo = oth_zeta(A, flip);
-    BMPC_UNROLL
-    for (int i = 0; i < NZ; i++) S.zeta[i] = zc[(size_t)i * A.NP + m.pi] + alpha * A.dz[(size_t)i * A.NP + m.pi];
-    if (m.valid)
+    (void)stage_params(A, A.L.trial, count, wave, lane, m, lds_par);
+    // The pairs of an instance are lanes of this wavefront, so the filter test of a trial point needs nobody else: the
+    // wavefront backtracks by itself -- trial, test, half the step length, again (at most 1 + trial_repeats trials per
+    // super-step) -- until each of its instances has an accepted point.  Rounds 1-2 (and trial_repeats = 0) tested in k_accept
+    // and gave a rejected instance its next trial one super-step later, after the evaluation and Riccati passes of everybody
+    // else.  Scheduling only: an instance sees the same sequence of trials either way.
+    LDSD* ended = lds_par + (size_t)ipw * NPAR;          // [IPW_MAX] 1: the instance's line search has ended (or no such instance)
+    if (lane < IPW_MAX) ended[lane] = (lane < ipw && wave * ipw + lane < count) ? 0.0 : 1.0;
+    BMPC_SYNC();
+    const int flip = A.st[m.b].flip;                     // (flipped by the accepting test: read once, the instance is dead then)
+    for (int round = 0;; round++) {
+        // the lane's coordinates pass through an opaque copy every round: everything below is recomputed from them, so the
+        // compiler cannot hoist the (hundreds of) round-invariant parameter loads out of the loop into registers it does not have
+        int b = m.b, k = m.k, li = m.li;
+        BMPC_OPAQUE_I(b); BMPC_OPAQUE_I(k); BMPC_OPAQUE_I(li);
+        const size_t pi = pair_of(A, b, k);
+        const bool term = (k == N - 1);
+        PGP pg = lds_par + li * NPAR;
+        GCD lbx = A.lbx + (size_t)A.src[b] * n_w;
+        GCD ubx = A.ubx + (size_t)A.src[b] * n_w;
+        GCD zc = cur_zeta(A, flip);
+        GD zo = oth_zeta(A, flip);
+        double iw0[3];
         BMPC_UNROLL
-        for (int i = 0; i < NZ; i++) zo[(size_t)i * A.NP + m.pi] = S.zeta[i];
-    stage_point(A, pg, iw0, k, dc, S);
-    TrialVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
-    walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
-    double th = 0;     // dynamics / initial-state part of theta
-    if (!term) {
-        double zn[NX], rdef[NX];
+        for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+        const bool live = m.valid && ended[li] == 0.0;
+        const double alpha = live ? A.st[b].alpha : 0.0;
+        StagePoint S;
         BMPC_UNROLL
-        for (int i = 0; i < NX; i++) zn[i] = zc[(size_t)i * A.NP + m.pi + 1] + alpha * A.dz[(size_t)i * A.NP + m.pi + 1];
-        defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
-        BMPC_UNROLL
-        for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
-    }
-    if (k == 1) {
-        double x1fix[24];
-        x1fix_eval(lbx, N, dc.dt, x1fix);
-        BMPC_UNROLL
-        for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
-    }
-    if (m.valid) {
-        GD P = A.part + m.pi;
-        P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th + V.thr;
-        P[PT_LS1 * A.NP] = log(V.lp) + (double)V.le * 0.69314718055994530942;
+        for (int i = 0; i < NZ; i++) S.zeta[i] = zc[(size_t)i * A.NP + pi] + alpha * A.dz[(size_t)i * A.NP + pi];
+        if (live)
+            BMPC_UNROLL
+            for (int i = 0; i < NZ; i++) zo[(size_t)i * A.NP + pi] = S.zeta[i];
+        stage_point(A, pg, iw0, k, dc, S);
+        TrialVisitor V;
+        V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
+        walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+        double th = 0;     // dynamics / initial-state part of theta
+        if (!term) {
+            double zn[NX], rdef[NX];
+            BMPC_UNROLL
+            for (int i = 0; i < NX; i++) zn[i] = zc[(size_t)i * A.NP + pi + 1] + alpha * A.dz[(size_t)i * A.NP + pi + 1];
+            defect_all(S.zeta, zn, S.C.v + 3, dc, rdef);
+            BMPC_UNROLL
+            for (int i = 0; i < NX; i++) th += fabs(rdef[i]);
+        }
+        if (k == 1) {
+            double x1fix[24];
+            x1fix_eval(lbx, N, dc.dt, x1fix);
+            BMPC_UNROLL
+            for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
+        }
+        if (live) {
+            GD P = A.part + pi;
+            P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th + V.thr;
+            P[PT_LS1 * A.NP] = log(V.lp) + (double)V.le * 0.69314718055994530942;
+        }
+        const bool last = round >= A.o.trial_repeats;
+        BMPC_FENCE_SYNC();
+        if (live && k == 1 && (ls_instance(A, b, last) || last)) ended[li] = 1.0;
+        BMPC_FENCE_SYNC();
+        bool left = false;
+        for (int q = 0; q < ipw; q++) left = left || (ended[q] == 0.0);
+        if (!left) break;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_accept: 256 threads = 64 pairs x 4 slot groups (a thread walks slots g, g+4, ...): per instance of the workgroup the
-// filter acceptance test on the partials k_trial left, and for an accepted trial the streaming update z += alpha_dual dz_row
-// (t and zeta: the instance's flip bit switches to the copies k_trial wrote).  Little register state: full occupancy.
-// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).  lds: 8 doubles.
+// k_accept: 256 threads = 64 pairs x 4 slot groups (a thread walks slots g, g+4, ...): for the instances whose trial k_trial's
+// filter test accepted, the streaming update z += alpha_dual dz_row (t and zeta: the instance's flip bit switched to the
+// copies k_trial wrote).  Little register state: full occupancy.
+// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).
 // (Round 1 had three streaming row kernels and three per-instance control kernels here; the row arithmetic now lives in
 // k_step and k_trial, whose row groups are loaded in batches.)
 // ------------------------------------------------------------------------------------------
@@ -1262,11 +1289,8 @@ BMPC_DEV void k_accept_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
     if (wave * ipw_of(N) >= count) return;
     const int lane = tid & 63, g = tid >> 6;
     PairMap m = pair_map(A, A.L.trial, count, wave, lane);
-    if (tid < IPW_MAX) lds[tid] = 0.0;       // per-instance verdicts
-    BMPC_SYNC();
-    if (g == 0 && m.valid && m.k == 1 && ls_instance(A, m.b)) lds[m.li] = 1.0;
-    BMPC_FENCE_SYNC();
-    if (!m.valid || lds[m.li] == 0.0) return;
+    (void)lds;
+    if (!m.valid || A.st[m.b].state != ST_EVAL) return;      // (k_trial's filter test made the accepted instances ST_EVAL)
     const double ad = A.st[m.b].ad;
     if (ad == 0.0) return;
     // z += alpha_dual dz_row; four slots per trip, all their loads issued before the first store (a trip per slot is two

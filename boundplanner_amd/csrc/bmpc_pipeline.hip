@@ -67,7 +67,6 @@ __global__ __launch_bounds__(64) void bmpc_k_admit(PipeArgsH H) { k_admit_body(D
 __global__ void bmpc_k_pool_reset(PipeArgsH H, int done_too) { if (threadIdx.x == 0 && blockIdx.x == 0) k_pool_reset_body(DV(H), done_too != 0); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
-__global__ void bmpc_k_retry(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_retry_body(DV(H)); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_mult(PipeArgsH H) { k_mult_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64) void bmpc_k_mult_sweep(PipeArgsH H) { k_mult_sweep_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
@@ -110,7 +109,7 @@ extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_ma
 }
 
 // one super-step for at most n_act active instances; swaps the double-buffered lists in *A
-extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, int trial_repeats, hipStream_t st) {
+extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st) {
     const int nw = waves_for(A->N, n_act);
     LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
@@ -121,20 +120,11 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, int trial_r
     else LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH(bmpc_k_accept, nw, 256);       // filter test per instance, accepted trials become the iterate
-    // the rejected trials are repeated with half the step length right away (the list of the rejected becomes the trial list): an
-    // instance that backtracks does not wait a whole super-step -- the evaluation and Riccati passes of the others -- per trial.
-    // Pure scheduling: every instance sees the same sequence of trials.
-    // (bmpc_opts.trial_repeats; BMPC_TRIAL_REPEATS in the environment, read once, overrides it: A/B runs)
+    // (BMPC_TRIAL_REPEATS in the environment, read once, overrides bmpc_opts.trial_repeats: A/B runs)
     static const int env_repeats = [] { const char* e = getenv("BMPC_TRIAL_REPEATS"); return e ? atoi(e) : -1; }();
-    const int repeats = env_repeats >= 0 ? env_repeats : trial_repeats;
-    for (int r = 0; r < repeats; r++) {
-        LAUNCH(bmpc_k_retry, 1, 64);
-        int* tt = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = tt;
-        LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false));
-        LAUNCH(bmpc_k_accept, nw, 256);
-    }
+    if (env_repeats >= 0) A->o.trial_repeats = env_repeats;
+    LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false) + IPW_MAX);      // trial points + filter test, backtracking inside
+    LAUNCH(bmpc_k_accept, nw, 256);       // accepted trials become the iterate: z += alpha_dual dz_row
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
     t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;

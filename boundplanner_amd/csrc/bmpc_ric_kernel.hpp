@@ -1042,12 +1042,6 @@ BMPC_DEV void k_rotate_body(const PipeArgs& A) {
     c[0] = c[3]; c[3] = 0; c[1] = 0; c[2] = c[4]; c[4] = 0; c[10] = 0;
 }
 
-// between two trial passes of one super-step: the rejected instances (trial_next, c[4]) become the trial list
-BMPC_DEV void k_retry_body(const PipeArgs& A) {
-    GI c = A.L.cnt;
-    c[2] = c[4]; c[4] = 0;
-}
-
 // per-instance outputs after k_out (done list)
 BMPC_DEV void k_fin_body(const PipeArgs& A, int e) {
     if (e >= A.L.cnt[8]) return;

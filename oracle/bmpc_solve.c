@@ -1431,7 +1431,7 @@ for (int k = 1; k < N; k++) {
             }
             printf("      step: |dq| %.2e |du| %.2e |dpi| %.2e |dslack| %.2e\n", mq, mu_, mpi, msl);
         }
-        if (o->verbose > 1) printf("      alpha_p %.3g (ftb %.3g) alpha_d %.3g ls_ok %d nu %.2e D %.2e th %.2e hreg %.1e tries %d\n", alpha, ap, ad, ls_ok, nu, D, th0, pb.hreg, tries);
+        if (o->verbose > 1) printf("      alpha_p %.3g (ftb %.3g) alpha_d %.3g ls_ok %d nu %.2e D %.2e th %.2e hreg %.1e tries %d hess %d stall %d\n", alpha, ap, ad, ls_ok, nu, D, th0, pb.hreg, tries, pb.hess, stall);
     }
 done:
     /* ---- outputs in the reference layout ---- */

@@ -75,13 +75,13 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
                               double kappa_mu, double theta_mu, double kappa_eps, int B, const double* x0,
                               const double* lbx, const double* ubx, const double* p, double* x, double* g, double* f,
                               int* iters, int* status, double* viol, int verbose, double* lam_g, double* lam_x, int slots,
-                              double mu_floor_k, double dw0, double inertia_err, int inertia, int stall_n, int gn_backoff, int slack_reset, double ls_alpha_mem) {
+                              double mu_floor_k, double dw0, double inertia_err, int inertia, int stall_n, int gn_backoff, int slack_reset, double ls_alpha_mem, int trial_repeats) {
     RobotConst rc;
     fill_robot_const(rc);
     PipeArgs A;   // emulation: BMPC_AS1 is empty, host and device views coincide
     A.B = B; A.N = N;
     A.lam_g = nullptr; A.lam_x = nullptr; A.cont = nullptr;
-    A.o = SolverOpts{N, dt, tol, max_iter, hess, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps, mu_floor_k, dw0, inertia_err, ls_alpha_mem, inertia, stall_n, gn_backoff, slack_reset};
+    A.o = SolverOpts{N, dt, tol, max_iter, hess, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps, mu_floor_k, dw0, inertia_err, ls_alpha_mem, inertia, stall_n, gn_backoff, slack_reset, trial_repeats};
     A.rc = &rc;
     A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.p = p;
     A.x = x; A.f = f; A.viol = viol; A.g = g; A.iters = iters; A.status = status;

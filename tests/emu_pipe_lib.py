@@ -23,7 +23,7 @@ def build(force=False):
 
 def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, hess=2, hess_switch=1.0, mu_init=0.1,
                 kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, want_g=False, verbose=0, want_lam=False, slots=0,
-                mu_floor_k=1e4, dw0=1e-4, inertia_err=1e-2, inertia=2, stall_n=8, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0):
+                mu_floor_k=1e4, dw0=1e-4, inertia_err=1e-2, inertia=2, stall_n=8, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0, trial_repeats=9):
     build()
     lib = ctypes.CDLL(LIB)
     n_w, n_g = 44 * N + 6, 147 * (N - 1) + 21
@@ -39,5 +39,5 @@ def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, hess=2, hess
     steps = lib.emu_pipe_solve(N, D(dt), D(tol), max_iter, hess, D(hess_switch), D(mu_init), D(kappa_mu), D(theta_mu),
                                D(kappa_eps), B, P(x0), P(lbx), P(ubx), P(p), P(x), P(g), P(f),
                                it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), P(viol), verbose, P(lam_g), P(lam_x), slots,
-                               D(mu_floor_k), D(dw0), D(inertia_err), inertia, stall_n, gn_backoff, slack_reset, D(ls_alpha_mem))
+                               D(mu_floor_k), D(dw0), D(inertia_err), inertia, stall_n, gn_backoff, slack_reset, D(ls_alpha_mem), trial_repeats)
     return dict(x=x, g=g, f=f, iters=it, status=st, viol=viol, steps=steps, lam_g=lam_g, lam_x=lam_x)

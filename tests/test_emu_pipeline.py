@@ -67,3 +67,17 @@ def test_emulated_field_major_layout_is_bitwise_the_same(monkeypatch):
     b = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
     for k in ("x", "g", "f", "iters", "status", "viol"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_emulated_backtracking_inside_k_trial_is_scheduling_only():
+    """bmpc_opts.trial_repeats: k_trial repeats a rejected trial itself (half the step length, up to nine times: the whole line
+    search in one super-step) instead of handing the instance to the next super-step's trial list (0, rounds 1-2).  Same
+    trials, same results bitwise, fewer super-steps."""
+    N, B = 18, 5
+    batch = scenes.make_batch(B, N, 18, O.fk_batch, randomize_sets=True)
+    r0 = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True, trial_repeats=0)
+    r2 = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True, trial_repeats=2)
+    r9 = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True, trial_repeats=9)
+    for k in ("x", "g", "f", "iters", "status", "viol"):
+        assert np.array_equal(r0[k], r9[k]) and np.array_equal(r0[k], r2[k]), k
+    assert r9["steps"] <= r2["steps"] < r0["steps"]          # some trial was rejected: the backtracking instance waited for nobody
