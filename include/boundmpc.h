@@ -53,9 +53,10 @@ typedef struct {
                            crawl, measured neutral on configs[2] and +5 % on configs[4] with m = 4 */
     int gn_backoff;     /* 2: after a Gauss-Newton fallback the exact Hessian is tried again after 1, then 2 iterations
                            (a failed attempt costs a Riccati sweep); 0: every iteration */
-    int trial_repeats;  /* 4 (default): rejected line-search trials are repeated up to this many times (each with half the step
-                           length) inside the super-step that rejected them, instead of one trial per super-step; scheduling only,
-                           results do not depend on it (bitwise) */
+    int trial_repeats;  /* 9 (default): a rejected line-search trial is repeated (half the step length) up to this many times by the
+                           wavefront that evaluated it (bmpc_k_trial holds all pairs of its instances, so it runs the filter test
+                           itself): the whole line search of an iteration in one super-step.  0: one trial per super-step
+                           (rounds 1-2).  Scheduling only, results do not depend on it (bitwise) */
     int watchdog_ms;    /* > 0 (default 30000): a wait for the GPU gives up after this long and the call returns 5 with a message
                            (the handle is unusable afterwards); 0: plain hipStreamSynchronize */
     int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
