@@ -126,7 +126,9 @@ def main():
     ap.add_argument("--same-batch", action="store_true", help="every step solves the seed-8192 batch (profiling passes)")
     ap.add_argument("--gen-workers", type=int, default=None, help="processes building problem instances (0: in this process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the single-batch and PCIe-inclusive measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the single-batch, PCIe-inclusive and closed-loop measurements")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the configs[4] leg")
+    ap.add_argument("--closed-loop-steps", type=int, default=200, help="MPC steps of the configs[4] leg (4096 rollouts, N=30; the config has 200)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -350,6 +352,18 @@ def main():
         same = all(bool(torch.equal(hs.h_out[0][k][:B], outs[0][k][:B].cpu())) for k in ("x", "iters", "status")) if nd_h >= 1 and args.steps % (depth * M) == 0 else None
         out["pcie_pipelined_first_batch_equals_device_resident"] = same
         del hs, pinned
+
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_closed_loop:
+        # BASELINE configs[4] (tools/closed_loop_device.py; --closed-loop-steps MPC steps, 200 = the config): 4096 rollouts,
+        # N=30, fixed sets, the reference's warm start, device-resident loop, three rollout groups in flight
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import closed_loop_device as CL
+            cl = CL.run(CL.parser().parse_args(["--steps", str(args.closed_loop_steps), "--chunk", str(max(1, args.closed_loop_steps // 2))]), progress=False)
+            out["closed_loop_configs4"] = {k: cl[k] for k in ("config", "groups", "solves", "wall_s", "solves_per_s", "ms_per_step", "iters_mean", "iters_p99",
+                                                              "fail_frac", "dead_frac", "reached_end_frac")}
+        except Exception as e:           # (reported, not fatal: the headline above is measured)
+            out["closed_loop_configs4"] = {"error": repr(e)}
 
     if rank == 0 and not args.no_cpu_baseline:
         import oracle_lib as O               # cpu_baseline leg only

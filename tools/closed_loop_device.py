@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rollouts", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=30)
@@ -33,7 +33,11 @@ def main():
     ap.add_argument("--diagnose", default=None, help="write a JSON with the classification of the rollouts that did not reach the path end")
     ap.add_argument("--groups", type=int, default=3, help="rollout groups stepped concurrently (own solver handle and stream "
                     "each): the straggler tail of one group's solve overlaps the bulk of another's")
-    args = ap.parse_args()
+    return ap
+
+
+def run(args, progress=True):
+    """The run described by `args` (parser()); returns the result record (bench.py calls this for its configs[4] leg)."""
     from boundplanner_amd import scenes
     from boundplanner_amd.batch_node import BatchMPCNode
     from boundplanner_amd.device_loop import DeviceLoop
@@ -79,7 +83,8 @@ def main():
         loop.upload()
     loop = loops[0]
     t_plan = time.perf_counter() - t0
-    print(f"plan-time host setup of {R} rollouts: {t_plan:.1f} s", file=sys.stderr, flush=True)
+    if progress:
+        print(f"plan-time host setup of {R} rollouts: {t_plan:.1f} s", file=sys.stderr, flush=True)
 
     L = loop.LOG
     iters, fails, reached_at = [], [], np.full(R, -1)
@@ -111,8 +116,9 @@ def main():
         for s in range(n):
             reached_at[(reached_at < 0) & at_end[s]] = done + s + 1
         done += n
-        print(f"step {done}/{args.steps}: {1e3 * (time.perf_counter() - t0) / done:.1f} ms/step, mean iters {iters[-1].mean():.1f}, "
-              f"at path end {(reached_at > 0).mean():.3f}", file=sys.stderr, flush=True)
+        if progress:
+            print(f"step {done}/{args.steps}: {1e3 * (time.perf_counter() - t0) / done:.1f} ms/step, mean iters {iters[-1].mean():.1f}, "
+                  f"at path end {(reached_at > 0).mean():.3f}", file=sys.stderr, flush=True)
     wall = time.perf_counter() - t0
     it = np.concatenate(iters)
     dead = float(log[-1, :, L["dead"]].mean())
@@ -202,7 +208,13 @@ def main():
             diag["stalled_other_final_speed_max"] = float(np.abs(sol["x"][sel][:, 7 * N + 1:14 * N:N]).max())
         json.dump(diag, open(args.diagnose, "w"), indent=1)
         print(json.dumps(diag), file=sys.stderr)
-    print(json.dumps(out))
+    for lp in loops:
+        lp.close()
+    return out
+
+
+def main():
+    print(json.dumps(run(parser().parse_args())))
 
 
 if __name__ == "__main__":
