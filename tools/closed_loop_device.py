@@ -16,6 +16,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# more than three rollout groups: their streams need hardware queues of their own (the runtime's default of 4 makes the fourth
+# stream share one: measured 23 k instead of 37 k solves/s with four groups); read when HIP initialises, as in bench.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def parser():
