@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
     k_fwd_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
-// filter test per instance + streaming accept pass: 64 pairs x 4 slot groups per workgroup
+// dual update of the accepted trials (streaming pass): 64 pairs x 4 slot groups per workgroup
 __global__ __launch_bounds__(256) void bmpc_k_accept(PipeArgsH H) {
     __shared__ double lds[8];
     k_accept_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);

@@ -964,7 +964,7 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
             A.L.done[pos] = b;
         } else {
             if (dw > 0.0) st->dw_last = dw;
-            // after a Gauss-Newton fallback the exact Hessian is tried again after 1, 2, ... gn_backoff iterations (k_accept)
+            // after a Gauss-Newton fallback the exact Hessian is tried again after 1, 2, ... gn_backoff iterations (ls_instance, in k_trial)
             if (gn_fell && o.gn_backoff > 0) {
                 const int gb = st->gn_back ? (2 * st->gn_back < o.gn_backoff ? 2 * st->gn_back : o.gn_backoff) : 1;
                 st->gn_back = gb; st->gn_skip = gb;
