@@ -92,7 +92,7 @@ def launch_ranks(args):
     """`--gpus N` without a launcher: start N ranks as a child torch.distributed.run (a child process, before this
     process has touched the GPU -- never a re-exec) and return its exit code."""
     have = visible_gpus()
-    if have < args.gpus:
+    if have < args.gpus and not args.rehearse_one_gpu:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to print a line for fewer ranks",
               file=sys.stderr)
         return 2
@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the single-batch, PCIe-inclusive and closed-loop measurements")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the configs[4] leg")
+    ap.add_argument("--rehearse-one-gpu", action="store_true", help="--gpus N on a box with ONE GPU: every rank uses device 0 and the all-gather "
+                    "runs over gloo (RCCL refuses two ranks on one device).  Rehearses the launch, sharding, gather and timing path of "
+                    "the N-rank run; the line it prints is marked and is NOT a scaling measurement")
     ap.add_argument("--closed-loop-steps", type=int, default=200, help="MPC steps of the configs[4] leg (4096 rollouts, N=30; the config has 200)")
     args = ap.parse_args()
 
@@ -159,8 +162,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: RCCL sees {dist.get_world_size()} ranks, --gpus {args.gpus}")
     if not torch.cuda.is_available():
@@ -316,6 +323,8 @@ def main():
     }
     if shard_check is not None:
         out["shard_check"] = shard_check
+    if args.rehearse_one_gpu:
+        out["rehearsal"] = f"{world} ranks sharing ONE GPU, all-gather over gloo: exercises the N-rank code path, not a scaling measurement"
 
     if rank == 0 and not args.no_extra:
         # SURVEY 8(d) as written: ONE batch at a time (depth 1, merge 1) ...
