@@ -36,6 +36,7 @@ def parser():
     ap.add_argument("--diagnose", default=None, help="write a JSON with the classification of the rollouts that did not reach the path end")
     ap.add_argument("--groups", type=int, default=3, help="rollout groups stepped concurrently (own solver handle and stream "
                     "each): the straggler tail of one group's solve overlaps the bulk of another's")
+    ap.add_argument("--opt", action="append", default=[], help="solver option key=value (bmpc_opts field), A/B runs")
     return ap
 
 
@@ -52,7 +53,11 @@ def run(args, progress=True):
     params = Params(n=N, dt=base.dt, build=False, weights=base.weights, nr_segs=base.nr_segs)
     G = 1 if args.async_ else max(1, args.groups)
     bounds = [R * g // G for g in range(G + 1)]
-    bes = [HipBoundMPC(N, max_batch=bounds[g + 1] - bounds[g]) for g in range(G)]
+    kw = {}
+    for kv in args.opt:
+        k, v = kv.split("=")
+        kw[k] = float(v) if ("." in v or "e" in v) else int(v)
+    bes = [HipBoundMPC(N, max_batch=bounds[g + 1] - bounds[g], **kw) for g in range(G)]
     be = bes[0]
     rng = np.random.default_rng(args.seed)
     t0 = time.perf_counter()
