@@ -463,6 +463,21 @@ def test_ric_variants_agree_bitwise(tmp_path):
     assert out[0]["iters"].max() > 40       # stragglers included
 
 
+def test_config4_generator_against_oracle(backends):
+    """The configs[4] generator at its horizon (N=30, seed 4096, fixed sets), 1024 cold-start instances -- the first solve of the
+    closed loop -- every instance against the oracle at both tolerances (tests/parity_lib.py), outliers to
+    gpurun_out/r03_parity_config4_N30.json."""
+    import parity_lib as PL
+    from boundplanner_amd import scenes
+    N, B = 30, 1024
+    be = backends(N)
+    batch = scenes.make_batch(B, N, 4096, be.fk, randomize_sets=False)
+    hip5, or5, hip8, or8 = four_solves(backends, N, batch)
+    rep, summ = check_parity(N, batch, hip5, or5, hip8, or8, max_outliers=int(0.05 * B), max_status_diff=8, dump="r03_parity_config4_N30.json")
+    assert rep["conv5"].sum() >= 0.99 * B and rep["conv8"].sum() >= 0.98 * B
+    PL.assert_same_truncation(rep)
+
+
 def test_trial_repeats_are_scheduling_only():
     """bmpc_opts.trial_repeats: rejected line-search trials are repeated inside the super-step that rejected them (0: one trial per
     super-step, as in rounds 1-2).  Every instance sees the same sequence of trials, so the results are bitwise the same -- with a
