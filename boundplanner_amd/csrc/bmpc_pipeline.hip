@@ -41,13 +41,16 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
-__global__ __launch_bounds__(BMPC_RIC_NT, 3) void bmpc_k_ric(PipeArgsH H) {          // throughput variant: 5 workgroups per CU (2.5 wavefronts / SIMD)
+// disable_tail_calls: a call site marked `tail` (LLVM marks every call that is handed no pointer into the caller's stack frame)
+// makes the callee save and restore the 64 callee-saved VGPRs it uses (the register-usage propagation that lets the sweeps clobber
+// them is skipped for functions with such call sites): 128 scratch accesses per lane and sweep
+__global__ __launch_bounds__(BMPC_RIC_NT, 3) __attribute__((disable_tail_calls)) void bmpc_k_ric(PipeArgsH H) {          // throughput variant: 5 workgroups per CU (2.5 wavefronts / SIMD)
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
-    k_ric_body<BMPC_RIC_NT, true>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
+    k_ric_body<BMPC_RIC_NT, true>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
-__global__ __launch_bounds__(BMPC_RIC_NT, 1) void bmpc_k_ric_lat(PipeArgsH H) {      // latency variant for the straggler tail
+__global__ __launch_bounds__(BMPC_RIC_NT, 1) __attribute__((disable_tail_calls)) void bmpc_k_ric_lat(PipeArgsH H) {      // latency variant for the straggler tail
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
-    k_ric_body<BMPC_RIC_NT, false>(H, blockIdx.x, threadIdx.x, (LDSD*)lds);
+    k_ric_body<BMPC_RIC_NT, false>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 #ifndef BMPC_RIC_LAT_BELOW
 #define BMPC_RIC_LAT_BELOW 512      // fewer active instances than this: the latency variant (every wavefront has a SIMD to itself anyway)

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #define BMPC_DEV __device__
+// the Riccati kernel reads its argument block from the kernel-argument segment (bmpc_ric_kernel.hpp, RicArgs)
+#define BMPC_KERNARG_ARGS 1
 #define BMPC_INL __device__ __forceinline__
 // kernel bodies: always inlined into their __global__ wrapper (as a separate function the body loses the wrapper's launch
 // bounds, and two such bodies -- k_init with batched parameter staging, k_step with the row steps -- did not terminate on gfx950)
@@ -31,7 +33,7 @@ typedef __attribute__((address_space(3))) double LDSD;
 #ifdef BMPC_NO_NOINLINE
 #define BMPC_NOINL __device__
 #else
-#define BMPC_NOINL __device__ __attribute__((noinline))
+#define BMPC_NOINL static __device__ __attribute__((noinline))
 #endif
 
 // 16-byte LDS vector access (ds_read_b128 / ds_write_b128) and fast reciprocal square root

@@ -164,6 +164,27 @@ BMPC_INL void chol9i_solve(const double* Lc, const double* invd, double* b) {
 
 #define RL(x) (lds + (x))
 
+// How the Riccati kernel reads its argument block.  On the GPU: straight from the kernel-argument segment (constant address
+// space, scalar loads into SGPRs) -- `RicArgs` is an empty tag.  Handing `const PipeArgsH&` to the non-inlined sweeps forced a
+// copy of the 480-byte block into every lane's scratch memory at kernel entry (30 x 16-byte stores per lane = 61 KB per
+// workgroup and launch, more than the 49 KB of gains an instance writes: the kernel's 2.7 x WRITE_SIZE of round 3) and every
+// use of a pointer inside the stage loop was a flat load from that copy on the critical path.  Emulation: a plain reference.
+#ifdef BMPC_KERNARG_ARGS
+typedef const __attribute__((address_space(4))) PipeArgsH* RicArgsPtr;
+struct RicArgs { RicArgsPtr p; };
+typedef const __attribute__((address_space(4))) PipeArgsH& RicArgsRef;
+BMPC_INL RicArgs ric_kernel_args() { return RicArgs{(RicArgsPtr)__builtin_amdgcn_kernarg_segment_ptr()}; }
+BMPC_INL RicArgsRef ric_args(RicArgs h) {      // the handle is uniform: back into scalar registers (function arguments arrive in VGPRs)
+    const unsigned long long v = (unsigned long long)h.p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return *(RicArgsPtr)(((unsigned long long)hi << 32) | lo);
+}
+#else
+typedef const PipeArgsH& RicArgs;
+typedef const PipeArgsH& RicArgsRef;
+BMPC_INL RicArgsRef ric_args(RicArgs a) { return a; }
+#endif
+
 // optional phase timing (diagnostic builds only: -DBMPC_PROFILE; never in the product build)
 #ifdef BMPC_PROFILE
 #define RPROF_START() long long rp_t0_ = clock64()
@@ -202,7 +223,8 @@ template <int NT> BMPC_DEV double rmin(double v, LDSD* red, int lane) {
 // zeta coordinates; coupling with stage k+1; adjoint, control-block factorisation, gains, Schur complement.  Integer and
 // pointer arguments only (see the note on floating-point arguments below).
 template <int NT>
-BMPC_INL void ric_phase_load_impl(const PipeArgsH& A, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
+BMPC_INL void ric_phase_load_impl(RicArgs AH, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
+    RicArgsRef A = ric_args(AH);
     const double hreg = lds[R_park + 12];
     const int N = A.N;
     const DynC dc = make_dync(A.o.dt);
@@ -328,7 +350,8 @@ BMPC_INL void ric_phase_load_impl(const PipeArgsH& A, LDSD* lds, int b, int lane
 }
 
 template <int NT>
-BMPC_INL void ric_phase_couple_impl(const PipeArgsH& A, LDSD* lds, int lane) {
+BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
+    RicArgsRef A = ric_args(AH);
     const DynC dc = make_dync(A.o.dt);
     const bool term = false;
     RPROF_START();
@@ -528,7 +551,8 @@ BMPC_INL void ric_phase_couple_impl(const PipeArgsH& A, LDSD* lds, int lane) {
 }
 
 template <int NT>
-BMPC_INL bool ric_phase_factor_impl(const PipeArgsH& A, LDSD* lds, int b, int lane, int k) {
+BMPC_INL bool ric_phase_factor_impl(RicArgs AH, LDSD* lds, int b, int lane, int k) {
+    RicArgsRef A = ric_args(AH);
     const double reg = 1e-9;      // fixed regularisation of the control block
     const size_t pi = pair_of(A, b, k);
     bool ok = true;
@@ -610,12 +634,12 @@ BMPC_INL bool ric_phase_factor_impl(const PipeArgsH& A, LDSD* lds, int b, int la
     return ok;
 }
 
-template <int NT> BMPC_NOINL void ric_phase_load(const PipeArgsH& A, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
-    ric_phase_load_impl<NT>(A, lds, b, lane, k, hess_mode, tpk);
+template <int NT> BMPC_NOINL void ric_phase_load(RicArgs AH, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
+    ric_phase_load_impl<NT>(AH, lds, b, lane, k, hess_mode, tpk);
 }
-template <int NT> BMPC_NOINL void ric_phase_couple(const PipeArgsH& A, LDSD* lds, int lane) { ric_phase_couple_impl<NT>(A, lds, lane); }
-template <int NT> BMPC_NOINL bool ric_phase_factor(const PipeArgsH& A, LDSD* lds, int b, int lane, int k) {
-    return ric_phase_factor_impl<NT>(A, lds, b, lane, k);
+template <int NT> BMPC_NOINL void ric_phase_couple(RicArgs AH, LDSD* lds, int lane) { ric_phase_couple_impl<NT>(AH, lds, lane); }
+template <int NT> BMPC_NOINL bool ric_phase_factor(RicArgs AH, LDSD* lds, int b, int lane, int k) {
+    return ric_phase_factor_impl<NT>(AH, lds, b, lane, k);
 }
 
 // SPLIT = true: the three phases are separate functions (230 VGPRs, two wavefronts per SIMD: the throughput variant, used while
@@ -623,7 +647,8 @@ template <int NT> BMPC_NOINL bool ric_phase_factor(const PipeArgsH& A, LDSD* lds
 // per stage: nothing is recomputed at the phase boundaries) for the straggler tail, where latency is all that counts.
 // Same arithmetic either way.
 template <int NT, bool SPLIT>
-BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int hess_mode, int may_abort) {
+BMPC_NOINL bool ric_backward(RicArgs AH, LDSD* lds, int b, int lane, int hess_mode, int may_abort) {
+    RicArgsRef A = ric_args(AH);
     // no floating-point arguments: an odd-aligned 64-bit argument pair that gets spilled trips a
     // register-alignment bug of this compiler; scalars travel through LDS (R_park)
     const double reg = 1e-9;      // fixed regularisation of the control block
@@ -656,25 +681,25 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
         const size_t pi = pair_of(A, b, k);
         if constexpr (SPLIT) {
 #ifdef BMPC_RIC_CALLS
-            ric_phase_load<NT>(A, lds, b, lane, k, hess_mode, tpk);
-            if (!term) ric_phase_couple<NT>(A, lds, lane);
-            if (!ric_phase_factor<NT>(A, lds, b, lane, k)) ok = false;
+            ric_phase_load<NT>(AH, lds, b, lane, k, hess_mode, tpk);
+            if (!term) ric_phase_couple<NT>(AH, lds, lane);
+            if (!ric_phase_factor<NT>(AH, lds, b, lane, k)) ok = false;
 #else
             // the phases inline, each on a lane index the compiler cannot relate to the others': the per-lane offsets are
             // recomputed per phase and stage (as with real calls) instead of being hoisted out of the stage loop, and no
             // call sequence / callee-saved registers are involved
             int l0 = lane, l1 = lane, l2 = lane;
             BMPC_OPAQUE_I(l0);
-            ric_phase_load_impl<NT>(A, lds, b, l0, k, hess_mode, tpk);
+            ric_phase_load_impl<NT>(AH, lds, b, l0, k, hess_mode, tpk);
             BMPC_OPAQUE_I(l1);
-            if (!term) ric_phase_couple_impl<NT>(A, lds, l1);
+            if (!term) ric_phase_couple_impl<NT>(AH, lds, l1);
             BMPC_OPAQUE_I(l2);
-            if (!ric_phase_factor_impl<NT>(A, lds, b, l2, k)) ok = false;
+            if (!ric_phase_factor_impl<NT>(AH, lds, b, l2, k)) ok = false;
 #endif
         } else {
-            ric_phase_load_impl<NT>(A, lds, b, lane, k, hess_mode, tpk);
-            if (!term) ric_phase_couple_impl<NT>(A, lds, lane);
-            if (!ric_phase_factor_impl<NT>(A, lds, b, lane, k)) ok = false;
+            ric_phase_load_impl<NT>(AH, lds, b, lane, k, hess_mode, tpk);
+            if (!term) ric_phase_couple_impl<NT>(AH, lds, lane);
+            if (!ric_phase_factor_impl<NT>(AH, lds, b, lane, k)) ok = false;
         }
         // a retry pass (the KKT quantities of the iterate are known from the first one) stops at the first control block that
         // is not positive definite; the verdict is uniform (read from LDS behind a barrier)
@@ -697,7 +722,8 @@ BMPC_NOINL bool ric_backward(const PipeArgsH& A, LDSD* lds, int b, int lane, int
 // part minimises the cost-to-go); false if the free part of the stage-1 value function is not positive definite
 // SPLIT: one instantiation per kernel variant, so that each is compiled under its kernel's register budget
 template <int NT, bool SPLIT>
-BMPC_NOINL bool ric_forward(const PipeArgsH& A, LDSD* lds, int b, int lane) {
+BMPC_NOINL bool ric_forward(RicArgs AH, LDSD* lds, int b, int lane) {
+    RicArgsRef A = ric_args(AH);
     const double mu = lds[R_park + 11];
     bool ok = true;
     // 8 x 8 system of the free part of x_1, once per iteration: rolled loops on LDS operands (unrolled, this function alone
@@ -834,14 +860,60 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
     }
 }
 
+// after the first backward sweep of an iteration: scaled KKT error (IPOPT's termination test), stall bookkeeping, monotone
+// Fiacco-McCormick barrier update with the error-tied floor.  Returns 0 converged / 1 iteration limit / -1 go on (then the new
+// barrier parameter is in R_park[11]).  A function of its own so that nothing of it (the polynomial constants of pow(), 17
+// register pairs) is alive in the kernel body across the sweep calls, where it was saved and restored around every call.
+template <bool SPLIT>      // (one instantiation per kernel variant, compiled under its kernel's register budget)
+BMPC_NOINL int ric_kkt_and_barrier(RicArgs AH, LDSD* lds, int b, int lane, int it, int hess_mode, int gn_ok) {
+    RicArgsRef A = ric_args(AH);
+    const auto& o = A.o;
+    InstState* st = A.st + b;
+    const int N = A.N;
+    const double lamsum = RL(R_park)[9], dual = RL(R_park)[10];
+    double mu = RL(R_park)[11];
+    const LDSD* pk = RL(R_park);
+    const double cmax = pk[0], cmin = pk[2], zsum = pk[3], prim = pk[4], nrows = pk[7];
+    const int neq = NX * (N - 2) + 24;
+    double sd = fmax(100.0, (lamsum + zsum) / ((double)neq + nrows)) / 100.0;
+    double sc = fmax(100.0, zsum / nrows) / 100.0;
+    double err = fmax(fmax(dual / sd, prim), cmax / sc);
+#ifdef BMPC_EMU_TRACE
+    if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d] it %3d err %.6e (d %.6e p %.6e c %.6e) mu %.2e hess_mode %d gn_ok %d stall %d\n", A.src[b], it, err, dual, prim, cmax, mu, hess_mode, gn_ok, st->stall);
+#endif
+    if (err <= o.tol && dual <= 1.0 && prim <= 1e-4 && cmax <= 1e-4) return 0;
+    if (it >= o.max_iter) return 1;
+    if (lane == 0) {
+        st->err_prev = err;
+        if (err < 0.9 * st->err_best) { st->err_best = err; st->stall = 0; } else st->stall += 1;
+    }
+    // monotone Fiacco-McCormick barrier update; a decrease stops at (scaled error) / mu_floor_k
+    double emu = fmax(fmax(dual / sd, prim), fmax(fabs(cmax - mu), fabs(cmin - mu)) / sc);
+    while (emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+        const double mu_before = mu;
+        mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+        if (o.mu_floor_k > 0) {
+            const double m2 = fmax(mu, fmin(emu / o.mu_floor_k, 0.1));
+            if (m2 >= mu_before) { mu = mu_before; break; }
+            mu = m2;
+        }
+        emu = fmax(fmax(dual / sd, prim), fmax(cmax - mu, 0.0) / sc);
+    }
+    BMPC_SYNC();                                     // every lane has read mu before lane 0 replaces it
+    if (lane == 0) RL(R_park)[11] = mu;
+    BMPC_SYNC();
+    return -1;
+}
+
 // lds: RIC_LDS_DOUBLES.  One workgroup (one wavefront) per entry of the eval list.
 template <int NT, bool SPLIT = true>
-BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
+BMPC_DEV void k_ric_body(RicArgs AH, int blk, int lane, LDSD* lds) {
+    RicArgsRef A = ric_args(AH);
     const int count = A.L.cnt[0];
     if (blk >= count) return;
     const int b = BMPC_UNIFORM(A.L.eval[blk]);
     const int N = A.N, n_w = 44 * N + 6;
-    const SolverOpts& o = A.o;
+    const auto& o = A.o;
     InstState* st = A.st + b;
     const double* lbx = A.lbx + (size_t)A.src[b] * n_w;
     // pinned part of x_1 and its defect
@@ -891,43 +963,13 @@ BMPC_DEV void k_ric_body(const PipeArgsH& A, int blk, int lane, LDSD* lds) {
     int status = -1;
     for (;;) {
         BMPC_SYNC();
-        bool ok = ric_backward<NT, SPLIT>(A, lds, b, lane, hess_mode, first ? 0 : 1);
-        const double lamsum = RL(R_park)[9], dual = RL(R_park)[10];
-        double mu = RL(R_park)[11];
+        bool ok = ric_backward<NT, SPLIT>(AH, lds, b, lane, hess_mode, first ? 0 : 1);
         if (first) {
             first = false;
-            const LDSD* pk = RL(R_park);
-            const double cmax = pk[0], cmin = pk[2], zsum = pk[3], prim = pk[4], nrows = pk[7];
-            const int neq = NX * (N - 2) + 24;
-            double sd = fmax(100.0, (lamsum + zsum) / ((double)neq + nrows)) / 100.0;
-            double sc = fmax(100.0, zsum / nrows) / 100.0;
-            double err = fmax(fmax(dual / sd, prim), cmax / sc);
-#ifdef BMPC_EMU_TRACE
-            if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d] it %3d err %.6e (d %.6e p %.6e c %.6e) mu %.2e hess_mode %d gn_ok %d stall %d\n", A.src[b], it, err, dual, prim, cmax, mu, hess_mode, gn_ok, st->stall);
-#endif
-            if (err <= o.tol && dual <= 1.0 && prim <= 1e-4 && cmax <= 1e-4) { status = 0; break; }
-            if (it >= o.max_iter) { status = 1; break; }
-            if (lane == 0) {
-                st->err_prev = err;
-                if (err < 0.9 * st->err_best) { st->err_best = err; st->stall = 0; } else st->stall += 1;
-            }
-            // monotone Fiacco-McCormick barrier update; a decrease stops at (scaled error) / mu_floor_k
-            double emu = fmax(fmax(dual / sd, prim), fmax(fabs(cmax - mu), fabs(cmin - mu)) / sc);
-            while (emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
-                const double mu_before = mu;
-                mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-                if (o.mu_floor_k > 0) {
-                    const double m2 = fmax(mu, fmin(emu / o.mu_floor_k, 0.1));
-                    if (m2 >= mu_before) { mu = mu_before; break; }
-                    mu = m2;
-                }
-                emu = fmax(fmax(dual / sd, prim), fmax(cmax - mu, 0.0) / sc);
-            }
+            status = ric_kkt_and_barrier<SPLIT>(AH, lds, b, lane, it, hess_mode, gn_ok);
+            if (status >= 0) break;
         }
-        BMPC_SYNC();                                     // every lane has read mu before lane 0 replaces it
-        if (lane == 0) RL(R_park)[11] = mu;
-        BMPC_SYNC();
-        { RPROF_START(); if (ok) ok = ric_forward<NT, SPLIT>(A, lds, b, lane); RPROF(6); }
+        { RPROF_START(); if (ok) ok = ric_forward<NT, SPLIT>(AH, lds, b, lane); RPROF(6); }
         if (ok) break;
         if (hess_mode && gn_ok) {                        // second-order terms not convex here: Gauss-Newton
             hess_mode = 0; ++tries; gn_fell = 1;
