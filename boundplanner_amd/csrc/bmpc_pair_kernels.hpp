@@ -2,7 +2,7 @@
 //   k_init   initial iterate from x0 (BoundMPC.py:412-416 warm/cold start vector), row slacks
 //   k_eval   accept the trial point, evaluate it, assemble the stage record for the Riccati sweep
 //   k_step   row steps of the Newton direction, fraction-to-boundary partials, merit derivative
-//   k_trial  line-search trial point: barrier objective pieces
+//   k_trial  line-search trial points (+ the multipliers' update), filter test, backtracking
 //   k_out    solution in the reference layout (casadi_ocp_formulation.py:89-101), g, violation
 // Bodies are plain functions of (args, wave, lane, lds) so that tests/emu can run them on the host.
 #pragma once
@@ -64,12 +64,12 @@ struct InitVisitor {
         th += fabs(h + t); ls += log(t);
         if (!valid) return;
         size_t o = (size_t)s * A->NP + pi;
-        A->t[o] = t; A->t_t[o] = t; A->z[o] = 1.0; A->dzr[o] = 0.0;
+        A->t[o] = t; A->t_t[o] = t; A->z[o] = 1.0; A->z_t[o] = 1.0;
     }
     BMPC_INL void skip(int s) {
         if (!valid) return;
         size_t o = (size_t)s * A->NP + pi;
-        A->t[o] = 1.0; A->t_t[o] = 1.0; A->z[o] = 0.0; A->dzr[o] = 0.0;
+        A->t[o] = 1.0; A->t_t[o] = 1.0; A->z[o] = 0.0; A->z_t[o] = 0.0;
     }
     BMPC_INL void diag(int s, int, double, double h) { set(s, h); }
     BMPC_INL void zdiag(int s, int, double, double h) { set(s, h); }
@@ -184,20 +184,20 @@ BMPC_KBODY void k_init_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 // ------------------------------------------------------------------------------------------
 struct RowAcc {   // row data access (accepting the trial values) + KKT partial sums
     const PipeArgs* A; size_t pi; bool valid; double ad;
-    GCD tc;                                          // the copy of the slack array that holds the iterate (cur_t)
+    GCD tc, zc;                                      // the copies of the slack / multiplier arrays that hold the iterate (cur_t, cur_z)
     double cmax, csum, cmin, zsum, prim, nrows;     // f, theta, sum log t of this point: k_trial / k_init
-    BMPC_INL void init(const PipeArgs* A_, size_t pi_, bool valid_, double ad_, GCD tc_) {
-        A = A_; pi = pi_; valid = valid_; ad = ad_; tc = tc_;
+    BMPC_INL void init(const PipeArgs* A_, size_t pi_, bool valid_, double ad_, GCD tc_, GCD zc_) {
+        A = A_; pi = pi_; valid = valid_; ad = ad_; tc = tc_; zc = zc_;
         cmax = 0; csum = 0; cmin = 1e300; zsum = 0; prim = 0; nrows = 0;
     }
     BMPC_INL void row(int s, double h, double& sg, double& r0, double& r1, double& zz) {
         size_t o = (size_t)s * A->NP + pi;
-        row_tz(tc[o], A->z[o], h, sg, r0, r1, zz);     // read-only here: the accepted trial was made current by k_accept
+        row_tz(tc[o], zc[o], h, sg, r0, r1, zz);        // read-only here: the accepted trial was made current by the flip bit
     }
     // the same with the slack t and the multiplier z of the row already in registers (RowPre)
     BMPC_INL void row_tz(double t, double z_in, double h, double& sg, double& r0, double& r1, double& zz) {
         zz = z_in;
-        r1 = 1.0 / t; sg = zz * r1; r0 = sg * (h + t);
+        r1 = BMPC_RCP(t); sg = zz * r1; r0 = sg * (h + t);
         double c = t * zz;
         cmax = fmax(cmax, c); csum += c; cmin = fmin(cmin, c); zsum += zz;
         prim = fmax(prim, fabs(h + t));
@@ -211,9 +211,9 @@ struct RowAcc {   // row data access (accepting the trial values) + KKT partial 
 template <int S0_, int CNT_> struct RowPre {
     static constexpr int S0 = S0_, CNT = CNT_;
     double t[CNT_], z[CNT_];
-    BMPC_INL void load(const PipeArgs& A, GCD tc, size_t pi) {
+    BMPC_INL void load(const PipeArgs& A, GCD tc, GCD zc, size_t pi) {
         BMPC_UNROLL
-        for (int i = 0; i < CNT_; i++) { size_t o = (size_t)(S0_ + i) * A.NP + pi; t[i] = tc[o]; z[i] = A.z[o]; }
+        for (int i = 0; i < CNT_; i++) { size_t o = (size_t)(S0_ + i) * A.NP + pi; t[i] = tc[o]; z[i] = zc[o]; }
     }
 };
 template <int I0_, int CNT_> struct BndPre {
@@ -243,7 +243,7 @@ struct PointAsm {
     BMPC_INL void skip(int) {}
     template <int C> BMPC_INL void point_begin() {
         BMPC_UNROLL
-        for (int i = 0; i < 15; i++) { size_t o = (size_t)(S_COL + 15 * C + i) * R->A->NP + R->pi; pt[i] = R->tc[o]; pz[i] = R->A->z[o]; }
+        for (int i = 0; i < 15; i++) { size_t o = (size_t)(S_COL + 15 * C + i) * R->A->NP + R->pi; pt[i] = R->tc[o]; pz[i] = R->zc[o]; }
         BMPC_UNROLL
         for (int i = 0; i < 6; i++) M3[i] = 0;
         BMPC_UNROLL
@@ -668,12 +668,12 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     BMPC_SYNC();
     StagePoint S;
     const int flip = A.st[m.b].flip;
-    GCD zc = cur_zeta(A, flip), tc = cur_t(A, flip);
+    GCD zc = cur_zeta(A, flip), tc = cur_t(A, flip), zcur = cur_z(A, flip);
     load_zeta(zc, A.NP, m.pi, S.zeta);
     // row data of the pose rows: in flight while the kinematics are evaluated
     RowPre<S_EE, 21> rp_pose;
-    rp_pose.load(A, tc, m.pi);
-    const double t_phi = tc[(size_t)S_PHI * A.NP + m.pi], z_phi = A.z[(size_t)S_PHI * A.NP + m.pi];
+    rp_pose.load(A, tc, zcur, m.pi);
+    const double t_phi = tc[(size_t)S_PHI * A.NP + m.pi], z_phi = zcur[(size_t)S_PHI * A.NP + m.pi];
     stage_point(A, pg, iw0, k, dc, S);
     double G[6][7];
     kin_G(S.K, S.Jl, S.y + Z_DQ, G);
@@ -684,7 +684,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         cost_hess(pg, S.C, term, Hp, HvX);
     }
     RowAcc R;
-    R.init(&A, m.pi, m.valid, ad, tc);
+    R.init(&A, m.pi, m.valid, ad, tc, zcur);
     // ---- collision-point results of k_points: q x d columns first, the rest where it is needed ----
     PointRes PA;
     PA.base = A.part + (size_t)PT_SIDE * A.NP + m.pi; PA.NP = A.NP;
@@ -704,7 +704,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     walk_pose_rows(pg, N, k, S.y, S.C, PO, rp_pose, t_phi, z_phi);
     {
         RowPre<S_TSET, 21> rp_term;          // one batch of loads per row group, right before the group is walked
-        rp_term.load(A, tc, m.pi);
+        rp_term.load(A, tc, zcur, m.pi);
         walk_pose_rows_term(pg, N, k, S.y, S.C, PO, rp_term);
     }
     const double hdt = 0.5 * dc.dt;
@@ -733,7 +733,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     {
         RowPre<0, 28> rp_a;                  // rows + bounds of the q, dq box
         BndPre<0, 14> bp_a;
-        rp_a.load(A, tc, m.pi); bp_a.load(lbx, ubx, N, k);
+        rp_a.load(A, tc, zcur, m.pi); bp_a.load(lbx, ubx, N, k);
         PA.load_p17();
         p17_emit_all<0>(A, pg, rp_a, bp_a, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, g12 + 6, E);
     }
@@ -766,7 +766,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     // ---- remaining diagonal rows + gradients: ddq, u, rs, drs, ps, dps, d ----
     RowPre<28, 40> rp_b;                     // rows + bounds of the ddq, u box, the slack rows, the zeta-diagonal rows
     BndPre<14, 14> bp_b;
-    rp_b.load(A, tc, m.pi); bp_b.load(lbx, ubx, N, k);
+    rp_b.load(A, tc, zcur, m.pi); bp_b.load(lbx, ubx, N, k);
     PA.load_dg();
     dg_emit_all<14>(A, pg, rp_b, bp_b, k, term, y2, R, PA, PO, E);
     // ---- zeta-diagonal rows (k == 1) ----
@@ -863,7 +863,7 @@ BMPC_KBODY void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_p
     BMPC_UNROLL
     for (int i = 0; i < 6; i++) C.sl[i] = pg[P_SLACKS0 + i] + y[Z_D + i];
     RowAcc R;
-    R.init(&A, m.pi, m.valid, 0.0, cur_t(A, flip));
+    R.init(&A, m.pi, m.valid, 0.0, cur_t(A, flip), cur_z(A, flip));
     PointAsm PA;
     PA.R = &R; PA.K = &K;
     PA.init();
@@ -1038,21 +1038,22 @@ struct StepVisitor {
     const double* dy;     // natural step
     const double* dzt;    // zeta step
     double dloc[6], dpt[6][3];
-    GCD tc;                                          // cur_t of the instance
+    GCD tc, zc;                                      // cur_t, cur_z of the instance
     double gt[ROW_GROUP_MAX], gz[ROW_GROUP_MAX];     // slack t and multiplier z of the current row group, loaded in one batch
     double rp, rdn, rdd, dbar;                        // max(-dt/t), max(-dz/z) as the fraction rdn / rdd (one division per pair
                                                       // instead of one per row), -mu sum dt/t over the rows of this pair
     template <int S0, int CNT> BMPC_INL void group() {
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
         BMPC_UNROLL
-        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gz[i] = A->z[o]; }
+        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gz[i] = zc[o]; }
     }
     BMPC_INL void fin(int s, double h, double adot) {
-        // row step: t + dt = c = -h - a.d (stored in A.dt: k_trial and the accept pass subtract t again),
-        // dz_row = (mu - t z - z dt) / t, fraction-to-boundary ratios, barrier part of the merit derivative
+        // row step: t + dt = c = -h - a.d (stored in A.dt: k_trial subtracts t again), dz_row = (mu - t z - z dt) / t = (mu - z c) / t
+        // (not stored: k_trial recomputes it from t, c, z where it updates the multipliers), fraction-to-boundary ratios, barrier
+        // part of the merit derivative
         const double c = -h - adot, t = gt[s - row_group_base(s)], z = gz[s - row_group_base(s)];
-        const double rt = 1.0 / t, dti = c - t, dzi = (mu - t * z - z * dti) * rt;
-        if (valid) { size_t o = (size_t)s * A->NP + pi; A->dt[o] = c; A->dzr[o] = dzi; }
+        const double rt = BMPC_RCP(t), dti = c - t, dzi = (mu - z * c) * rt;
+        if (valid) { size_t o = (size_t)s * A->NP + pi; A->dt[o] = c; }
         rp = fmax(rp, -dti * rt);
         if (-dzi * rdd > rdn * z) { rdn = -dzi; rdd = z; }          // -dzi / z > rdn / rdd  (z, rdd > 0)
         dbar -= mu * dti * rt;
@@ -1119,7 +1120,7 @@ BMPC_KBODY void k_step_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     load_zeta(A.dz, A.NP, m.pi, dzt);
     nat_all(dzt, dc, dy);
     StepVisitor V;
-    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu); V.tc = cur_t(A, flip);
+    V.A = &A; V.pi = m.pi; V.valid = m.valid; V.mu = mu; V.tau = fmax(0.99, 1.0 - mu); V.tc = cur_t(A, flip); V.zc = cur_z(A, flip);
     V.dy = dy; V.dzt = dzt; V.rp = 0.0; V.rdn = 0.0; V.rdd = 1.0; V.dbar = 0.0;
     double dv[6];
     BMPC_UNROLL
@@ -1173,6 +1174,10 @@ struct TrialVisitor {
     const PipeArgs* A; size_t pi; bool valid;
     double alpha;
     GCD tc; GD tn_out;                                // cur_t (read) and oth_t (the trial slacks go there) of the instance
+    // the multipliers' step does not depend on the primal step length: the first trial of an iteration also writes
+    // z + alpha_dual dz_row, dz_row = (mu - z c) / t, into the other copy of z (what the streaming kernel k_accept did with a
+    // dz_row array that k_step stored) -- whichever trial is accepted, the flip bit makes it current together with t and zeta
+    bool dual; double ad, mu; GCD zc; GD zn_out;
     double gt[ROW_GROUP_MAX], gc[ROW_GROUP_MAX];      // slack t and t + dt (k_step's c) of the current row group, one batch of loads
     double thr;                                       // row part of theta
     double lp; int le;                                // sum log t of the trial point as log of the running product lp * 2^le
@@ -1181,9 +1186,19 @@ struct TrialVisitor {
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
         BMPC_UNROLL
         for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gc[i] = A->dt[o]; }
+        if (dual) {
+            // a slot is live iff z > 0 (inactive slots keep t = 1, z = 0 in both copies from k_init); done here, on the whole
+            // group at once, so that no multiplier stays in a register while the group's rows are walked
+            double gz[CNT];
+            BMPC_UNROLL
+            for (int i = 0; i < CNT; i++) gz[i] = zc[(size_t)(S0 + i) * A->NP + pi];
+            BMPC_UNROLL
+            for (int i = 0; i < CNT; i++)
+                if (gz[i] > 0.0) zn_out[(size_t)(S0 + i) * A->NP + pi] = gz[i] + ad * ((mu - gz[i] * gc[i]) * BMPC_RCP(gt[i]));
+        }
     }
     BMPC_INL void fin(int s, double h) {
-        // trial slack t + alpha dt (reset to -h where that is larger), its share of theta and of the barrier term; kept for the accept pass
+        // trial slack t + alpha dt (reset to -h where that is larger), its share of theta and of the barrier term
         const double t = gt[s - row_group_base(s)];
         double tn = t + alpha * (gc[s - row_group_base(s)] - t);
         if (A->o.slack_reset) tn = fmax(tn, -h);      // slack reset: never below what closes the row at the trial point
@@ -1243,6 +1258,7 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
         stage_point(A, pg, iw0, k, dc, S);
         TrialVisitor V;
         V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
+        V.dual = live && round == 0; V.ad = A.st[b].ad; V.mu = A.st[b].mu; V.zc = cur_z(A, flip); V.zn_out = oth_z(A, flip);
         walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
         double th = 0;     // dynamics / initial-state part of theta
         if (!term) {
@@ -1271,43 +1287,6 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
         bool left = false;
         for (int q = 0; q < ipw; q++) left = left || (ended[q] == 0.0);
         if (!left) break;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_accept: 256 threads = 64 pairs x 4 slot groups (a thread walks slots g, g+4, ...): for the instances whose trial k_trial's
-// filter test accepted, the streaming update z += alpha_dual dz_row (t and zeta: the instance's flip bit switched to the
-// copies k_trial wrote).  Little register state: full occupancy.
-// A slot is live iff z > 0 (inactive slots keep t = 1, z = 0 from k_init).
-// (Round 1 had three streaming row kernels and three per-instance control kernels here; the row arithmetic now lives in
-// k_step and k_trial, whose row groups are loaded in batches.)
-// ------------------------------------------------------------------------------------------
-constexpr int ROW_GROUPS = 4;
-
-BMPC_DEV void k_accept_body(const PipeArgs& A, int wave, int tid, LDSD* lds) {
-    const int count = A.L.cnt[2], N = A.N;
-    if (wave * ipw_of(N) >= count) return;
-    const int lane = tid & 63, g = tid >> 6;
-    PairMap m = pair_map(A, A.L.trial, count, wave, lane);
-    (void)lds;
-    if (!m.valid || A.st[m.b].state != ST_EVAL) return;      // (k_trial's filter test made the accepted instances ST_EVAL)
-    const double ad = A.st[m.b].ad;
-    if (ad == 0.0) return;
-    // z += alpha_dual dz_row; four slots per trip, all their loads issued before the first store (a trip per slot is two
-    // dependent round trips).  t and zeta need no copy: the instance's flip bit now points at the trial copies.
-    static_assert(NSLOT % (4 * ROW_GROUPS) == 0, "slots per thread");
-    for (int s0 = g; s0 < NSLOT; s0 += 4 * ROW_GROUPS) {
-        double z4[4], d4[4];
-        BMPC_UNROLL
-        for (int u = 0; u < 4; u++) {
-            size_t o = (size_t)(s0 + u * ROW_GROUPS) * A.NP + m.pi;
-            z4[u] = A.z[o]; d4[u] = A.dzr[o];
-        }
-        BMPC_UNROLL
-        for (int u = 0; u < 4; u++) {
-            size_t o = (size_t)(s0 + u * ROW_GROUPS) * A.NP + m.pi;
-            if (z4[u] > 0.0) A.z[o] = z4[u] + ad * d4[u];
-        }
     }
 }
 
@@ -1433,10 +1412,11 @@ BMPC_KBODY void k_out_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par)
 // ------------------------------------------------------------------------------------------
 struct MultVisitor {
     const PipeArgs* A; size_t pi; int N, k;
+    GCD zc;              // cur_z of the instance
     GD lg;               // inequality rows of this stage in lam_g
     GD lx;               // lam_x of the instance
     double bz[6], Fc[6][3], sPS, sRS, sD[6], lxq[7], lxdq[7], lxddq[7], znn[4], z1[2];
-    BMPC_INL double zrow(int s) const { return A->z[(size_t)s * A->NP + pi]; }
+    BMPC_INL double zrow(int s) const { return zc[(size_t)s * A->NP + pi]; }
     BMPC_INL void skip(int s) {
         if (s >= S_EE && s < (k == N - 1 ? S_END : S_TSET)) lg[s - S_EE] = 0.0;
     }
@@ -1523,7 +1503,7 @@ BMPC_KBODY void k_mult_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     BMPC_UNROLL
     for (int f = 0; f < 40; f++) lx[(size_t)f * N + k] = 0.0;
     MultVisitor V;
-    V.A = &A; V.pi = pi; V.N = N; V.k = k;
+    V.A = &A; V.pi = pi; V.N = N; V.k = k; V.zc = cur_z(A, A.st[m.b].flip);
     V.lg = A.lam_g + b * n_g + 35 * (N - 1) + 112 * (k - 1);
     V.lx = lx;
     V.sPS = 0; V.sRS = 0; V.z1[0] = 0; V.z1[1] = 0;

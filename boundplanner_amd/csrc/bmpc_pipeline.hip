@@ -60,11 +60,6 @@ __global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
     k_fwd_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
-// dual update of the accepted trials (streaming pass): 64 pairs x 4 slot groups per workgroup
-__global__ __launch_bounds__(256) void bmpc_k_accept(PipeArgsH H) {
-    __shared__ double lds[8];
-    k_accept_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
-}
 __global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64) void bmpc_k_admit(PipeArgsH H) { k_admit_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ void bmpc_k_pool_reset(PipeArgsH H, int done_too) { if (threadIdx.x == 0 && blockIdx.x == 0) k_pool_reset_body(DV(H), done_too != 0); }
@@ -126,8 +121,7 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     // (BMPC_TRIAL_REPEATS in the environment, read once, overrides bmpc_opts.trial_repeats: A/B runs)
     static const int env_repeats = [] { const char* e = getenv("BMPC_TRIAL_REPEATS"); return e ? atoi(e) : -1; }();
     if (env_repeats >= 0) A->o.trial_repeats = env_repeats;
-    LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false) + IPW_MAX);      // trial points + filter test, backtracking inside
-    LAUNCH(bmpc_k_accept, nw, 256);       // accepted trials become the iterate: z += alpha_dual dz_row
+    LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false) + IPW_MAX);      // trial points (+ multiplier update) + filter test, backtracking inside
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
     t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;

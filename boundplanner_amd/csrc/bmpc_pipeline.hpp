@@ -119,7 +119,7 @@ template <int DEV> struct PipeArgsT {
     // SS = N-1) and slot-major (all arrays of a slot in one block: NP = N-1, SS = HS = KS = block size)
     size_t NP, SS, HS, KS;
     typename PT::D zeta, zeta_t, dz;     // 41 fields
-    typename PT::D t, t_t, z, dt, dzr;   // NSLOT fields
+    typename PT::D t, t_t, z, dt, z_t;   // NSLOT fields (dt holds t + dt, k_step's `c`)
     typename PT::D hrec;                 // HREC doubles per pair
     typename PT::D krec;                 // KREC doubles per pair
     typename PT::D dx1;                  // [B][32] step of x_1 (k_ric -> k_fwd)
@@ -139,10 +139,13 @@ typedef PipeArgsT<1> PipeArgs;           // device view (same layout)
 static_assert(sizeof(PipeArgsH) == sizeof(PipeArgs), "host/device argument layouts differ");
 typedef BMPC_AS1 InstState* GST;
 
-// The iterate's slacks and zeta live in t / zeta or in t_t / zeta_t, per instance (InstState.flip): k_trial writes the trial
-// point into the other copy and an accepted trial becomes the iterate by flipping the bit -- no copy pass.
+// The iterate's slacks, row multipliers and zeta live in t / z / zeta or in t_t / z_t / zeta_t, per instance (InstState.flip):
+// k_trial writes the trial point (and the updated multipliers, which do not depend on the primal step length) into the other
+// copy and an accepted trial becomes the iterate by flipping the bit -- no copy pass, no update pass.
 template <class AT> BMPC_INL auto cur_t(const AT& A, int flip) -> decltype(A.t) { return flip ? A.t_t : A.t; }
 template <class AT> BMPC_INL auto oth_t(const AT& A, int flip) -> decltype(A.t) { return flip ? A.t : A.t_t; }
+template <class AT> BMPC_INL auto cur_z(const AT& A, int flip) -> decltype(A.z) { return flip ? A.z_t : A.z; }
+template <class AT> BMPC_INL auto oth_z(const AT& A, int flip) -> decltype(A.z) { return flip ? A.z : A.z_t; }
 template <class AT> BMPC_INL auto cur_zeta(const AT& A, int flip) -> decltype(A.zeta) { return flip ? A.zeta_t : A.zeta; }
 template <class AT> BMPC_INL auto oth_zeta(const AT& A, int flip) -> decltype(A.zeta) { return flip ? A.zeta : A.zeta_t; }
 template <class AT> BMPC_INL size_t pair_of(const AT& A, int b, int k) { return (size_t)b * A.SS + (k - 1); }      // SoA offset
@@ -165,7 +168,7 @@ template <class AT> inline void pipe_carve(AT& A, double* w, int cap, int N, int
     double* w0 = w;
     A.zeta = w; w += NZ * NP; A.zeta_t = w; w += NZ * NP; A.dz = w; w += NZ * NP;
     A.t = w; w += NSLOT * NP; A.t_t = w; w += NSLOT * NP; A.z = w; w += NSLOT * NP; A.dt = w; w += NSLOT * NP;
-    A.dzr = w; w += NSLOT * NP;
+    A.z_t = w; w += NSLOT * NP;
     A.part = w; w += NPART * NP;
     if (slot_major) w = w0 + ((size_t)(w - w0) + 15) / 16 * 16;      // records 128-byte aligned inside the slot block
     A.hrec = w; w += HREC * NP; A.krec = w; w += KREC * NP;

@@ -237,8 +237,9 @@ BMPC_INL void ric_phase_load_impl(RicArgs AH, LDSD* lds, int b, int lane, int k,
     // ---- stage matrix from the record (natural coordinates): the record's loads are in flight while W is cleared ----
     GCD hrec_k = (GCD)(A.hrec + hrec_of(A, b, k));
     double rv[NF];
+    // (fields F_CQP .. HREC, the curvature block k_curv writes, are read in hess_mode only: the last 128 doubles of the record)
     BMPC_UNROLL
-    for (int i = 0; i < NF; i++) rv[i] = hrec_k[lane + NT * i];
+    for (int i = 0; i < NF; i++) rv[i] = (hess_mode || NT * (i + 1) <= F_CQP) ? hrec_k[lane + NT * i] : 0.0;
     {
         const bmpc_v2d z2 = {0.0, 0.0};
         for (int e = lane; e < NZ * LDW / 2; e += NT) *(LDSV2*)(RL(R_W) + 2 * e) = z2;
@@ -272,7 +273,7 @@ BMPC_INL void ric_phase_load_impl(RicArgs AH, LDSD* lds, int b, int lane, int k,
     // every lane has consumed the staged record: fetch the next stage's behind the rest of this stage
     // the next stage's record (5 KB): one dword per 128-byte line into the junk area by LDS-DMA (no register, nobody waits
     // for it) so that its loads hit the L2 when that stage starts
-    if (k > 1 && lane < HREC / 16) BMPC_TOUCH_LINE((GCD)(A.hrec + hrec_of(A, b, k - 1)) + 16 * lane, RL(R_misc));
+    if (k > 1 && lane < (hess_mode ? HREC : F_CQP) / 16) BMPC_TOUCH_LINE((GCD)(A.hrec + hrec_of(A, b, k - 1)) + 16 * lane, RL(R_misc));
     RPROF(0);
     // ---- second-order term of the pi dynamics: multiplier lam_pi(k+1) times d2(dt w)/d(q,dq)2 ----
     if (hess_mode && !term) {

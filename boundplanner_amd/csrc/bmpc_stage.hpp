@@ -460,7 +460,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
     // collision points (ocp :323-330)
     walk_points<V, 0>(pg, K, C, v);
     // phi cap (ocp :332)
-    v.template group<S_PHI, S_END - S_PHI>();
+    if (term) v.template group<S_PHI, S_END - S_PHI>(); else v.template group<S_PHI, 1>();      // (the 21 terminal slots exist at the last stage only)
     {
         double a6[6] = {C.dpp[0], C.dpp[1], C.dpp[2], 0, 0, 0};
         v.pose(S_PHI, a6, 0, C.phi - (C.phiend + 0.005));

@@ -27,6 +27,7 @@ typedef double LDSD;
 typedef double bmpc_v2d __attribute__((vector_size(16)));
 typedef bmpc_v2d LDSV2;
 #define BMPC_RSQRT(x) (1.0 / std::sqrt(x))
+#define BMPC_RCP(x) (1.0 / (x))
 #define BMPC_LDS_ADD(ptr, v) (*(ptr) += (v))
 #define BMPC_AS1
 template <int NCH, int NT> static inline void bmpc_async_copy(const double* gsrc, double* lds_dst, int lane) {
@@ -126,7 +127,6 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body(A, blk, l, lds.data()); });
-        launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_accept_body(A, blk, l, lds.data()); }, 256);
         k_rotate_body(A);
         std::swap(A.L.eval, A.L.eval_next);
         std::swap(A.L.trial, A.L.trial_next);
