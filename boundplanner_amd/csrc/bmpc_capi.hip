@@ -577,6 +577,35 @@ extern "C" int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16) {
     return 0;
 }
 
+// diagnostic: per-instance solver state the most recent finished solve left in the workspace, row by row (out [B][12], host):
+// {iterations, status, mu, alpha (1e300: the line search found no acceptable step), alpha_dual, fraction-to-boundary alpha, delta_w,
+//  exact Hessian wanted next, factorisation retries, rejected trials, KKT error of the previous iterate, stall counter} -- with
+// max_iter = k these are the decisions of iteration k - 1 (tests/test_iterate_parity.py compares them with the oracle's).  Needs
+// a solve that kept every instance in a slot of its own (B <= slots).
+extern "C" int bmpc_debug_inst_state(bmpc_handle* h, int B, double* out) {
+    if (!h || !out) { if (h) h->err = "bmpc_debug_inst_state: null argument"; return 1; }
+    int rc = bmpc_wait(h);
+    if (rc) return rc;
+    WEDGED_FAIL(h);
+    if (!h->last_valid || h->last_args.B != B || B > h->pipe_cap || (h->o.pool_slots > 0 && B > h->o.pool_slots)) {
+        h->err = "bmpc_debug_inst_state: no finished solve of this batch size with a slot per instance on the handle"; return 1;
+    }
+    HIPCHK(h, hipSetDevice(h->o.device));
+    std::vector<InstState> st((size_t)B);
+    std::vector<int> src((size_t)B);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_pipe_st, st.size() * sizeof(InstState), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(src.data(), h->last_args.src, src.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int s = 0; s < B; s++) {
+        const InstState& t = st[(size_t)s];
+        const int row = src[(size_t)s];
+        if (row < 0 || row >= B) { h->err = "bmpc_debug_inst_state: slot map out of range"; return 1; }
+        double* o = out + (size_t)row * 12;
+        o[0] = t.it; o[1] = t.status; o[2] = t.mu; o[3] = t.alpha; o[4] = t.ad; o[5] = t.ap; o[6] = t.hreg; o[7] = t.hess_mode;
+        o[8] = t.tries; o[9] = t.bt; o[10] = t.err_prev; o[11] = t.stall;
+    }
+    return 0;
+}
+
 // diagnostic: keep the handle's stream busy for `ms` milliseconds (at most 10 s) -- lets a test exercise the watchdog
 extern "C" int bmpc_debug_spin(bmpc_handle* h, int ms) {
     if (!h) return 1;

@@ -159,6 +159,11 @@ int bmpc_last_kernel_ms(bmpc_handle* h, float* ms);
 
 /* Diagnostic builds (-DBMPC_PROFILE) only: per-phase shader-cycle sums of the last launches. */
 int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16);
+/* Diagnostic: per-instance solver state of the most recent finished solve (B rows of 12 doubles, host memory): iterations, status,
+ * mu, alpha (1e300: no acceptable step), alpha_dual, fraction-to-boundary alpha, delta_w, exact Hessian wanted next, factorisation
+ * retries, rejected line-search trials, KKT error of the previous iterate, stall counter.  With max_iter = k: the decisions of
+ * iteration k - 1, which the iterate-for-iterate parity test compares with the oracle's.  B <= workspace slots. */
+int bmpc_debug_inst_state(bmpc_handle* h, int B, double* out);
 /* Diagnostic: keeps the handle's stream busy for `ms` milliseconds (at most 10 s, then the kernel ends by itself), so that the
  * watchdog (bmpc_opts.watchdog_ms) can be exercised without a kernel that really hangs. */
 int bmpc_debug_spin(bmpc_handle* h, int ms);

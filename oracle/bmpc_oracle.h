@@ -92,6 +92,15 @@ int bmpc_oracle_solve_batch(const bmpc_oracle_opts* o, int B, const double* x0,
                             const double* lbx, const double* ubx, const double* p, double* x,
                             double* f, int* iters, int* status, double* viol, int nthreads);
 
+/* The same + info[B][BMPC_ORACLE_INFO]: decisions of the LAST iteration of each solve -- {iterations, status, mu, alpha (1e300: no
+ * acceptable step), alpha_dual, fraction-to-boundary alpha, delta_w, exact Hessian wanted next, factorisation retries, rejected
+ * trials, KKT error of the previous iterate, stall counter}; compared with the HIP path's per-instance state by
+ * tests/test_iterate_parity.py, run by run with max_iter = 1, 2, 3, ... */
+#define BMPC_ORACLE_INFO 12
+int bmpc_oracle_solve_batch_info(const bmpc_oracle_opts* o, int B, const double* x0,
+                                 const double* lbx, const double* ubx, const double* p, double* x,
+                                 double* f, int* iters, int* status, double* viol, double* info, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

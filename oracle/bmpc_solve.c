@@ -1041,6 +1041,13 @@ static void recover_multipliers(prob_t* pb, const double* x, double* lam_g, doub
     free(J); free(gr); free(res);
 }
 
+/* Decisions of the LAST iteration a solve took (tests/test_iterate_parity.py compares them with the HIP path's InstState, run by
+ * run with max_iter = 1, 2, 3, ...): when non-NULL, bmpc_oracle_solve leaves
+ *   {iterations, status, mu, alpha (1e300: no acceptable step), alpha_dual, alpha fraction-to-boundary, delta_w, exact Hessian
+ *    wanted next, factorisation retries, backtracks, KKT error of the previous iterate, stall counter}   (BMPC_ORACLE_INFO = 12)
+ * here; set per thread by bmpc_oracle_solve_batch_info. */
+static _Thread_local double* g_info = NULL;
+
 int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double* lbx,
                       const double* ubx, const double* p, double* x, double* g, double* lam_g,
                       double* lam_x, double* f, int* iters, int* status, double* viol) {
@@ -1073,6 +1080,8 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
     int gn_skip = 0, gn_back = 0;
     double alpha_last = 1e300;
     int stall = 0;                   /* iterations since the optimality error last improved (by 10 %) */
+    double info_ad = 0, info_ap = 0, info_dw = 0;      /* last iteration's decisions (g_info) */
+    int info_tries = 0, info_bt = 0;
     for (it = 0;; it++) {
         /* gdual needs current z: assemble with a provisional mu (only H,g depend on mu) */
         for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
@@ -1225,7 +1234,7 @@ for (int k = 1; k < N; k++) {
          * fraction-to-boundary length): an iterate that needed six halvings is unlikely to take a full step next time, and every
          * rejected trial is an evaluation pass (a super-step on the GPU).  0: always from the fraction-to-boundary length (IPOPT) */
         if (o->ls_alpha_mem > 0 && it > 0) alpha = fmin(ap, o->ls_alpha_mem * alpha_last);
-        int ls_ok = 0, armijo_case = 0;
+        int ls_ok = 0, armijo_case = 0, ls_bt = 0;   /* ls_bt: rejected trials (a failed search keeps its tenth trial: 9) */
         const int soc_on = o->soc, soc_after = o->soc_after;
         double* save = (double*)malloc(sizeof(double) * N * (NZ + MAXROWS));
         for (int k = 1; k < N; k++) {
@@ -1233,6 +1242,7 @@ for (int k = 1; k < N; k++) {
             memcpy(save + k * (NZ + MAXROWS) + NZ, pb.st[k].t, sizeof(double) * MAXROWS);
         }
         for (int bt = 0; bt < 10; bt++) {
+            ls_bt = bt;
             bmpc_dbg_trials++;
             for (int k = 1; k < N; k++) {
                 stage_t* s = &pb.st[k];
@@ -1415,6 +1425,8 @@ for (int k = 1; k < N; k++) {
         }
         err_prev = kk.err;
         alpha_last = ls_ok ? alpha : 1e300;      /* a search that found no acceptable step leaves no memory */
+        info_ad = ad; info_ap = ap; info_dw = pb.hreg; info_tries = tries;
+        info_bt = ls_bt;
         pb.hreg = 0.0;                       /* the next iteration's model starts without a correction */
         if (kk.err < 0.9 * err_best) { err_best = kk.err; stall = 0; } else stall++;
         if (o->verbose > 1 && lim_k > 0) {
@@ -1434,6 +1446,12 @@ for (int k = 1; k < N; k++) {
         if (o->verbose > 1) printf("      alpha_p %.3g (ftb %.3g) alpha_d %.3g ls_ok %d nu %.2e D %.2e th %.2e hreg %.1e tries %d hess %d stall %d\n", alpha, ap, ad, ls_ok, nu, D, th0, pb.hreg, tries, pb.hess, stall);
     }
 done:
+    if (g_info) {
+        int want = (o->hess == 2) && ((err_prev < o->hess_switch) || (o->inertia == 2 && stall >= o->stall_n));
+        if (o->gn_backoff > 0 && want && gn_skip > 0) want = 0;
+        g_info[0] = it; g_info[1] = st; g_info[2] = mu; g_info[3] = alpha_last; g_info[4] = info_ad; g_info[5] = info_ap;
+        g_info[6] = info_dw; g_info[7] = want; g_info[8] = info_tries; g_info[9] = info_bt; g_info[10] = err_prev; g_info[11] = stall;
+    }
     /* ---- outputs in the reference layout ---- */
     {
         memset(x, 0, sizeof(double) * n_w);
@@ -1513,6 +1531,25 @@ int bmpc_oracle_solve_batch(const bmpc_oracle_opts* o, int B, const double* x0,
         bmpc_oracle_solve(o, x0 + (size_t)b * n_w, lbx + (size_t)b * n_w, ubx + (size_t)b * n_w,
                           p + (size_t)b * BMPC_NP, x + (size_t)b * n_w, NULL, NULL, NULL, f + b,
                           iters + b, status + b, viol + b);
+    return 0;
+}
+
+/* the same, and info[b][BMPC_ORACLE_INFO]: the decisions of the last iteration of every solve (see g_info) */
+int bmpc_oracle_solve_batch_info(const bmpc_oracle_opts* o, int B, const double* x0,
+                                 const double* lbx, const double* ubx, const double* p, double* x,
+                                 double* f, int* iters, int* status, double* viol, double* info, int nthreads) {
+    int n_w = 44 * o->N + 6;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic)
+#endif
+    for (int b = 0; b < B; b++) {
+        g_info = info + (size_t)b * BMPC_ORACLE_INFO;
+        bmpc_oracle_solve(o, x0 + (size_t)b * n_w, lbx + (size_t)b * n_w, ubx + (size_t)b * n_w,
+                          p + (size_t)b * BMPC_NP, x + (size_t)b * n_w, NULL, NULL, NULL, f + b,
+                          iters + b, status + b, viol + b);
+        g_info = NULL;
+    }
     return 0;
 }
 

@@ -103,3 +103,24 @@ def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, nthreads=0, 
     lib().bmpc_oracle_solve_batch(ctypes.byref(o), B, _P(x0), _P(lbx), _P(ubx), _P(p), _P(x), _P(f),
                                   it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), _P(viol), nthreads)
     return dict(x=x, f=f, iters=it, status=st, viol=viol)
+
+
+INFO_FIELDS = ("iters", "status", "mu", "alpha", "alpha_dual", "alpha_ftb", "delta_w", "hess_next", "retries", "backtracks", "err_prev", "stall")
+
+
+def solve_batch_info(N, x0, lbx, ubx, p, nthreads=0, **kw):
+    """solve_batch + info [B][12]: the decisions of the last iteration of every solve (bmpc_oracle_solve_batch_info)."""
+    B = x0.shape[0]
+    d = dict(dt=0.1, tol=1e-5, max_iter=100, hess=2, mu_strategy=1, hess_switch=1.0, mu_init=0.1, kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0,
+             inertia=2, dw0=1e-4, inertia_err=1e-2, stall_n=8, mu_floor_k=1e4, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0, soc=0, soc_after=0, pi_shoot=0)
+    d.update(kw)
+    o = Opts(N, d["dt"], d["tol"], d["max_iter"], 0, d["hess"], d["mu_strategy"], d["hess_switch"], d["mu_init"], d["kappa_mu"], d["theta_mu"],
+             d["kappa_eps"], d["inertia"], d["dw0"], d["inertia_err"], d["stall_n"], d["gn_backoff"], d["slack_reset"], d["ls_alpha_mem"],
+             d["mu_floor_k"], d["soc"], d["soc_after"], d["pi_shoot"])
+    lbx = np.where(np.isinf(lbx), -1e20, lbx); ubx = np.where(np.isinf(ubx), 1e20, ubx)
+    x0, lbx, ubx, p = (np.ascontiguousarray(a, float) for a in (x0, lbx, ubx, p))
+    x = np.zeros_like(x0); f = np.zeros(B); viol = np.zeros(B); info = np.zeros((B, 12))
+    it = np.zeros(B, np.int32); st = np.zeros(B, np.int32)
+    lib().bmpc_oracle_solve_batch_info(ctypes.byref(o), B, _P(x0), _P(lbx), _P(ubx), _P(p), _P(x), _P(f),
+                                       it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), _P(viol), _P(info), nthreads)
+    return dict(x=x, f=f, iters=it, status=st, viol=viol, info=info)
