@@ -333,9 +333,30 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     const long max_steps = hook ? (1L << 40) : 12L * (h->o.max_iter + 2) * ((B + cap - 1) / cap + 1);
     while (retired < B && steps < max_steps) {
         const int burst = steps < 8 ? 8 : 4;
+        if (hook) {
+            // closed loop without lock step: a burst of super-steps, then the counters come back and exactly the rollouts whose
+            // solve finished in this burst (cnt[8], the done list) are retired -- outputs, the caller's hook (post-processing, next
+            // problem), re-admission -- with grids sized by that count; nothing is launched when nobody finished.  (Round 3 ran
+            // the whole retirement sequence before every super-step with grids sized for all rollouts: ~1 ms of empty launches
+            // per super-step.)  A finished rollout waits at most one burst for its next problem.
+            for (int i = 0; i < burst; i++, steps++) HIPCHK(h, bmpc_pipe_launch_step(&A, n_act, st));
+            HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
+            if (int r = wait_stream(h, st)) return r;
+            const int n_done = h->h_cnt[8];
+            if (n_done > 0) { if (int r = retire(n_done, 1)) return r; }
+            retired = h->h_cnt[7];                   // rows whose rollout has ended (counted by k_admit: one burst behind)
+            if (n_done > 0 && retired + n_done >= B) {      // possibly the last ones: their retirement decides whether anybody goes on
+                HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
+                if (int r = wait_stream(h, st)) return r;
+                retired = h->h_cnt[7];
+            }
+            n_act = B - retired;
+            h->n_active.store(B - retired);
+            continue;
+        }
         // while input rows are left (as far as the host knows: next_row only grows), finished instances make room before
         // every super-step; afterwards they are retired once per burst
-        const bool rows_left = streaming && (hook ? retired < B : next_row < B);
+        const bool rows_left = streaming && next_row < B;
         for (int i = 0; i < burst; i++, steps++) {
             if (rows_left && i > 0) { if (int r = retire(cap, 1)) return r; }
             HIPCHK(h, bmpc_pipe_launch_step(&A, rows_left ? cap : n_act, st));
@@ -346,7 +367,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
         retired = h->h_cnt[7];
         next_row = h->h_cnt[6] < B ? h->h_cnt[6] : B;
         n_act = next_row - retired;
-        if (streaming && (hook ? retired < B : next_row < B)) n_act = cap < B ? cap : B;
+        if (streaming && next_row < B) n_act = cap < B ? cap : B;
         h->n_active.store(B - retired);
     }
     h->last_steps = steps;
