@@ -36,7 +36,9 @@ HORIZON = 20
 BATCH_PER_GPU = 8192
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VEC_PEAK_TFLOPS = 78.6    # vector FP64 peak (spec); the binding resource of this kernel
-MAX_DISTINCT = 24              # distinct batches resident at once (231 MB each); longer runs cycle through them
+MAX_DISTINCT = 16              # distinct batches resident at once (231 MB each); longer runs (and the warm-up) cycle through them
+MAX_DISTINCT_MULTI = 8         # ... per rank of a multi-GPU run: 6 generator processes per rank build 8 batches in < 60 s
+RIC_FLOPS_PER_STAGE = 1.13e5   # Riccati share of the SURVEY 8(d) stage model (F_stage = 1.2e5: n_x = 26, n_u = 9), per instance, stage, sweep
 
 
 def alg_bytes_per_solve(N):
@@ -47,6 +49,17 @@ def alg_bytes_per_solve(N):
 def alg_flops_per_solve(N, iters):
     # iters * N * F_stage, F_stage = 1.2e5 (condensed stage n_x=26, n_u=9)
     return iters * N * 1.2e5
+
+
+def kernel_src_sha():
+    """Hash of the device sources the library was built from: profiles/pmc_traffic.json is stamped with it when the PMC passes are
+    taken (tools/summarize_pmc.py), so that a traffic figure measured on an older build is flagged (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "boundplanner_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def batch_seed(world, rank, step):
@@ -149,11 +162,11 @@ def main():
     M = max(1, min(args.merge, 4))
     if args.pool > 0:
         M = max(1, min((args.steps + depth - 1) // depth, MAX_DISTINCT))      # the timed batches in `depth` streaming calls
-    n_distinct = 1 if args.same_batch else min(max(args.steps + args.warmup, M), MAX_DISTINCT)
+    n_distinct = 1 if args.same_batch else min(max(args.steps, M), MAX_DISTINCT if world == 1 else MAX_DISTINCT_MULTI)
     n_distinct = M * ((n_distinct + M - 1) // M)
     # instance-building workers: forked BEFORE this process initialises the GPU; they never touch it
     pool = None
-    n_workers = args.gen_workers if args.gen_workers is not None else max(0, min(16, len(os.sched_getaffinity(0)) // max(1, world) - 2))
+    n_workers = args.gen_workers if args.gen_workers is not None else max(0, min(32, len(os.sched_getaffinity(0)) // max(1, world) - 2))
     if n_workers > 0 and n_distinct > 1:
         import multiprocessing as mp
         pool = mp.get_context("fork").Pool(n_workers)
@@ -225,6 +238,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    profiling_pass = world == 1 and depth == 1 and M == 1 and n_distinct == 1      # (the timed batch IS the lone batch below)
+    if rank == 0 and profiling_pass:
+        be.time_ric(True)
     stream.run(args.warmup)
     barrier()
     stream.kernel_ms.clear()
@@ -241,9 +257,14 @@ def main():
     # ---- untimed: the seed-of-step-0 batch alone on one handle -> solver statistics, parity sample, shard check ----
     one = BatchStream([HipHandle(be)], [outs[0]], {k: v[:B] for k, v in d.items()}, B, merge=1, dist=dist,
                       gathered=gathered, sync_gather=lambda: torch.cuda.current_stream(dev).synchronize())
-    if world > 1 or not (depth == 1 and M == 1 and n_distinct == 1):     # (profiling passes: the timed batch IS that solve)
+    if not profiling_pass:
+        if rank == 0:
+            be.time_ric(True)       # HIP events around every launch of the Riccati kernel on the handle's stream: the roofline leg
         one.run(1)
     torch.cuda.synchronize(dev)
+    ric = be.ric_stats() if rank == 0 else None
+    if rank == 0:
+        be.time_ric(False)
     x = outs[0]["x"][:B]
     it_np, st_np, viol_np = (outs[0][k][:B].cpu().numpy() for k in ("iters", "status", "viol"))
     ok = (st_np == 0) | (viol_np < 1e-4)            # the reference's acceptance test (BoundMPC.py:617)
@@ -279,17 +300,47 @@ def main():
     mean_it = float(it_np.mean())
     ach_tf = alg_flops_per_solve(N, mean_it) * B / (k_ms * 1e-3) / 1e12
 
-    # HBM bytes of one batch from the PMC passes of tools/profile_round.sh (separate rocprofv3 --pmc runs of one
-    # synchronous batch of this same workload), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-    traffic, traffic_note, fetch_raw, write_raw = None, None, None, None
+    # HBM bytes of one batch from the PMC passes of tools/gpu_quick.sh / profile_round.sh (separate rocprofv3 --pmc runs of one
+    # synchronous batch of this same workload), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; stamped with the
+    # hash of the device sources it was taken on -- a figure from another build is reported as stale
+    traffic, traffic_note, fetch_raw, write_raw, traffic_stale = None, None, None, None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj) and (B, N) == (BATCH_PER_GPU, HORIZON):
         t = json.load(open(tj))
         fetch_raw, write_raw = t["fetch_bytes_raw"], t["write_bytes"]
         traffic = 2.0 * fetch_raw + write_raw
-        traffic_note = (f"profiles/pmc_traffic.json ({t.get('build', 'round-1 build')}): 2 x FETCH_SIZE {t['fetch_bytes_raw'] / 1e9:.1f} GB (gfx950 "
+        traffic_stale = t.get("kernel_src_sha16") != kernel_src_sha()
+        traffic_note = (f"profiles/pmc_traffic.json (device sources {t.get('kernel_src_sha16', 'unstamped')}): 2 x FETCH_SIZE {t['fetch_bytes_raw'] / 1e9:.1f} GB (gfx950 "
                         f"correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE {t['write_bytes'] / 1e9:.1f} GB per batch, all kernels")
 
+    # roofline of the DOMINANT KERNEL, bmpc_k_ric (the backward Riccati sweep: ~40 % of a batch's kernel time): algorithmic flops of
+    # its launches over their summed duration, measured live with HIP events around every launch on the handle's stream while the
+    # step-0 batch is solved alone (no other call in flight: a launch's duration is its own).  An instance-iteration is one
+    # backward sweep over the N-1 stages (retry sweeps -- Gauss-Newton fallback, delta_w escalation -- run in the same launch
+    # and are not counted as work).  The latency variant bmpc_k_ric_lat (nearly empty super-steps of the tail) is reported beside it.
+    roof = {"bound": "valu_fp64", "kernel": "bmpc_k_ric", "achieved": None, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None}
+    if ric is not None:
+        ms_b, n_b, sw_b = ric["bmpc_k_ric"]
+        ms_l, n_l, sw_l = ric["bmpc_k_ric_lat"]
+        fl = RIC_FLOPS_PER_STAGE * (N - 1)
+        if ms_b > 0:
+            roof["achieved"] = sw_b * fl / (ms_b * 1e-3) / 1e12
+            roof["frac"] = roof["achieved"] / FP64_VEC_PEAK_TFLOPS
+        roof.update({"launches": int(n_b), "launch_ms_avg": ms_b / n_b if n_b else None, "launch_ms_sum": ms_b, "instance_iterations": int(sw_b),
+                     "alg_flops_per_instance_iteration": fl,
+                     "measured": "HIP events around every launch on the solver handle's stream (bmpc_debug_time_ric), the step-0 batch alone",
+                     "latency_variant": {"kernel": "bmpc_k_ric_lat", "launches": int(n_l), "launch_ms_avg": ms_l / n_l if n_l else None,
+                                         "launch_ms_sum": ms_l, "instance_iterations": int(sw_l)}})
+    roof.update({"traffic": traffic, "traffic_stale": traffic_stale, "traffic_note": traffic_note,
+                 # measured HBM bytes of a batch (all kernels) over the per-batch time of THIS run: what the memory system sustains
+                 "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                 "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                 "fetch_size_raw_bytes": fetch_raw, "write_size_bytes": write_raw,
+                 # SURVEY 8(d)'s HBM figure: compulsory bytes of a solve (x0, p, state in; x out) over the per-batch time
+                 "hbm_alg_gbs": ach_gbs, "hbm_alg_frac": ach_gbs / HBM_PEAK_GBS, "alg_bytes_per_solve": alg_bytes_per_solve(N),
+                 "per_batch_ms": k_ms, "event_ms_per_batch": event_ms})
+
+    gather_name = "gloo all-gather (one-GPU rehearsal)" if args.rehearse_one_gpu else "RCCL all-gather"
     out = {
         "metric": "MPC solves/sec (whole node), iiwa14 7-DOF, N=20",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -298,26 +349,19 @@ def main():
         "config": {"workload": (f"BASELINE configs[2]: {B}-batch, randomized convex-set obstacles, N={N}, cold start, tol 1e-5, "
                                 "max_iter 100; a fresh batch every step" if world == 1 else
                                 f"BASELINE configs[3]: one {world * B}-batch (seed 65536) cut into {world} contiguous shards of {B}, "
-                                f"randomized convex-set obstacles, N={N}, cold start, RCCL all-gather of x"),
-                   "value_is": "device-resident inputs, pipelined solver calls (see solver_handles_in_flight / batches_per_solver_call); "
-                               "value_single_batch and value_pcie_inclusive are the SURVEY 8(d) one-batch figures",
+                                f"randomized convex-set obstacles, N={N}, cold start, {gather_name} of x"),
+                   "value_is": "inputs resident in HBM when the timed region starts, pipelined solver calls (solver_handles_in_flight / "
+                               "batches_per_solver_call): `value` EXCLUDES host<->device transfers.  The SURVEY 8(d) figure with the transfers "
+                               "inside the same schedule is value_pcie_inclusive_pipelined; value_single_batch / value_pcie_inclusive are one batch at a time",
                    "batch_per_gpu": B, "horizon": N, "distinct_batches": n_distinct,
-                   "sharding": "contiguous shards, no data-path collective, RCCL all-gather of x" if world > 1 else "single GPU",
+                   "sharding": f"contiguous shards, no data-path collective, {gather_name} of x" if world > 1 else "single GPU",
                    "hess": int(be.opts.hess), "solver_handles_in_flight": depth,
                    "batches_per_solver_call": M, "batches_in_flight": depth * M, "pool_slots": args.pool},
         "solver": {"iters_mean": mean_it, "iters_p50": float(np.median(it_np)), "iters_p99": float(np.percentile(it_np, 99)),
                    "iters_max": int(it_np.max()), "converged_frac": float((st_np == 0).mean()),
                    "accepted_frac": float(ok.mean()), "gen_s": t_gen, "stats_of": "the step-0 batch solved alone"},
-        "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                     # measured HBM bytes of a batch over the per-batch time of THIS run: what the memory system actually sustains
-                     "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                     "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "fetch_size_raw_bytes": fetch_raw, "write_size_bytes": write_raw,
-                     "kernel": "bmpc_k_ric (+ bmpc_k_eval, k_step, k_trial): one batch",
-                     "kernel_ms": k_ms, "event_ms_per_batch": event_ms, "alg_bytes_per_solve": alg_bytes_per_solve(N),
-                     "note": "not HBM- or MFMA-bound: latency/VALU/LDS-bound small-matrix IP loop (DESIGN.md); "
-                             "the meaningful limiter is FP64 VALU, reported in valu_fp64"},
+        "roofline": roof,
+        # the whole path against the same peak: SURVEY 8(d)'s flop model of a solve over the per-batch time of the timed region
         "valu_fp64": {"achieved": ach_tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": ach_tf / FP64_VEC_PEAK_TFLOPS, "alg_flops_per_solve": alg_flops_per_solve(N, mean_it)},
     }
@@ -386,11 +430,18 @@ def main():
         x_gpu = x[:ns].cpu().numpy()
         both = (ro["status"] == 0) & (st_np[:ns] == 0)
         same_it = both & (ro["iters"] == it_np[:ns])
+        # a genuine CasADi + IPOPT timing if the box happens to have the wheel -- probed, not assumed
+        try:
+            import casadi  # noqa: F401
+            ipopt_on_box = True
+        except Exception:
+            ipopt_on_box = False
         out["cpu_baseline"] = {
-            "value": ns / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
+            "value": ns / tc, "unit": "solves/s", "cores": nthr, "kind": "port", "ipopt_on_box": ipopt_on_box,
             "sample": f"first {ns} instances of the step-0 batch, oracle/bmpc_solve.c (same algorithm, FP64, -O3 -march=x86-64-v3, "
-                      f"OpenMP over instances) on {nthr} host threads in {tc:.1f} s; the reference's CasADi+IPOPT "
-                      "cannot run here (no wheel, no network)",
+                      f"OpenMP over instances) on {nthr} host threads in {tc:.1f} s, threads not pinned, the box is shared: +-25 % between runs; "
+                      + ("casadi imports on this box but the IPOPT leg is not wired up: parity with IPOPT stays unpinned" if ipopt_on_box else
+                         "`import casadi` fails on this box, so the reference's CasADi+IPOPT cannot be timed: IPOPT parity unpinned"),
             "iters_mean": float(ro["iters"].mean()),
             "status_equal_frac": float((ro["status"] == st_np[:ns]).mean()),
             "iters_equal_frac_of_both_converged": float(same_it.sum() / max(1, both.sum())),

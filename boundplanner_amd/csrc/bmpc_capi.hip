@@ -28,7 +28,7 @@ extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_ma
 // closed loop: called between the two halves of a retirement with the list of slots whose instances have just retired
 // (device pointers: list, its length); enqueues the caller's post-processing / next-problem kernels on the stream
 typedef int (*bmpc_retire_hook)(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream);
-extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st);
+extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int* was_lat);
 extern "C" hipError_t bmpc_pipe_launch_mult(const PipeArgsH* A, hipStream_t st);
 extern "C" void bmpc_pipe_build_table(int* tbl);
 extern "C" size_t bmpc_pipe_state_bytes(void);
@@ -65,6 +65,12 @@ struct bmpc_handle {
     bool cap_g = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
+    // bmpc_debug_time_ric: HIP events around every launch of the Riccati kernel (the dominant kernel: bench.py's roofline leg)
+    bool time_ric = false;
+    hipEvent_t ric_ev[16] = {nullptr};      // 8 pairs: a burst has at most 8 super-steps and ends with a wait for the stream
+    int ric_pending = 0, ric_is_lat[8] = {0};
+    double ric_ms[2] = {0, 0};              // [0] bmpc_k_ric, [1] bmpc_k_ric_lat: summed launch durations of the last solve
+    long ric_launches[2] = {0, 0}, ric_sweeps[2] = {0, 0};
     bool wedged = false;           // a wait ran into the watchdog: the stream may still be busy, the handle refuses further work
     float last_ms = 0.f;
     std::atomic<bool> busy{false}; // a solve is running on this handle (a handle serves one host thread at a time)
@@ -179,7 +185,16 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (!h) return;
     if (h->n_loops.load() > 0) { h->destroy_pending = true; return; }     // deferred until the last loop is gone
     if (h->worker.joinable()) h->worker.join();
+    if (h->wedged) {
+        // The handle ran into its watchdog: its stream may never drain, and kernels still queued on it may write the workspace.
+        // Nothing is waited for and nothing is freed -- device buffers, events and the stream are leaked on purpose (a
+        // hipStreamSynchronize / hipFree here is the unbounded wait the watchdog exists to prevent).  The process should end
+        // with an error and let a fresh one take over (include/boundmpc.h, bmpc_opts.watchdog_ms).
+        delete h;
+        return;
+    }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ric_ev) if (e) (void)hipEventDestroy(e);
     double* bufs[] = {h->d_x0, h->d_lbx, h->d_ubx, h->d_p, h->d_x, h->d_g, h->d_f, h->d_viol};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->d_iters) (void)hipFree(h->d_iters);
@@ -215,6 +230,7 @@ extern "C" void bmpc_robot_gen3(bmpc_robot* r) { if (r) robot_gen3(*r); }
 
 extern "C" int bmpc_set_robot(bmpc_handle* h, const bmpc_robot* r) {
     if (!h || !r) return 1;
+    WEDGED_FAIL(h);
     int rc_ = bmpc_wait(h);
     if (rc_) return rc_;
     BUSY_OR_FAIL(h, "bmpc_set_robot");
@@ -280,6 +296,23 @@ static int pipe_ensure(bmpc_handle* h, int B) {
     return 0;
 }
 
+// one super-step; with bmpc_debug_time_ric the Riccati launch is bracketed by an event pair (collected by ric_collect after the
+// next wait for the stream)
+static hipError_t step_timed(bmpc_handle* h, PipeArgsH* A, int n_act, hipStream_t st) {
+    if (!h->time_ric || h->ric_pending >= 8) return bmpc_pipe_launch_step(A, n_act, st, nullptr, nullptr, nullptr);
+    const int i = h->ric_pending++;
+    return bmpc_pipe_launch_step(A, n_act, st, h->ric_ev[2 * i], h->ric_ev[2 * i + 1], &h->ric_is_lat[i]);
+}
+static void ric_collect(bmpc_handle* h) {        // the stream is idle: every recorded pair has completed
+    for (int i = 0; i < h->ric_pending; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ric_ev[2 * i], h->ric_ev[2 * i + 1]) == hipSuccess) {
+            h->ric_ms[h->ric_is_lat[i] ? 1 : 0] += ms; h->ric_launches[h->ric_is_lat[i] ? 1 : 0] += 1;
+        }
+    }
+    h->ric_pending = 0;
+}
+
 static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
                       const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
                       double* d_viol, hipStream_t st, bmpc_retire_hook hook = nullptr, void* hook_ctx = nullptr,
@@ -330,6 +363,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     // read back every few super-steps.
     int n_act = n0, steps = 0, retired = 0, next_row = n0;
     h->n_active.store(B);
+    h->ric_pending = 0; h->ric_ms[0] = h->ric_ms[1] = 0; h->ric_launches[0] = h->ric_launches[1] = 0;
     const long max_steps = hook ? (1L << 40) : 12L * (h->o.max_iter + 2) * ((B + cap - 1) / cap + 1);
     while (retired < B && steps < max_steps) {
         const int burst = steps < 8 ? 8 : 4;
@@ -339,9 +373,10 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
             // problem), re-admission -- with grids sized by that count; nothing is launched when nobody finished.  (Round 3 ran
             // the whole retirement sequence before every super-step with grids sized for all rollouts: ~1 ms of empty launches
             // per super-step.)  A finished rollout waits at most one burst for its next problem.
-            for (int i = 0; i < burst; i++, steps++) HIPCHK(h, bmpc_pipe_launch_step(&A, n_act, st));
+            for (int i = 0; i < burst; i++, steps++) HIPCHK(h, step_timed(h, &A, n_act, st));
             HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
             if (int r = wait_stream(h, st)) return r;
+            ric_collect(h);
             const int n_done = h->h_cnt[8];
             if (n_done > 0) { if (int r = retire(n_done, 1)) return r; }
             retired = h->h_cnt[7];                   // rows whose rollout has ended (counted by k_admit: one burst behind)
@@ -359,11 +394,12 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
         const bool rows_left = streaming && next_row < B;
         for (int i = 0; i < burst; i++, steps++) {
             if (rows_left && i > 0) { if (int r = retire(cap, 1)) return r; }
-            HIPCHK(h, bmpc_pipe_launch_step(&A, rows_left ? cap : n_act, st));
+            HIPCHK(h, step_timed(h, &A, rows_left ? cap : n_act, st));
         }
         if (int r = retire(rows_left ? cap : n_act, rows_left ? 1 : 0)) return r;
         HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
         if (int r = wait_stream(h, st)) return r;
+        ric_collect(h);
         retired = h->h_cnt[7];
         next_row = h->h_cnt[6] < B ? h->h_cnt[6] : B;
         n_act = next_row - retired;
@@ -371,6 +407,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
         h->n_active.store(B - retired);
     }
     h->last_steps = steps;
+    h->ric_sweeps[0] = h->h_cnt[11]; h->ric_sweeps[1] = h->h_cnt[12];
     HIPCHK(h, hipEventRecord(h->ev1, st));
     // the outputs are complete and the per-handle workspace is free when the call returns (the loop above synchronised)
     if (int r = wait_stream(h, st)) return r;
@@ -458,6 +495,7 @@ extern "C" int bmpc_solve_dev_async(bmpc_handle* h, int B, const double* d_x0, c
 // in the workspace.  d_lam_g [B][n_g], d_lam_x [B][n_w]: device pointers; enqueued on `stream` and waited for.
 extern "C" int bmpc_multipliers_dev(bmpc_handle* h, int B, double* d_lam_g, double* d_lam_x, void* stream) {
     if (!h || !d_lam_g || !d_lam_x) { if (h) h->err = "bmpc_multipliers_dev: null argument"; return 1; }
+    WEDGED_FAIL(h);
     int rc = bmpc_wait(h);
     if (rc) return rc;
     if (!h->last_valid || h->last_args.B != B) { h->err = "bmpc_multipliers_dev: no finished solve of this batch size on the handle"; return 1; }
@@ -501,6 +539,7 @@ extern "C" int bmpc_solve(bmpc_handle* h, int B, const double* x0, const double*
         return 1;
     }
     if (B == 0) return 0;
+    WEDGED_FAIL(h);                // (before ensure_cap below, whose hipFree would wait for a stream that never drains)
     int rc = bmpc_wait(h);         // an asynchronous solve in flight owns the workspace
     if (rc) return rc;
     BUSY_OR_FAIL(h, "bmpc_solve");
@@ -627,9 +666,31 @@ extern "C" int bmpc_debug_inst_state(bmpc_handle* h, int B, double* out) {
     return 0;
 }
 
+// diagnostic / measurement: HIP events around every launch of the Riccati kernel (bmpc_k_ric: the throughput variant, bmpc_k_ric_lat:
+// the latency variant of nearly empty super-steps) on the handle's stream, from the next solve on.  bmpc_debug_ric_stats returns, for
+// the most recent solve, out[0..2] = {summed launch durations in ms, launches, instance-iterations (workgroups that ran)} of
+// bmpc_k_ric and out[3..5] the same for bmpc_k_ric_lat.  bench.py's roofline leg: algorithmic flops of the launches / their duration.
+extern "C" int bmpc_debug_time_ric(bmpc_handle* h, int on) {
+    if (!h) return 1;
+    int rc = bmpc_wait(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->o.device));
+    if (on && !h->ric_ev[0]) for (auto& e : h->ric_ev) HIPCHK(h, hipEventCreate(&e));
+    h->time_ric = on != 0;
+    return 0;
+}
+extern "C" int bmpc_debug_ric_stats(bmpc_handle* h, double* out6) {
+    if (!h || !out6) return 1;
+    int rc = bmpc_wait(h);
+    if (rc) return rc;
+    for (int v = 0; v < 2; v++) { out6[3 * v] = h->ric_ms[v]; out6[3 * v + 1] = (double)h->ric_launches[v]; out6[3 * v + 2] = (double)h->ric_sweeps[v]; }
+    return 0;
+}
+
 // diagnostic: keep the handle's stream busy for `ms` milliseconds (at most 10 s) -- lets a test exercise the watchdog
 extern "C" int bmpc_debug_spin(bmpc_handle* h, int ms) {
     if (!h) return 1;
+    WEDGED_FAIL(h);
     HIPCHK(h, hipSetDevice(h->o.device));
     HIPCHK(h, bmpc_launch_spin(ms, h->stream));
     return 0;

@@ -149,6 +149,7 @@ extern "C" int bmpc_loop_set_record(bmpc_loop* L, int n, const int* rollouts) {
     std::vector<int> slot((size_t)L->R, -1);
     for (int j = 0; j < n; j++) {
         if (rollouts[j] < 0 || rollouts[j] >= L->R) { L->err = "bmpc_loop_set_record: rollout index out of range"; return 1; }
+        if (slot[(size_t)rollouts[j]] >= 0) { L->err = "bmpc_loop_set_record: a rollout is listed twice"; return 1; }
         slot[(size_t)rollouts[j]] = j;
     }
     if (!L->d_rec_slot) LCHK(L, hipMalloc((void**)&L->d_rec_slot, (size_t)L->R * sizeof(int)));
@@ -157,12 +158,15 @@ extern "C" int bmpc_loop_set_record(bmpc_loop* L, int n, const int* rollouts) {
     L->n_rec = n; L->rec_steps = 0;
     return 0;
 }
-// the records of the last bmpc_loop_run: out [steps][n][bmpc_loop_record_doubles(N)]
-extern "C" int bmpc_loop_records(bmpc_loop* L, double* out, int* steps) {
-    if (!L || !out) return 1;
+// the records of the last bmpc_loop_run: out [steps][n][bmpc_loop_record_doubles(N)], room for max_steps steps (out == NULL: only
+// *steps is returned, to size the buffer); more recorded steps than room: rc 1, nothing copied
+extern "C" int bmpc_loop_records(bmpc_loop* L, double* out, int max_steps, int* steps) {
+    if (!L || (!out && !steps)) return 1;
     LCHK(L, hipSetDevice(L->dev));
     LCHK(L, hipStreamSynchronize(L->st));
     if (steps) *steps = (int)L->rec_steps;
+    if (!out) return 0;
+    if (L->rec_steps > (size_t)(max_steps < 0 ? 0 : max_steps)) { L->err = "bmpc_loop_records: more recorded steps than the buffer holds"; return 1; }
     if (L->rec_steps > 0)
         LCHK(L, hipMemcpy(out, L->d_rec, L->rec_steps * L->n_rec * lp_rec_doubles(L->N) * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
@@ -364,6 +368,7 @@ extern "C" int bmpc_loop_finish(bmpc_loop* L, double* log) {
             L->rec_cap = need;
         }
     }
+    if (L->n_rec > 0) LCHK(L, hipMemsetAsync(L->d_rec, 0, (size_t)L->n_rec * lp_rec_doubles(L->N) * sizeof(double), L->st));      // (a dead rollout's record stays zero)
     if (int rc = launch_finish(L, L->st, L->R, log ? L->d_log : nullptr, nullptr, nullptr, nullptr, nullptr, 0, L->n_rec > 0 ? L->d_rec : nullptr)) return rc;
     L->rec_steps = L->n_rec > 0 ? 1 : 0;
     LCHK(L, hipStreamSynchronize(L->st));
@@ -385,6 +390,7 @@ extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_to
         }
     }
     double solve_s = 0.0;
+    if (L->n_rec > 0) LCHK(L, hipMemsetAsync(L->d_rec, 0, (size_t)nsteps * L->n_rec * lp_rec_doubles(L->N) * sizeof(double), L->st));     // (a dead rollout's record stays zero)
     LCHK(L, hipEventRecord(L->e0, L->st));
     for (int s = 0; s < nsteps; s++) {
         if (int rc = launch_prepare(L, L->st, L->R)) return rc;

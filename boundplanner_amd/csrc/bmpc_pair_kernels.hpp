@@ -1030,7 +1030,7 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b, bool requeue) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_step: row steps for the Newton direction dz (forward_sweep of bmpc_solver.hpp, row part)
+// k_step: row steps for the Newton direction dz
 // ------------------------------------------------------------------------------------------
 struct StepVisitor {
     const PipeArgs* A; size_t pi; bool valid;

@@ -107,15 +107,19 @@ extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_ma
 }
 
 // one super-step for at most n_act active instances; swaps the double-buffered lists in *A
-extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st) {
+// e0 / e1 (optional): events recorded around the Riccati launch (bmpc_debug_time_ric); *was_lat: which variant was launched
+extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int* was_lat) {
     const int nw = waves_for(A->N, n_act);
     LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
     // BMPC_RIC_LAT_BELOW in the environment (read once): A/B runs and the test that the two variants agree bitwise
     static const int lat_below = [] { const char* e = getenv("BMPC_RIC_LAT_BELOW"); return e ? atoi(e) : BMPC_RIC_LAT_BELOW; }();
+    if (e0) (void)hipEventRecord(e0, st);
     if (n_act < lat_below) LAUNCH(bmpc_k_ric_lat, n_act, BMPC_RIC_NT);
     else LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
+    if (e1) (void)hipEventRecord(e1, st);
+    if (was_lat) *was_lat = n_act < lat_below;
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
     // (BMPC_TRIAL_REPEATS in the environment, read once, overrides bmpc_opts.trial_repeats: A/B runs)

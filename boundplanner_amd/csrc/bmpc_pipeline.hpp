@@ -1,6 +1,6 @@
 // bmpc_pipeline.hpp -- batch-synchronous interior-point pipeline (device code, gfx950).
 //
-// The per-instance IP loop of bmpc_solver.hpp is split by parallelism:
+// One interior-point iteration (oracle/bmpc_solve.c documents the algebra) is split by its parallelism:
 //   * everything that is independent per (instance, stage) pair -- kinematics, rows, Hessian
 //     assembly, row steps, line-search trial evaluation -- runs ONE THREAD PER PAIR
 //     (bmpc_stage.hpp), iterate and row data in SoA arrays [field][pair] so that consecutive
@@ -102,8 +102,9 @@ template <int DEV> struct ListsT {           // work lists (slot ids) with their
     typename PtrT<DEV>::I done, admit;   // slots whose instance finished (to retire) / slots that got a new instance (to initialise)
     typename PtrT<DEV>::I cnt;   // [0] n_eval [1] n_step [2] n_trial [3] n_eval_next [4] n_trial_next [5] finished (cumulative)
                                  // [6] next input row to admit [7] retired (cumulative) [8] n_done [9] n_admit [10] n_curv
+                                 // [11] / [12] workgroups (= instance-iterations) run by bmpc_k_ric / bmpc_k_ric_lat (cumulative)
 };
-constexpr int NCNT = 12;
+constexpr int NCNT = 14;
 
 template <int DEV> struct PipeArgsT {
     typedef PtrT<DEV> PT;

@@ -913,6 +913,7 @@ BMPC_DEV void k_ric_body(RicArgs AH, int blk, int lane, LDSD* lds) {
     const int count = A.L.cnt[0];
     if (blk >= count) return;
     const int b = BMPC_UNIFORM(A.L.eval[blk]);
+    if (lane == 0) BMPC_ATOMIC_INC(A.L.cnt + (SPLIT ? 11 : 12));      // instance-iterations of this variant (bmpc_debug_ric_stats)
     const int N = A.N, n_w = 44 * N + 6;
     const auto& o = A.o;
     InstState* st = A.st + b;

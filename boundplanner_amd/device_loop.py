@@ -215,14 +215,15 @@ class DeviceLoop:
         self._chk(self.lib.bmpc_loop_set_record(self._l, len(sel), sel.ctypes.data_as(_ip) if len(sel) else None), "bmpc_loop_set_record")
         self._rec_sel = [int(r) for r in sel]
 
-    def records(self, max_steps=1):
+    def records(self):
         """Raw records [steps][len(rollouts)][width] of the last run() / finish(); mpc_data.from_device_record decodes one."""
         n = len(getattr(self, "_rec_sel", []))
         w = self.lib.bmpc_loop_record_doubles(self.N)
-        out = np.zeros((max_steps, max(n, 1), w))
         steps = ctypes.c_int(0)
-        self._chk(self.lib.bmpc_loop_records(self._l, self._P(out), ctypes.byref(steps)), "bmpc_loop_records")
-        return out[:steps.value, :n] if steps.value <= max_steps else None
+        self._chk(self.lib.bmpc_loop_records(self._l, None, 0, ctypes.byref(steps)), "bmpc_loop_records")      # how many steps were recorded
+        out = np.zeros((max(steps.value, 1), max(n, 1), w))
+        self._chk(self.lib.bmpc_loop_records(self._l, self._P(out), out.shape[0], ctypes.byref(steps)), "bmpc_loop_records")
+        return out[:steps.value, :n]
 
     # ---- stepping
     def run(self, nsteps, log=True):

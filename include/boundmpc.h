@@ -58,7 +58,9 @@ typedef struct {
                            itself): the whole line search of an iteration in one super-step.  0: one trial per super-step
                            (rounds 1-2).  Scheduling only, results do not depend on it (bitwise) */
     int watchdog_ms;    /* > 0 (default 30000): a wait for the GPU gives up after this long and the call returns 5 with a message
-                           (the handle is unusable afterwards); 0: plain hipStreamSynchronize */
+                           (the handle is unusable afterwards: every entry point returns 5, and bmpc_destroy neither waits for the
+                           stream nor frees device memory that queued kernels may still write -- it leaks them; end the process
+                           with an error and let a fresh one take over); 0: plain hipStreamSynchronize */
     int max_batch;      /* capacity hint for host-pointer calls (device staging buffers) */
     int pool_slots;     /* 0 (default) = every instance of a call has its own workspace slot; > 0 = the workspace
                            holds this many instances and a call with more of them STREAMS them through it: a slot whose
@@ -164,6 +166,12 @@ int bmpc_debug_phase_cycles(bmpc_handle* h, double* out16);
  * retries, rejected line-search trials, KKT error of the previous iterate, stall counter.  With max_iter = k: the decisions of
  * iteration k - 1, which the iterate-for-iterate parity test compares with the oracle's.  B <= workspace slots. */
 int bmpc_debug_inst_state(bmpc_handle* h, int B, double* out);
+/* Measurement: from the next solve on, HIP events bracket every launch of the Riccati kernel on the handle's stream
+ * (bmpc_debug_time_ric(h, 1)); bmpc_debug_ric_stats then returns for the most recent solve {summed launch durations [ms], launches,
+ * instance-iterations} of the throughput variant of that kernel in out6[0..2] and of its latency variant (nearly empty super-steps)
+ * in out6[3..5].  bench.py derives its roofline line from these. */
+int bmpc_debug_time_ric(bmpc_handle* h, int on);
+int bmpc_debug_ric_stats(bmpc_handle* h, double* out6);
 /* Diagnostic: keeps the handle's stream busy for `ms` milliseconds (at most 10 s, then the kernel ends by itself), so that the
  * watchdog (bmpc_opts.watchdog_ms) can be exercised without a kernel that really hangs. */
 int bmpc_debug_spin(bmpc_handle* h, int ms);
@@ -204,14 +212,15 @@ int bmpc_loop_download(bmpc_loop* l, int first, int count, double* state, double
 int bmpc_loop_run(bmpc_loop* l, int nsteps, double* log, float* ms_total, float* ms_solve);
 /* Trace records with the content of the reference's message boundmpcmsg/msg/MPCData.msg:1-64, written by the finish kernel for
  * the rollouts selected with bmpc_loop_set_record (n = 0 switches them off; they cost 16 + 64 N + 600 doubles per rollout and
- * step).  bmpc_loop_records copies the records of the last bmpc_loop_run / bmpc_loop_finish: out [steps][n][record_doubles(N)],
+ * step).  bmpc_loop_records copies the records of the last bmpc_loop_run / bmpc_loop_finish: out [steps][n][record_doubles(N)] with room for
+ * max_steps steps (rc 1 when more were recorded; out == NULL returns only *steps, to size the buffer; records of dead rollouts are zero),
  * each: header (iters, status, viol, error_count, valid stages n, sector, phi_max, split_idxs[5], next selector, 0, 0, 0);
  * N stage blocks of 64 (p 6, v 6, q 7, dq 7, ddq 7, dddq 7, phi, dphi, e_p 3, de_p 3, e_r 3, de_r 3, e_r_orth1, e_r_par,
  * e_r_orth2, p_ref 6, segment; zero beyond n); the a_set / b_set / a_set_joints / b_set_joints blocks of the step's parameter
  * vector (600).  boundplanner_amd.mpc_data.from_device_record decodes them.  Lock-step runs only. */
 int bmpc_loop_record_doubles(int N);
 int bmpc_loop_set_record(bmpc_loop* l, int n, const int* rollouts);
-int bmpc_loop_records(bmpc_loop* l, double* out, int* steps);
+int bmpc_loop_records(bmpc_loop* l, double* out, int max_steps, int* steps);
 /* The same nsteps MPC steps of all rollouts WITHOUT lock step: the rollouts are independent, so each one starts its next
  * step as soon as its own solve has retired (its workspace slot is re-admitted with the next problem, prepared on the
  * device) instead of waiting for the slowest solve of the batch at every step.  Same log as bmpc_loop_run (bitwise). */

@@ -1086,6 +1086,12 @@ int bmpc_oracle_solve(const bmpc_oracle_opts* o, const double* x0, const double*
         /* gdual needs current z: assemble with a provisional mu (only H,g depend on mu) */
         for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
         kkt_error(&pb, &kk, mu);
+        /* the second-order term of the pi dynamics in the exact Hessian is weighted by the adjoint multipliers lam_{k+1} that
+         * kkt_error has just computed AT THIS ITERATE (the HIP kernels take them from the same backward sweep); the assembly above
+         * still saw those of the previous iterate (round 4: found by the iterate-for-iterate comparison -- after the first
+         * exact-Hessian iteration the two sides' steps differed by 1e-3 relative) */
+        if (pb.hess)
+            for (int k = 1; k < N; k++) assemble_stage(&pb, k, mu);
         if (o->verbose)
             printf("it %3d f %.6e err %.2e (d %.2e p %.2e c %.2e) mu %.2e\n", it, kk.f, kk.err, kk.dual, kk.prim, kk.compl, mu);
         if (kk.err <= o->tol && kk.dual <= 1.0 && kk.prim <= 1e-4 && kk.compl <= 1e-4) { st = 0; break; }

@@ -419,7 +419,7 @@ def test_config0_plan_then_track_with_replanning_on_the_device_loop(golden_dir):
     loop.set_record([0])
     log = loop.run(10)
     from boundplanner_amd import mpc_data
-    recs = loop.records(max_steps=10)
+    recs = loop.records()
     assert recs.shape[:2] == (10, 1)
     for k in range(10):                          # the trace of the run: one MPCData record per step, consistent with the log
         md = mpc_data.from_device_record(recs[k, 0], N)

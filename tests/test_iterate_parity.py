@@ -3,13 +3,19 @@
 The replaced call is `self.solver(x0, lbx, ubx, lbg, ubg, p)` (/root/reference/bound_planner/BoundMPC/BoundMPC.py:594-617).  The HIP
 kernels and oracle/bmpc_solve.c run the same interior-point iteration in FP64 with different summation orders, libm and reciprocal
 sequences.  With max_iter = k both return the iterate after k accepted steps and the decisions of the last iteration
-(tests/iterate_parity_lib.py).  Asserted, per workload:
-  * after ONE iteration every instance is in step and the iterates agree to 1e-9 (relative, per block): the arithmetic of one
-    iteration -- evaluation, assembly, Riccati factorisation, row steps, line search -- is the same computation on both sides;
-  * while an instance is in step (same branch decisions so far) the distance may grow only by the conditioning of the Newton
-    systems: the bound per k is stated below and the measured table is written to gpurun_out/ (committed under profiles/);
-  * an instance leaves only through a recorded decision (a line-search trial accepted on one side and rejected on the other, a barrier
-    decrease one iteration apart, an inertia decision), never through "iterations" alone in the first iterations.
+(tests/iterate_parity_lib.py: HIP bmpc_debug_inst_state, oracle bmpc_oracle_solve_batch_info).  Asserted, per workload:
+  * after ONE iteration every instance is in step and the iterates agree to 1e-12 (relative, per block), after four to 1e-9: the
+    arithmetic of an iteration -- evaluation, assembly, Riccati factorisation, row steps, line search -- is the same computation;
+  * nearly every instance takes the same discrete decisions on both sides for all twelve iterations;
+  * while an instance is in step, the distance between the two sides' iterates is rounding noise carried by the iteration itself:
+    its quantiles stay within a factor of the oracle's SELF-sensitivity -- the oracle against itself from a start vector perturbed
+    by 1e-14 -- measured in the same test on the same instances.  (Some iterations amplify noise by 1e3 .. 1e5: a Newton system
+    whose exact Hessian is positive definite by a hair; the yardstick shows the same jumps.)
+The table goes to gpurun_out/r04_iterate_parity_<workload>.json (committed under profiles/).
+
+Round 4: this test found that the oracle weighted the second-order term of the pi dynamics with the adjoint multipliers of the
+PREVIOUS iterate (the HIP kernels use those of the current backward sweep): from the second exact-Hessian iteration on the two sides'
+steps differed by 1e-3 relative although every branch agreed -- the unexplained 7e-4 rad at equal iteration counts of round 3.
 """
 import json
 import os
@@ -23,47 +29,36 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KS = list(range(1, 13))
-
-
-def _factory():
-    from boundplanner_amd.solver import HipBoundMPC
-    cache = {}
-
-    def get(N, k):
-        if (N, k) not in cache:
-            cache[(N, k)] = HipBoundMPC(N, max_iter=k)
-        return cache[(N, k)]
-    return get
-
-
 # (workload, N, instances, seed, randomized sets): BASELINE configs[2] (first 1024), configs[1] (all), the configs[4] generator (256)
 CASES = [("config2_first1024", 20, 1024, 8192, True), ("config1_all", 10, 1024, 1024, False), ("config4_gen_256", 30, 256, 4096, False)]
+FACTOR = 30.0       # HIP-vs-oracle quantile <= FACTOR x oracle-vs-perturbed-oracle quantile (+ FLOOR)
+FLOOR = 1e-12
 
 
 @pytest.mark.parametrize("name,N,B,seed,rnd", CASES)
 def test_iterates_agree_while_the_branches_agree(name, N, B, seed, rnd):
     from boundplanner_amd import scenes
-    get = _factory()
-    be = get(N, 1)
-    full = scenes.make_batch(8192 if name.startswith("config2") else B, N, seed, be.fk, randomize_sets=rnd)
+    from boundplanner_amd.solver import HipBoundMPC
+    bes = {}
+    get = lambda k: bes.setdefault(k, HipBoundMPC(N, max_iter=k))
+    full = scenes.make_batch(8192 if name.startswith("config2") else B, N, seed, get(1).fk, randomize_sets=rnd)
     batch = {k: v[:B] for k, v in full.items() if hasattr(v, "shape") and v.shape[:1] == full["x0"].shape[:1]}
-    rows, left_at, reason = IP.table(N, batch, lambda k: get(N, k), O, KS)
-    out = {"workload": name, "N": N, "instances": B, "rows": rows,
+    rows, left_at, reason = IP.table(N, batch, get, O, KS)
+    yard = IP.self_sensitivity(N, batch, O, KS)
+    out = {"workload": name, "N": N, "instances": B, "rows": rows, "oracle_self_sensitivity_eps1e-14": yard,
            "left": {str(k): {r: int(((left_at == k) & (reason == r)).sum()) for r in sorted(set(reason[left_at == k]))} for k in KS if (left_at == k).any()},
            "never_left": int((left_at == 0).sum())}
     print(json.dumps(out))
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
         json.dump(out, open(os.path.join(d, f"r04_iterate_parity_{name}.json"), "w"), indent=1)
-    r1 = rows[0]
-    assert r1["in_step"] == B and r1["max_rel_dx_in_step"] <= 1e-9, r1
-    for r in rows:
-        if r["in_step"]:
-            assert r["max_rel_dx_in_step"] <= BOUND(r["k"]), r
-    # the two sides stay together: most instances take the same decisions for all twelve iterations
-    assert rows[-1]["in_step"] + (np.array([r["running_both"] for r in rows])[-1] == 0) >= 0.8 * rows[-1]["running_both"], rows[-1]
-
-
-def BOUND(k):
-    """Relative distance allowed between in-step iterates after k iterations (see DESIGN.md section 5 for the measured table)."""
-    return 1e-9 if k <= 3 else 1e-6
+    assert rows[0]["in_step"] == B and rows[0]["max_rel_dx_in_step"] <= 1e-12, rows[0]
+    for r in rows[:4]:
+        assert r["in_step"] == r["running_both"] and r["max_rel_dx_in_step"] <= 1e-9, r
+    for r, y in zip(rows, yard):
+        if not r["in_step"] or "median" not in y:
+            continue
+        assert r["in_step"] >= 0.97 * r["running_both"], r                       # the same decisions on both sides
+        for q_hip, q_self in (("median_rel_dx_in_step", "median"), ("p90_rel_dx_in_step", "p90"), ("p99_rel_dx_in_step", "p99")):
+            assert r[q_hip] <= FACTOR * y[q_self] + FLOOR, (r["k"], q_hip, r[q_hip], y[q_self])
+        assert r["median_rel_dx_in_step"] <= 1e-10, r

@@ -143,6 +143,9 @@ def run(args, progress=True):
         "iters_first_step_mean": float(it[0].mean()), "fail_frac": float(np.concatenate(fails).mean()), "dead_frac": dead,
         "reached_end_frac": float((reached_at > 0).mean()),
         "steps_to_end_median": float(np.median(reached_at[reached_at > 0])) if (reached_at > 0).any() else None,
+        # what bounds the schedules: lock step pays the slowest solve of every step, no lock step the slowest rollout's own chain
+        "iters_sum_of_per_step_max": int(it.max(axis=1).sum()), "iters_per_rollout_total_max": int(it.sum(axis=0).max()),
+        "iters_per_rollout_total_mean": float(it.sum(axis=0).mean()),
     }
     if args.dump_failing and G == 1:
         sol = loop.solution()

@@ -18,7 +18,10 @@ if "--traffic-json" in sys.argv:
     import json
     fetch = sum(v for (k, c), v in acc.items() if c == "FETCH_SIZE") * 1024
     write = sum(v for (k, c), v in acc.items() if c == "WRITE_SIZE") * 1024
-    json.dump({"fetch_bytes_raw": fetch, "write_bytes": write, "unit": "bytes per batch (B=8192, N=20)",
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    json.dump({"fetch_bytes_raw": fetch, "write_bytes": write, "unit": "bytes per batch (B=8192, N=20)", "kernel_src_sha16": bench.kernel_src_sha(),
                "per_kernel_GB": {k: {"fetch_raw": acc.get((k, "FETCH_SIZE"), 0) * 1024 / 1e9, "write": acc.get((k, "WRITE_SIZE"), 0) * 1024 / 1e9}
                                  for k in sorted({k for k, _ in acc})}},
               open(sys.argv[sys.argv.index("--traffic-json") + 1], "w"), indent=1)
