@@ -635,6 +635,73 @@ BMPC_INL bool ric_phase_factor_impl(RicArgs AH, LDSD* lds, int b, int lane, int 
     return ok;
 }
 
+// One stage of the backward sweep reduced to the ADJOINT recursion: Lagrangian gradient gz_k in zeta coordinates, + Phi^T lam_{k+1},
+// dual-residual / |lambda| accumulators, lam_k.  Runs for the stages below the first control block that was not positive definite in
+// the FIRST sweep of an iteration: that sweep has to go on (the KKT error of the iterate needs the whole adjoint recursion), but
+// nothing of its factorisation is used any more -- the retry sweep (Gauss-Newton fallback or delta_w) redoes it.  Same expressions
+// on gz as ric_phase_load / _couple / _factor, so the KKT error does not depend on where the sweep failed.
+template <int NT>
+BMPC_INL void ric_stage_adjoint_impl(RicArgs AH, LDSD* lds, int b, int lane, int k, const int* tpk) {
+    RicArgsRef A = ric_args(AH);
+    const int N = A.N;
+    const DynC dc = make_dync(A.o.dt);
+    constexpr int NF = HREC / NT;
+    const int junk = R_misc + (lane & 31);
+    const bool term = (k == N - 1);
+    GCD hrec_k = (GCD)(A.hrec + hrec_of(A, b, k));
+    double rv[NF];
+    BMPC_UNROLL
+    for (int i = 0; i < NF; i++) rv[i] = (NT * (i + 1) <= F_CQP) ? hrec_k[lane + NT * i] : 0.0;
+    BMPC_SYNC();                                       // the previous stage has read gz / ew / dz2
+    BMPC_UNROLL
+    for (int i = 0; i < NF; i++) {                     // the store pass of the scatter (gz, ew, dz2 among it; W entries are not used)
+        const int ps = tpk[i] >> 26, o1 = tpk[i] & 8191, o2 = (tpk[i] >> 13) & 8191;
+        lds[ps == 1 ? o1 : junk] = rv[i]; lds[ps == 1 ? o2 : junk] = rv[i];
+    }
+    if (k > 1 && lane < F_CQP / 16) BMPC_TOUCH_LINE((GCD)(A.hrec + hrec_of(A, b, k - 1)) + 16 * lane, RL(R_misc));
+    BMPC_SYNC();
+    // natural -> zeta coordinates of gz: the nine (u_j, drs, dps) entries of the row pass of ric_phase_load
+    {
+        const int t = lane < 9 ? lane : 0;
+        const bool isj = t < 7;
+        const int sp = isj ? Z_Q + t : (t == 7 ? Z_RS : Z_PS), dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
+        const int o_d = lane < 9 ? R_gz + dp : junk, o_s = lane < 9 ? R_gz + sp : junk;
+        const double d0 = lds[o_d], s0 = lds[o_s], s1 = lds[isj && lane < 9 ? o_s + 7 : o_s], s2 = lds[isj && lane < 9 ? o_s + 14 : o_s];
+        lds[o_d] = d0 + (isj ? dc.c3 : 0.5 * dc.dt) * s0 + (isj ? dc.c2 : 0.0) * s1 + (isj ? dc.c1 : 0.0) * s2;
+    }
+    BMPC_SYNC();
+    if (k == 1 && lane < 2) { const int pos = lane ? Z_PS : Z_RS; RL(R_gz)[pos] -= RL(R_dz2)[6 + lane]; }
+    BMPC_SYNC();                                       // (the line above touches the RS / PS entries that lanes 24 / 25 update next)
+    if (!term && lane < NZ) {                          // gz += Phi^T lam_{k+1} (the vector part of the coupling phase)
+        const int c = lane;
+        double ea[3];
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) {
+            double v = 0;
+            if (c < Z_DQ) v = dc.dt * RL(R_ew)[7 * a + c];
+            else if (c < Z_DDQ) v = dc.dt * RL(R_ew)[21 + 7 * a + c - 7];
+            else if (c >= Z_U && c < Z_DRS) v = dc.dt * (dc.c3 * RL(R_ew)[7 * a + c - Z_U] + dc.c2 * RL(R_ew)[21 + 7 * a + c - Z_U]);
+            ea[a] = v;
+        }
+        PhiCol pc = phi_col(c, dc);
+        double l3[3], lp[3];
+        l3[0] = RL(R_lam)[pc.i0]; l3[1] = RL(R_lam)[pc.i1]; l3[2] = RL(R_lam)[pc.i2];
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) lp[a] = RL(R_lam)[Z_PI + a];
+        double gl = pc.c0 * l3[0] + pc.c1 * l3[1] + pc.c2 * l3[2];
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) gl += ea[a] * lp[a];
+        RL(R_gz)[c] += gl;
+    }
+    BMPC_SYNC();
+    if (lane < NZ) {                                   // adjoint multipliers + dual residual, as ric_phase_factor
+        double gl = RL(R_gz)[lane];
+        if (lane >= NX || (k == 1 && lane >= 24)) RL(R_acc)[48 + lane] = fmax(RL(R_acc)[48 + lane], fabs(gl));
+        if (lane < NX) { RL(R_lam)[lane] = gl; RL(R_acc)[lane] += fabs(gl); }
+    }
+}
+template <int NT> BMPC_NOINL void ric_stage_adjoint(RicArgs AH, LDSD* lds, int b, int lane, int k, const int* tpk) { ric_stage_adjoint_impl<NT>(AH, lds, b, lane, k, tpk); }
+
 template <int NT> BMPC_NOINL void ric_phase_load(RicArgs AH, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
     ric_phase_load_impl<NT>(AH, lds, b, lane, k, hess_mode, tpk);
 }
@@ -705,6 +772,16 @@ BMPC_NOINL bool ric_backward(RicArgs AH, LDSD* lds, int b, int lane, int hess_mo
         // a retry pass (the KKT quantities of the iterate are known from the first one) stops at the first control block that
         // is not positive definite; the verdict is uniform (read from LDS behind a barrier)
         if (may_abort && !ok) break;
+        // the first pass goes on for the KKT error of the iterate, but only with the adjoint recursion: the factorisation below a
+        // failed block is not used (round 4: a failed first sweep cost 19 full stages; the stragglers fail at every iteration)
+        if (!ok) {
+            for (int k2 = k - 1; k2 >= 1; k2--) {
+                int l3 = lane;
+                BMPC_OPAQUE_I(l3);
+                ric_stage_adjoint_impl<NT>(AH, lds, b, l3, k2, tpk);
+            }
+            break;
+        }
     }
     // |lambda| sum (lanes < 32 contribute) and dual-residual maximum (lanes < 41), in lane order
     BMPC_SYNC();
