@@ -8,9 +8,15 @@
 // the Riccati kernel reads its argument block from the kernel-argument segment (bmpc_ric_kernel.hpp, RicArgs)
 #define BMPC_KERNARG_ARGS 1
 #define BMPC_INL __device__ __forceinline__
-// kernel bodies: always inlined into their __global__ wrapper (as a separate function the body loses the wrapper's launch
-// bounds, and two such bodies -- k_init with batched parameter staging, k_step with the row steps -- did not terminate on gfx950)
+// kernel bodies: always inlined into their __global__ wrapper.  As separate functions two of them (k_init, k_step) never returned on
+// gfx950: their early exit is a long branch, and LLVM's branch relaxation expands it through s[30:31] -- the return address of a leaf
+// function, which nothing has saved -- so a wavefront without work "returns" to the exit block for ever
+// (tools/repro_noinline_hang/README.md; -DBMPC_KBODY_CALL rebuilds that variant for the static check there)
+#ifdef BMPC_KBODY_CALL
+#define BMPC_KBODY __device__ __attribute__((noinline))
+#else
 #define BMPC_KBODY __device__ __forceinline__
+#endif
 #define BMPC_SYNC() __syncthreads()
 // optimisation barrier on a double in a vector register: the value after it is a new one for the register allocator
 // (used to end the live range of a spilled value and start a register-resident copy for a hot block)
