@@ -111,7 +111,8 @@ BMPC_DEV void kin_eval(const RobotConst* rc, const double* q, Kin& k) {
         for (int a = 0; a < 3; a++) t[a] += tmp[a];
         mat3mul(R, rc->jrot[i], Rn);
         for (int a = 0; a < 3; a++) { k.o[i][a] = t[a]; k.z[i][a] = Rn[3 * a + 2]; }
-        double c = cos(q[i]), s = sin(q[i]);
+        double c, s;
+        BMPC_SINCOS(q[i], s, c);
         double Rz[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
         mat3mul(Rn, Rz, R);
         if (i == 3) {

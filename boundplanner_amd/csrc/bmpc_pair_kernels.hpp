@@ -1184,14 +1184,13 @@ struct TrialVisitor {
                                                       // (mantissa renormalised every row: one log per pair instead of one per row)
     template <int S0, int CNT> BMPC_INL void group() {
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
+        // (z is loaded with t and c, one memory round trip per group, also by the later trials of a search, which do not use it)
+        double gz[CNT];
         BMPC_UNROLL
-        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gc[i] = A->dt[o]; }
+        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gc[i] = A->dt[o]; gz[i] = zc[o]; }
         if (dual) {
             // a slot is live iff z > 0 (inactive slots keep t = 1, z = 0 in both copies from k_init); done here, on the whole
             // group at once, so that no multiplier stays in a register while the group's rows are walked
-            double gz[CNT];
-            BMPC_UNROLL
-            for (int i = 0; i < CNT; i++) gz[i] = zc[(size_t)(S0 + i) * A->NP + pi];
             BMPC_UNROLL
             for (int i = 0; i < CNT; i++)
                 if (gz[i] > 0.0) zn_out[(size_t)(S0 + i) * A->NP + pi] = gz[i] + ad * ((mu - gz[i] * gc[i]) * BMPC_RCP(gt[i]));

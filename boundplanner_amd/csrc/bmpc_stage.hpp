@@ -41,7 +41,8 @@ BMPC_INL void kin_chain(GRC rc, const double* q, KinT& K) {
                 Rn[3 * a + b] = R[3 * a] * rc->jrot[i][b] + R[3 * a + 1] * rc->jrot[i][3 + b] + R[3 * a + 2] * rc->jrot[i][6 + b];
         BMPC_UNROLL
         for (int a = 0; a < 3; a++) { K.o[i][a] = t[a]; K.zx[i][a] = Rn[3 * a + 2]; }
-        double c = cos(q[i]), s = sin(q[i]);
+        double c, s;
+        BMPC_SINCOS(q[i], s, c);
         BMPC_UNROLL
         for (int a = 0; a < 3; a++) {
             R[3 * a] = Rn[3 * a] * c + Rn[3 * a + 1] * s;

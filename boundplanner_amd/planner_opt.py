@@ -236,6 +236,53 @@ def _sweep_row(a, p_prev, p, om_prev, om, l_ee, omega, omega_norm):
     return 0.5 * (lo + hi)
 
 
+def via_rot_reference_fg(nr_via, max_set_size, x, params):
+    """Objective and constraint vector of the reference's via-point / rotation NLP in ITS variables and ordering
+    (/root/reference/bound_planner/utils/optimization_functions.py:227-387): x = per via point [p (3), omega (1), phi_max (S)],
+    g = per via point [A_inter p - b (S); per row j of its via set: (d/dphi of the swept row at phi_max_j if that derivative changes
+    sign on [0, 1], else 0), (swept row at phi_max_j) - b_j; A_inter p_ee - b (S)], then the two mid points of the last segment
+    (2 S).  Pinned against the reference's own construction of the problem (tests/golden/via_rot.npz); via_rot_problem below solves
+    the same problem with the phi_max variables eliminated."""
+    S = max_set_size
+    params = np.asarray(params, float); x = np.asarray(x, float)
+    p_start, p_end, l_ee, omega = params[0:3], params[3:6], params[6:9], params[9:12]
+    omega_norm = params[12]
+    w = params[13:13 + nr_via + 1]
+    o = 13 + nr_via + 1
+    inter, via = [], []
+    for _ in range(nr_via):
+        inter.append((params[o:o + 3 * S].reshape(3, S).T, params[o + 3 * S:o + 4 * S])); o += 4 * S
+    for _ in range(nr_via + 1):
+        via.append((params[o:o + 3 * S].reshape(3, S).T, params[o + 3 * S:o + 4 * S])); o += 4 * S
+    step = 4 + S
+    k = np.cross(omega, l_ee); kk = np.cross(omega, k)
+    J, g, pp, op = 0.0, [], p_start, 0.0
+    for i in range(nr_via):
+        P, O, phis = x[step * i:step * i + 3], x[step * i + 3], x[step * i + 4:step * (i + 1)]
+        J += w[i] * ((P - pp) @ (P - pp) + (O - op) ** 2)
+        Ai, bi = inter[i]
+        g.append(Ai @ P - bi)
+        Av, bv = via[i]
+        v, dom = P - pp, omega_norm * (O - op)
+        rows = np.zeros(2 * S)
+        for j in range(S):
+            def dh(phi, a=Av[j]):
+                ang = omega_norm * (op + phi * (O - op))
+                return a @ v + dom * (np.cos(ang) * (a @ k) + np.sin(ang) * (a @ kk))
+            rows[2 * j] = dh(phis[j]) if dh(0.0) * dh(1.0) < 0 else 0.0
+            pm = pp + phis[j] * v + rodrigues(omega, omega_norm * (op + phis[j] * (O - op))) @ l_ee
+            rows[2 * j + 1] = Av[j] @ pm - bv[j]
+        g.append(rows)
+        g.append(Ai @ (P + rodrigues(omega, omega_norm * O) @ l_ee) - bi)
+        pp, op = P, O
+    J += w[-1] * ((p_end - pp) @ (p_end - pp) + (1 - op) ** 2)
+    Av, bv = via[-1]
+    for pos in (0.25, 0.5):
+        pm = pp + pos * (p_end - pp) + rodrigues(omega, omega_norm * (op + pos * (1 - op))) @ l_ee
+        g.append(Av @ pm - bv)
+    return J, np.concatenate(g)
+
+
 def via_rot_problem(nr_via, max_set_size, x0, params):
     """The reference's NLP with its phi_max variables eliminated (each sits at the stationary point of its row's sweep when
     there is one; otherwise its two constraints are vacuous).  x0, params and the returned x are in the reference's layouts

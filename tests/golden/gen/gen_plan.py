@@ -12,8 +12,9 @@ them available in this image -- are filled by the small exact solvers of boundpl
     IPOPT via-point / rotation NLP (via_point_rot_optimization_problem) -> via_rot_problem  [*]
 so the fixture pins the planner LOGIC of this repository (graph construction, set growth, via-point selection) against
 the reference's; the sub-problem solvers are validated against scipy in tests/test_planner.py.
-[*] that NLP is built with symbolic CasADi calls (ca.jacobian, ca.Function) the numeric shim cannot run, so its FORMULATION is
-restated in planner_opt.via_rot_problem from optimization_functions.py:227-387: unpinned at that boundary.
+[*] that NLP's FORMULATION is pinned separately (round 4): tests/golden/gen/gen_via_rot.py builds the reference's own problem under the
+numeric casadi stand-in (its ca.jacobian / ca.Function calls are served by re-evaluation) and tests/golden/via_rot.npz holds f and g at
+sample points, which planner_opt.via_rot_reference_fg reproduces; via_rot_problem solves that problem with phi_max eliminated.
 The fixture is data only; no reference source is copied.
 
     python tests/golden/gen/gen_plan.py

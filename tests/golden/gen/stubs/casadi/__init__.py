@@ -5,7 +5,11 @@ problem with this module evaluates it at the supplied point.  Semantics follow C
 where the reference relies on them: column-major ``X[:]``/``reshape``, single-index
 slicing of vectors keeps their orientation, 1x1 broadcasting, comparisons -> 0/1,
 ``if_else`` as a numeric select.  dtype may be switched to complex for complex-step
-derivatives.  This file is test tooling: it is never imported by the product.
+derivatives.  Round 4: the pure operations also record how their value was computed (`rec`), so that an expression can be
+RE-EVALUATED with some symbols bound to other values: that is what `ca.Function(name, inputs, outputs)(args)` and
+`ca.jacobian(expr, x)` (complex step on the re-evaluation; scalar by scalar only) need in the reference's via-point NLP
+(optimization_functions.py:227-387).  Matrices that are filled in place (`m[i, j] = ...`) stay leaves: their value at build time is
+used as is.  This file is test tooling: it is never imported by the product.
 """
 import os
 import sys
@@ -42,6 +46,39 @@ def _bc(a, b):
     raise ValueError(f"shape mismatch {a.shape} vs {b.shape}")
 
 
+def _node(fn, *parents):
+    """M with the value fn(parent arrays) that remembers fn and its parents (M objects or plain constants)"""
+    m = M(fn(*[q.a if isinstance(q, M) else q for q in parents]))
+    m.rec = (fn, parents)
+    return m
+
+
+def _eval(m, subs, memo):
+    """value of m (array) with the M objects in `subs` (by id) bound to other arrays"""
+    if not isinstance(m, M):
+        return m
+    if id(m) in subs:
+        return subs[id(m)]
+    if id(m) in memo:
+        return memo[id(m)]
+    rec = getattr(m, "rec", None)
+    if rec is None:
+        v = m.a
+    elif rec[0] == "jac":                  # d expr / d x by complex step at the CURRENT binding of x
+        _, expr, x = rec
+        x0 = np.asarray(_eval(x, subs, memo), dtype=complex)
+        s2 = dict(subs); s2[id(x)] = x0 + 1e-30j
+        v = np.imag(np.asarray(_eval(expr, s2, {}))) / 1e-30
+    else:
+        fn, parents = rec
+        v = fn(*[_eval(q, subs, memo) if isinstance(q, M) else q for q in parents])
+    v = np.asarray(v)
+    if v.ndim == 0:
+        v = v.reshape(1, 1)
+    memo[id(m)] = v
+    return v
+
+
 class M:
     __array_priority__ = 1000
 
@@ -60,7 +97,7 @@ class M:
 
     @property
     def T(self):
-        return M(self.a.T)
+        return _node(lambda a: a.T, self)
 
     def size1(self):
         return self.a.shape[0]
@@ -76,7 +113,7 @@ class M:
 
     def reshape(self, shp):
         r, c = shp
-        return M(self.a.reshape((r, c), order="F"))
+        return _node(lambda a: a.reshape((r, c), order="F"), self)
 
     def full(self):
         return np.real(self.a).copy() if DTYPE[0] is float else self.a.copy()
@@ -103,16 +140,17 @@ class M:
     def __getitem__(self, k):
         if isinstance(k, tuple):
             i, j = k
-            sub = self.a[self._ax(i, 0)][:, self._ax(j, 1)]
-            return M(sub)
+            ii, jj = self._ax(i, 0), self._ax(j, 1)
+            return _node(lambda a: a[ii][:, jj], self)
         # single index: column-major linear indexing
-        flat = self.a.reshape(-1, order="F")
-        sel = flat[k]
-        if np.ndim(sel) == 0:
-            return M(sel)
-        if self.a.shape[0] == 1 and self.a.shape[1] != 1:
-            return M(np.asarray(sel).reshape(1, -1))
-        return M(np.asarray(sel).reshape(-1, 1))
+        row = self.a.shape[0] == 1 and self.a.shape[1] != 1
+
+        def pick(a):
+            sel = a.reshape(-1, order="F")[k]
+            if np.ndim(sel) == 0:
+                return np.asarray(sel).reshape(1, 1)
+            return np.asarray(sel).reshape(1, -1) if row else np.asarray(sel).reshape(-1, 1)
+        return _node(pick, self)
 
     def _ax(self, i, axis):
         n = self.a.shape[axis]
@@ -150,8 +188,9 @@ class M:
 
     # -- arithmetic ------------------------------------------------------
     def _bin(self, o, f, rev=False):
-        a, b = _bc(self.a, _arr(o))
-        return M(f(b, a) if rev else f(a, b))
+        _bc(self.a, _arr(o))              # shape check
+        other = o if isinstance(o, M) else _arr(o)
+        return _node((lambda a, b: f(b, a)) if rev else (lambda a, b: f(a, b)), self, other)
 
     def __add__(self, o): return self._bin(o, np.add)
     def __radd__(self, o): return self._bin(o, np.add, True)
@@ -162,20 +201,14 @@ class M:
     def __truediv__(self, o): return self._bin(o, np.divide)
     def __rtruediv__(self, o): return self._bin(o, np.divide, True)
     def __pow__(self, o): return self._bin(o, np.power)
-    def __neg__(self): return M(-self.a)
+    def __neg__(self): return _node(lambda a: -a, self)
     def __pos__(self): return self
 
     def __matmul__(self, o):
-        a, b = self.a, _arr(o)
-        if a.size == 1 or b.size == 1:
-            return M(a * b)
-        return M(a @ b)
+        return _node(_mm, self, o if isinstance(o, M) else _arr(o))
 
     def __rmatmul__(self, o):
-        a, b = _arr(o), self.a
-        if a.size == 1 or b.size == 1:
-            return M(a * b)
-        return M(a @ b)
+        return _node(_mm, o if isinstance(o, M) else _arr(o), self)
 
     # comparisons act on real parts and give 0/1
     def _cmp(self, o, f):
@@ -236,36 +269,41 @@ class DM(M):
     pass
 
 
+def _mm(a, b):
+    return a * b if (a.size == 1 or b.size == 1) else a @ b
+
+
+def _lift(x):
+    return x if isinstance(x, M) else _arr(x)
+
+
 def vertcat(*args):
-    parts = [_arr(a) for a in args if _arr(a).size > 0]
-    return M(np.vstack(parts))
+    parts = [_lift(a) for a in args if _arr(a).size > 0]
+    return _node(lambda *p: np.vstack(p), *parts)
 
 
 def horzcat(*args):
-    parts = [_arr(a) for a in args if _arr(a).size > 0]
-    return M(np.hstack(parts))
+    parts = [_lift(a) for a in args if _arr(a).size > 0]
+    return _node(lambda *p: np.hstack(p), *parts)
 
 
 def sumsqr(x):
-    a = _arr(x)
-    return M(np.sum(a * a))          # NOT |a|^2: analytic for complex step
+    return _node(lambda a: np.sum(a * a), _lift(x))          # NOT |a|^2: analytic for complex step
 
 
 def dot(x, y):
-    a, b = _arr(x), _arr(y)
-    return M(np.sum(a.reshape(-1, order="F") * b.reshape(-1, order="F")))
+    return _node(lambda a, b: np.sum(a.reshape(-1, order="F") * b.reshape(-1, order="F")), _lift(x), _lift(y))
 
 
 def norm_2(x):
-    a = _arr(x)
-    return M(np.sqrt(np.sum(a * a)))
+    return _node(lambda a: np.sqrt(np.sum(a * a)), _lift(x))
 
 
 def _elem(fn, x):
     # like CasADi on plain numbers: numeric in, numeric out (the host-side numpy code of the reference
     # calls ca.sin / ca.cos on floats, optimization_functions.py:101-103)
     if isinstance(x, M):
-        return M(fn(_arr(x)))
+        return _node(fn, x)
     return fn(np.asarray(x, dtype=float)) if np.ndim(x) else float(fn(x))
 
 
@@ -280,8 +318,14 @@ def if_else(c, a, b):
     return a if cv else b
 
 
-def jacobian(*a, **k):
-    return None
+def jacobian(expr, x, *a, **k):
+    """d expr / d x for a scalar expression and a scalar symbol: complex step on the re-evaluated expression (see _eval)."""
+    if not (isinstance(expr, M) and isinstance(x, M) and expr.a.size == 1 and x.a.size == 1):
+        return None
+    m = M(np.zeros((1, 1)))
+    m.rec = ("jac", expr, x)
+    m.a = np.asarray(_eval(m, {}, {}), dtype=DTYPE[0] if DTYPE[0] is float else complex)
+    return m
 
 
 class _TapeWrap:
@@ -297,9 +341,16 @@ class Function:
 
     def __init__(self, *a, **k):
         self.args = a
+        # Function(name, [input symbols], [output expressions]): callable by re-evaluation
+        self.inputs = list(a[1]) if len(a) >= 3 and isinstance(a[1], (list, tuple)) else None
+        self.outputs = list(a[2]) if len(a) >= 3 and isinstance(a[2], (list, tuple)) else None
 
     def __call__(self, *a, **k):
-        raise RuntimeError("symbolic Function call is not supported by the numeric shim")
+        if self.inputs is None or len(a) != len(self.inputs) or not all(isinstance(i, M) for i in self.inputs):
+            raise RuntimeError("this Function call is not supported by the numeric shim")
+        subs = {id(sym): np.asarray(_arr(val)) for sym, val in zip(self.inputs, a)}
+        outs = [M(_eval(o, subs, {})) for o in self.outputs]
+        return outs[0] if len(outs) == 1 else outs
 
     @staticmethod
     def load(path):

@@ -131,3 +131,41 @@ def test_plan_feeds_the_tracker(plan):
     mpc.update([p.copy() for p in p_via], [r.copy() for r in r_via], [b.copy() for b in bp1], [np.array([0, 0, 1.0])] * n, [e.copy() for e in erb],
                [s[0] for s in sets], [s[1] for s in sets], [], np.zeros(6), p0=p0, params=prm)
     assert mpc.phi_max > 0.5
+
+
+def test_via_rot_formulation_matches_the_reference(golden_dir):
+    """The via-point / rotation NLP (optimization_functions.py:227-387): objective and every constraint row of the reference's own
+    problem construction at sample points (tests/golden/via_rot.npz, generated by tests/golden/gen/gen_via_rot.py from the
+    unmodified reference under the numeric casadi stand-in) equal planner_opt.via_rot_reference_fg; and the form via_rot_problem
+    solves -- phi_max eliminated -- is that problem: with phi_max at the stationary point of its row's sweep the reference's
+    stationarity rows vanish and its swept rows are the eliminated constraints."""
+    from boundplanner_amd import planner_opt as PO
+    d = np.load(os.path.join(golden_dir, "via_rot.npz"))
+    n_stat = n_stat_active = 0
+    for tag in ("a", "b", "c"):
+        nr_via, S = int(d[f"{tag}_nr_via"]), int(d[f"{tag}_S"])
+        assert d[f"{tag}_g"].shape[1] == 4 * S * nr_via + 2 * S == len(d[f"{tag}_lbg"])
+        for x, p, f, g in zip(d[f"{tag}_x"], d[f"{tag}_p"], d[f"{tag}_f"], d[f"{tag}_g"]):
+            f2, g2 = PO.via_rot_reference_fg(nr_via, S, x, p)
+            assert abs(f2 - f) <= 1e-12 * max(1.0, abs(f))
+            assert np.abs(g2 - g).max() <= 1e-9, (tag, np.abs(g2 - g).argmax())
+            for i in range(nr_via):
+                st = g[4 * S * i + S:4 * S * i + 3 * S:2]
+                n_stat += S; n_stat_active += int((st != 0).sum())
+            # eliminated form: put every phi_max at the stationary point (or leave it where the sweep is monotone)
+            step = 4 + S
+            xs = x.copy()
+            pp, op = p[0:3], 0.0
+            o = 13 + nr_via + 1 + 4 * S * nr_via
+            for i in range(nr_via):
+                Av = p[o + 4 * S * i:o + 4 * S * i + 3 * S].reshape(3, S).T
+                P, O = x[step * i:step * i + 3], x[step * i + 3]
+                for j in range(S):
+                    phi = PO._sweep_row(Av[j], pp, P, op, O, p[6:9], p[9:12], p[12])
+                    if phi is not None:
+                        xs[step * i + 4 + j] = phi
+                pp, op = P, O
+            _, gs = PO.via_rot_reference_fg(nr_via, S, xs, p)
+            for i in range(nr_via):
+                assert np.abs(gs[4 * S * i + S:4 * S * i + 3 * S:2]).max() <= 1e-9      # stationarity rows at the eliminated phi_max
+    assert 0 < n_stat_active < n_stat        # both cases occur in the fixture: interior stationary point / monotone sweep
