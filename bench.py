@@ -120,7 +120,7 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16, help="timed batches (default 16: four streaming calls of four batches)")
+    ap.add_argument("--steps", type=int, default=32, help="timed batches (default 32: four streaming calls of eight batches; the steps cycle through 16 distinct batches)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=HORIZON)

@@ -17,6 +17,15 @@ using namespace bmpc;
 #ifndef BMPC_EVAL_WPS
 #define BMPC_EVAL_WPS BMPC_PAIR_WPS
 #endif
+#ifndef BMPC_TRIAL_WPS
+#define BMPC_TRIAL_WPS BMPC_PAIR_WPS
+#endif
+#ifndef BMPC_STEP_WPS
+#define BMPC_STEP_WPS BMPC_PAIR_WPS
+#endif
+#ifndef BMPC_POINTS_WPS
+#define BMPC_POINTS_WPS BMPC_PAIR_WPS
+#endif
 #ifndef BMPC_RIC_WPS
 #define BMPC_RIC_WPS 1
 #endif
@@ -33,7 +42,7 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { 
 __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval(PipeArgsH H) {
     k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_points(PipeArgsH H) { k_points_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64, BMPC_POINTS_WPS) void bmpc_k_points(PipeArgsH H) { k_points_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
     __shared__ double lds[EM_DOUBLES + 8];
     k_curv_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
@@ -59,11 +68,11 @@ __global__ __launch_bounds__(64) void bmpc_k_fwd(PipeArgsH H) {
     __shared__ __attribute__((aligned(16))) double lds[FW_LDS_DOUBLES];
     k_fwd_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64, BMPC_STEP_WPS) void bmpc_k_step(PipeArgsH H) { k_step_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64) void bmpc_k_admit(PipeArgsH H) { k_admit_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ void bmpc_k_pool_reset(PipeArgsH H, int done_too) { if (threadIdx.x == 0 && blockIdx.x == 0) k_pool_reset_body(DV(H), done_too != 0); }
-__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64, BMPC_TRIAL_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_mult(PipeArgsH H) { k_mult_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
