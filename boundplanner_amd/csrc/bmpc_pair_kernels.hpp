@@ -500,11 +500,11 @@ BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][
 }
 // P17 blocks: for position I of the (q, dq, pi) block emit the three slack-column couplings, then
 // D, g0, g1, gz of that position (its diagonal rows are walked here), 7 fields
-template <int I, class RP, class BP>
+template <int I, int IEND, class RP, class BP>
 BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp, int k, const double* y, const KinT& K,
                            const double Jl[3][7], const double G[6][7], double hdt, RowAcc& R, const PointRes& PA,
                            const PoseAsm& P, const double* bv, Emitter& E) {
-    if constexpr (I < 17) {
+    if constexpr (I < IEND) {
         PGP wts = pg + P_W;
         double cO[6], cV[6];
         chain_cols<I>(K, Jl, G, hdt, cO, cV);
@@ -536,7 +536,7 @@ BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp
             D += w2; g0 += val; gz += val;
         }
         E.put(D); E.put(g0); E.put(g1); E.put(gz);
-        p17_emit_all<I + 1>(A, pg, rp, bp, k, y, K, Jl, G, hdt, R, PA, P, bv, E);
+        p17_emit_all<I + 1, IEND>(A, pg, rp, bp, k, y, K, Jl, G, hdt, R, PA, P, bv, E);
     }
 }
 
@@ -648,8 +648,14 @@ BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp,
     }
 }
 
-// lds: EM_DOUBLES doubles per wave
-BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
+// ------------------------------------------------------------------------------------------
+// k_pose (round 4): reference / error context, output-space cost gradient and Hessian, the pose rows (EE set, orientation bounds,
+// path-parameter cap, terminal rows) -> pose-space Hessian M6, slack couplings, gradients: 84 doubles per pair in the side array,
+// which k_eval chains through the kinematic columns.  Split off k_eval because the context (~150 doubles) and the kinematic columns
+// (111) together with the accumulators do not fit one wavefront's register file; neither kernel needs the other's big state.
+// lds: staged parameter vectors only.
+// ------------------------------------------------------------------------------------------
+BMPC_KBODY void k_pose_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
     const int count = A.L.cnt[0], N = A.N;
     if (wave * ipw_of(N) >= count) return;
     PairMap m = pair_map(A, A.L.eval, count, wave, lane);
@@ -657,15 +663,10 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
     GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
-    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
-    PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds + EM_DOUBLES + 8);
-    const double ad = A.st[m.b].ad;
+    PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds_par);
     double iw0[3];
     BMPC_UNROLL
     for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
-    Emitter E;
-    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid);
-    BMPC_SYNC();
     StagePoint S;
     const int flip = A.st[m.b].flip;
     GCD zc = cur_zeta(A, flip), tc = cur_t(A, flip), zcur = cur_z(A, flip);
@@ -675,8 +676,6 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     rp_pose.load(A, tc, zcur, m.pi);
     const double t_phi = tc[(size_t)S_PHI * A.NP + m.pi], z_phi = zcur[(size_t)S_PHI * A.NP + m.pi];
     stage_point(A, pg, iw0, k, dc, S);
-    double G[6][7];
-    kin_G(S.K, S.Jl, S.y + Z_DQ, G);
     double g12[12], Hp[21];
     cost_grad12(pg, S.C, term, g12);
     {
@@ -684,20 +683,12 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         cost_hess(pg, S.C, term, Hp, HvX);
     }
     RowAcc R;
-    R.init(&A, m.pi, m.valid, ad, tc, zcur);
-    // ---- collision-point results of k_points: q x d columns first, the rest where it is needed ----
-    PointRes PA;
-    PA.base = A.part + (size_t)PT_SIDE * A.NP + m.pi; PA.NP = A.NP;
-    R.cmax = PA.at(SD_KKT); R.csum = PA.at(SD_KKT + 1); R.cmin = PA.at(SD_KKT + 2); R.zsum = PA.at(SD_KKT + 3);
-    R.prim = PA.at(SD_KKT + 4); R.nrows = PA.at(SD_KKT + 5);
-    {
-        double cdv[35];
-        BMPC_UNROLL
-        for (int i = 0; i < 35; i++) cdv[i] = PA.at(SD_CD + i);
-        BMPC_UNROLL
-        for (int i = 0; i < 35; i++) E.put(cdv[i]);
+    R.init(&A, m.pi, m.valid, 0.0, tc, zcur);
+    {   // KKT partial sums so far (the collision-point rows, k_points)
+        GCD Sd = A.part + (size_t)PT_SIDE * A.NP + m.pi;
+        R.cmax = Sd[(size_t)(SD_KKT + 0) * A.NP]; R.csum = Sd[(size_t)(SD_KKT + 1) * A.NP]; R.cmin = Sd[(size_t)(SD_KKT + 2) * A.NP];
+        R.zsum = Sd[(size_t)(SD_KKT + 3) * A.NP]; R.prim = Sd[(size_t)(SD_KKT + 4) * A.NP]; R.nrows = Sd[(size_t)(SD_KKT + 5) * A.NP];
     }
-    // ---- pose rows -> chained (q, dq, pi) block ----
     PoseAsm PO;
     PO.R = &R;
     PO.init(Hp, g12);
@@ -707,9 +698,10 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         rp_term.load(A, tc, zcur, m.pi);
         walk_pose_rows_term(pg, N, k, S.y, S.C, PO, rp_term);
     }
+    if (!m.valid) return;
     const double hdt = 0.5 * dc.dt;
     // generalised forces for the second-order kinematic terms (k_curv)
-    if (m.valid && A.o.hess == 2) {
+    if (A.o.hess == 2) {
         GD F = A.part + (size_t)PT_FORCE * A.NP + m.pi;
         BMPC_UNROLL
         for (int a = 0; a < 3; a++) F[(size_t)a * A.NP] = PO.bpz[a];
@@ -729,18 +721,103 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             Sg[(size_t)(4 + bb) * A.NP] = c2 * ge;
         }
     }
+    GD Pz = A.part + (size_t)PT_POSE * A.NP + m.pi;
+    BMPC_UNROLL
+    for (int i = 0; i < 21; i++) Pz[(size_t)(PZ_M6 + i) * A.NP] = PO.M6[i];
+    BMPC_UNROLL
+    for (int sl = 0; sl < 3; sl++) {
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) Pz[(size_t)(PZ_MS + 6 * sl + i) * A.NP] = PO.mS[sl][i];
+        Pz[(size_t)(PZ_SS + sl) * A.NP] = PO.sS[sl];
+        Pz[(size_t)(PZ_BS0 + sl) * A.NP] = PO.bS0[sl]; Pz[(size_t)(PZ_BS1 + sl) * A.NP] = PO.bS1[sl]; Pz[(size_t)(PZ_BSZ + sl) * A.NP] = PO.bSz[sl];
+    }
+    BMPC_UNROLL
+    for (int i = 0; i < 6; i++) {
+        Pz[(size_t)(PZ_BP0 + i) * A.NP] = PO.bp0[i]; Pz[(size_t)(PZ_BP1 + i) * A.NP] = PO.bp1[i]; Pz[(size_t)(PZ_BPZ + i) * A.NP] = PO.bpz[i];
+        Pz[(size_t)(PZ_BV + i) * A.NP] = g12[6 + i];
+    }
+    Pz[(size_t)(PZ_KKT + 0) * A.NP] = R.cmax; Pz[(size_t)(PZ_KKT + 1) * A.NP] = R.csum; Pz[(size_t)(PZ_KKT + 2) * A.NP] = R.cmin;
+    Pz[(size_t)(PZ_KKT + 3) * A.NP] = R.zsum; Pz[(size_t)(PZ_KKT + 4) * A.NP] = R.prim; Pz[(size_t)(PZ_KKT + 5) * A.NP] = R.nrows;
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) Pz[(size_t)(PZ_VANG + a) * A.NP] = S.C.v[3 + a];
+}
+
+// lds: EM_DOUBLES doubles per wave
+BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
+    const int count = A.L.cnt[0], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    PairMap m = pair_map(A, A.L.eval, count, wave, lane);
+    const int k = m.k, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
+    const DynC dc = make_dync(A.o.dt);
+    GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
+    GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
+    PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds + EM_DOUBLES + 8);
+    const double ad = A.st[m.b].ad;
+    Emitter E;
+    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid);
+    BMPC_SYNC();
+    // kinematic columns at the iterate (the reference / error context and the pose rows are k_pose's: their results come from the side array)
+    struct { double zeta[NZ], y[NZ]; KinT K; double Jl[3][7]; } S;
+    const int flip = A.st[m.b].flip;
+    GCD zc = cur_zeta(A, flip), tc = cur_t(A, flip), zcur = cur_z(A, flip);
+    load_zeta(zc, A.NP, m.pi, S.zeta);
+    nat_all(S.zeta, dc, S.y);
+    kin_chain(A.rc, S.y + Z_Q, S.K);
+    kin_jlin(S.K, S.Jl);
+    double G[6][7];
+    kin_G(S.K, S.Jl, S.y + Z_DQ, G);
+    RowAcc R;
+    R.init(&A, m.pi, m.valid, ad, tc, zcur);
+    // ---- results of k_pose (pose-space Hessian, slack couplings, gradients): loaded phase by phase, right before their use ----
+    PoseAsm PO;
+    PO.R = &R;
+    GCD Pz = A.part + (size_t)PT_POSE * A.NP + m.pi;
+    R.cmax = Pz[(size_t)(PZ_KKT + 0) * A.NP]; R.csum = Pz[(size_t)(PZ_KKT + 1) * A.NP]; R.cmin = Pz[(size_t)(PZ_KKT + 2) * A.NP];
+    R.zsum = Pz[(size_t)(PZ_KKT + 3) * A.NP]; R.prim = Pz[(size_t)(PZ_KKT + 4) * A.NP]; R.nrows = Pz[(size_t)(PZ_KKT + 5) * A.NP];
+    // ---- collision-point results of k_points: q x d columns first, the rest where it is needed ----
+    PointRes PA;
+    PA.base = A.part + (size_t)PT_SIDE * A.NP + m.pi; PA.NP = A.NP;
+    {
+        double cdv[35];
+        BMPC_UNROLL
+        for (int i = 0; i < 35; i++) cdv[i] = PA.at(SD_CD + i);
+        BMPC_UNROLL
+        for (int i = 0; i < 35; i++) E.put(cdv[i]);
+    }
+    const double hdt = 0.5 * dc.dt;
     // ---- slack-column couplings + gradients + diagonal rows of the 17 chained positions ----
     {
-        RowPre<0, 28> rp_a;                  // rows + bounds of the q, dq box
-        BndPre<0, 14> bp_a;
-        rp_a.load(A, tc, zcur, m.pi); bp_a.load(lbx, ubx, N, k);
+        double bvv[6];
+        BMPC_UNROLL
+        for (int sl = 0; sl < 3; sl++)
+            BMPC_UNROLL
+            for (int i = 0; i < 6; i++) PO.mS[sl][i] = Pz[(size_t)(PZ_MS + 6 * sl + i) * A.NP];
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) {
+            PO.bp0[i] = Pz[(size_t)(PZ_BP0 + i) * A.NP]; PO.bp1[i] = Pz[(size_t)(PZ_BP1 + i) * A.NP]; PO.bpz[i] = Pz[(size_t)(PZ_BPZ + i) * A.NP];
+            bvv[i] = Pz[(size_t)(PZ_BV + i) * A.NP];
+        }
         PA.load_p17();
-        p17_emit_all<0>(A, pg, rp_a, bp_a, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, g12 + 6, E);
+        {
+            RowPre<0, 14> rp_a;              // rows + bounds of the q box
+            BndPre<0, 7> bp_a;
+            rp_a.load(A, tc, zcur, m.pi); bp_a.load(lbx, ubx, N, k);
+            p17_emit_all<0, 7>(A, pg, rp_a, bp_a, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, bvv, E);
+        }
+        {
+            RowPre<14, 14> rp_a;             // ... of the dq box (the pi positions have no rows)
+            BndPre<7, 7> bp_a;
+            rp_a.load(A, tc, zcur, m.pi); bp_a.load(lbx, ubx, N, k);
+            p17_emit_all<7, 17>(A, pg, rp_a, bp_a, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, bvv, E);
+        }
     }
     // ---- chained (q, dq, pi) block ----
     {
-        double HpX[21], Hv[21];
-        cost_hess(pg, S.C, term, HpX, Hv);
+        double Hv[21];
+        cost_hess_v(pg, N, k, Hv);
+        BMPC_UNROLL
+        for (int i = 0; i < 21; i++) PO.M6[i] = Pz[(size_t)(PZ_M6 + i) * A.NP];
         PA.load_hqq();
         // register-resident copies of the kinematic columns for this block (they are read ~20 times each here; the originals
         // were parked in scratch while the pose / diagonal rows needed the registers)
@@ -759,7 +836,6 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     // The iterate is read again (and its natural form recomputed) for the rest of the kernel instead of being carried
     // through the chained block: there the register file is needed for the kinematic columns (K, Jl, G), which the register
     // allocator otherwise parks in scratch memory and reloads for every entry of the block
-    const double vang[3] = {S.C.v[3], S.C.v[4], S.C.v[5]};
     double zeta2[NZ], y2[NZ];
     load_zeta(zc, A.NP, m.pi, zeta2);
     nat_all(zeta2, dc, y2);
@@ -767,6 +843,11 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     RowPre<28, 40> rp_b;                     // rows + bounds of the ddq, u box, the slack rows, the zeta-diagonal rows
     BndPre<14, 14> bp_b;
     rp_b.load(A, tc, zcur, m.pi); bp_b.load(lbx, ubx, N, k);
+    BMPC_UNROLL
+    for (int sl = 0; sl < 3; sl++) {
+        PO.sS[sl] = Pz[(size_t)(PZ_SS + sl) * A.NP];
+        PO.bS0[sl] = Pz[(size_t)(PZ_BS0 + sl) * A.NP]; PO.bS1[sl] = Pz[(size_t)(PZ_BS1 + sl) * A.NP]; PO.bSz[sl] = Pz[(size_t)(PZ_BSZ + sl) * A.NP];
+    }
     PA.load_dg();
     dg_emit_all<14>(A, pg, rp_b, bp_b, k, term, y2, R, PA, PO, E);
     // ---- zeta-diagonal rows (k == 1) ----
@@ -812,6 +893,9 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             double zn[NX];
             BMPC_UNROLL
             for (int i = 0; i < NX; i++) zn[i] = zc[(size_t)i * A.NP + m.pi + 1];
+            double vang[3];
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) vang[a] = Pz[(size_t)(PZ_VANG + a) * A.NP];
             defect_all(zeta2, zn, vang, dc, rdef);
             BMPC_UNROLL
             for (int i = 0; i < NX; i++) prim = fmax(prim, fabs(rdef[i]));

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(64) void bmpc_k_init_inst(PipeArgsH H) { k_init_ins
 // dynamic LDS of the thread-per-pair kernels: [emitter tile (k_eval, k_curv)] [staged parameter vectors]
 extern __shared__ __attribute__((aligned(16))) double bmpc_dyn_lds[];
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { k_init_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_pose(PipeArgsH H) { k_pose_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval(PipeArgsH H) {
     k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
@@ -120,6 +121,7 @@ extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_ma
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int* was_lat) {
     const int nw = waves_for(A->N, n_act);
     LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
+    LAUNCH_DYN(bmpc_k_pose, nw, 64, pair_lds_doubles(A->N, false));
     LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
     LAUNCH(bmpc_k_curv, nw, 64);
     // BMPC_RIC_LAT_BELOW in the environment (read once): A/B runs and the test that the two variants agree bitwise

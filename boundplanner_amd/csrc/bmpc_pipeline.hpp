@@ -57,13 +57,16 @@ constexpr int dg_pos_c(int i) {
 BMPC_HD int pos17(int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); }
 
 constexpr int KREC = 320;               // gains per pair: K (9x32) + kf (2x16)
-constexpr int NPART = 184;              // per-pair partial sums (16) + forces for k_curv (27) + point-group results (121) + PT_SIG (10)
+constexpr int NPART = 272;              // per-pair partial sums (16) + forces for k_curv (27) + point-group results (121) + PT_SIG (10) + pose-row results (88)
 constexpr int PT_FORCE = 16;            // Fp[3], Fv[6], Fc[6][3]
 constexpr int PT_SIG = 169;             // k_eval -> k_curv: c1 = 2 sig sig'' |e|^2, dpp[3], 2 sig sig' De^T e [6] (exact curvature of sig^2 |e|^2)
 // results of the collision-point rows (k_points), read by k_eval where it needs them
 constexpr int PT_SIDE = 48, SD_CD = 0 /*[5][7]*/, SD_CD5 = 35 /*7*/, SD_HQQ = 42 /*28*/, SD_GQ = 70 /*[3][7]*/,
               SD_DD = 91 /*6*/, SD_GD = 97 /*[3][6]*/, SD_KKT = 115 /*cmax csum cmin zsum prim nrows*/, SD_END = 121;
-static_assert(PT_SIDE + SD_END <= PT_SIG && PT_SIG + 10 <= NPART, "partials layout");
+// results of the pose rows and of the output-space cost (k_pose), read by k_eval: pose-space Hessian / slack couplings / gradients
+constexpr int PT_POSE = 184, PZ_M6 = 0 /*21*/, PZ_MS = 21 /*[3][6]*/, PZ_SS = 39 /*3*/, PZ_BP0 = 42 /*6*/, PZ_BP1 = 48, PZ_BPZ = 54,
+              PZ_BS0 = 60 /*3*/, PZ_BS1 = 63, PZ_BSZ = 66, PZ_BV = 69 /*6: d f / d v*/, PZ_KKT = 75 /*6, as SD_KKT*/, PZ_VANG = 81 /*3*/, PZ_END = 84;
+static_assert(PT_SIDE + SD_END <= PT_SIG && PT_SIG + 10 <= PT_POSE && PT_POSE + PZ_END <= NPART, "partials layout");
 enum { PT_CMAX = 0, PT_CSUM, PT_CMIN, PT_ZSUM, PT_PRIM, PT_THETA, PT_LOGS, PT_NROWS, PT_FVAL,
        PT_AP, PT_AD, PT_DBAR, PT_DPHIF, PT_F1, PT_TH1, PT_LS1 };
 

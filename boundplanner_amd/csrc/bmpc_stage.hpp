@@ -359,6 +359,34 @@ BMPC_INL void cost_hess(PGP pg, const SegCtx& C, bool term, double* Hp /*21*/, d
         }
 }
 
+// the v x v block alone: it depends on the parameters (segment of the stage, weights) only -- k_eval recomputes it instead of
+// carrying the whole context (same expressions as in cost_hess)
+BMPC_INL void cost_hess_v(PGP pg, int N, int k, double* Hv /*21*/) {
+    PGP wts = pg + P_W;
+    const bool term = (k == N - 1);
+    int s = 0;
+    if ((double)k > pg[P_SPLIT + 1]) s = 1;
+    if ((double)k > pg[P_SPLIT + 2]) s = 2;
+    const double w_vp = wts[2], w_vr = wts[3];
+    double dpp[3];
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++) dpp[a] = PTAB(P_DPREF, s, a);
+    double dWd = 0;
+    BMPC_UNROLL
+    for (int a = 0; a < 6; a++) { double da = PTAB(P_DPREF, s, a); dWd += da * da * (a < 3 ? w_vp : w_vr); }
+    BMPC_UNROLL
+    for (int i = 0; i < 6; i++)
+        BMPC_UNROLL
+        for (int j = i; j < 6; j++) {
+            double wi = (i < 3 ? w_vp : w_vr), wj = (j < 3 ? w_vp : w_vr);
+            double di = (i < 3) ? dpp[i < 3 ? i : 0] : 0.0, dj = (j < 3) ? dpp[j < 3 ? j : 0] : 0.0;
+            double hv = (i == j ? wi : 0.0) - wi * PTAB(P_DPREF, s, i) * dj - di * wj * PTAB(P_DPREF, s, j) + di * dj * dWd;
+            hv = 2 * hv + 2 * wts[5] * di * dj;
+            if (term && i == j) hv += 200.0;
+            Hv[sym6(i, j)] = hv;
+        }
+}
+
 // ------------------------------------------------------------------------------------------
 // inequality rows.  Visitor interface: the row walker calls, for every ACTIVE slot s,
 //   v.diag(s, pos, coef, h)            natural-diagonal row   h = coef*y[pos] + const

@@ -122,6 +122,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         if (cnt[7] >= B) break;
         if (verbose) printf("step %d: n_eval %d n_trial %d finished %d retired %d next row %d\n", steps, cnt[0], cnt[2], cnt[5], cnt[7], cnt[6]);
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_points_body(A, blk, l, lds.data()); });
+        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_pose_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[10]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
         launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);

@@ -39,7 +39,7 @@ def parse(path):
             solves.append(cur); cur = []
         cur.append((name, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
     solves.append(cur)
-    names = ["bmpc_k_points", "bmpc_k_eval", "bmpc_k_curv", "bmpc_k_ric", "bmpc_k_ric_lat", "bmpc_k_fwd", "bmpc_k_step",
+    names = ["bmpc_k_points", "bmpc_k_pose", "bmpc_k_eval", "bmpc_k_curv", "bmpc_k_ric", "bmpc_k_ric_lat", "bmpc_k_fwd", "bmpc_k_step",
              "bmpc_k_trial", "bmpc_k_accept"]      # (k_accept: builds before round 4)
     print("B      " + " ".join(f"{n[7:]:>9s}" for n in names) + "   (us, first super-step of the solve; k_eval workgroups)")
     for B, sv in zip(SIZES, solves):
