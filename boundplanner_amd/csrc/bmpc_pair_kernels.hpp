@@ -805,7 +805,7 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
             rp_a.load(A, tc, zcur, m.pi); bp_a.load(lbx, ubx, N, k);
             p17_emit_all<0, 7>(A, pg, rp_a, bp_a, k, S.y, S.K, S.Jl, G, hdt, R, PA, PO, bvv, E);
         }
-        {
+            {
             RowPre<14, 14> rp_a;             // ... of the dq box (the pi positions have no rows)
             BndPre<7, 7> bp_a;
             rp_a.load(A, tc, zcur, m.pi); bp_a.load(lbx, ubx, N, k);
@@ -832,6 +832,28 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         BMPC_UNROLL
         for (int i = 0; i < 21; i++) BMPC_PIN(PO.M6[i]);
         chain_all<0>(S.K, S.Jl, G, hdt, PO.M6, Hv, PA, E);
+    }
+    // ---- dynamics linearisation data (angular Jacobian, joint axes, suffix sums of the angular velocity): emitted here, while the
+    // kinematic columns are still in registers; nothing below needs them ----
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++)
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) E.put(G[3 + a][j]);
+    BMPC_UNROLL
+    for (int a = 0; a < 3; a++)
+        BMPC_UNROLL
+        for (int j = 0; j < 7; j++) E.put(S.K.zx[j][a]);
+    {
+        double sz[3] = {0, 0, 0}, sufz[7][3];
+        BMPC_UNROLL
+        for (int j = 6; j >= 0; j--)
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) { sz[a] += S.K.zx[j][a] * S.y[Z_DQ + j]; sufz[j][a] = sz[a]; }
+        // sufz[m] for m = 1..7 (sufz[7] = 0)
+        BMPC_UNROLL
+        for (int mm = 1; mm < 8; mm++)
+            BMPC_UNROLL
+            for (int a = 0; a < 3; a++) E.put(mm < 7 ? sufz[mm < 7 ? mm : 0][a] : 0.0);
     }
     // The iterate is read again (and its natural form recomputed) for the rest of the kernel instead of being carried
     // through the chained block: there the register file is needed for the kinematic columns (K, Jl, G), which the register
@@ -864,27 +886,6 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         E.put(sg2[0]); E.put(sg2[1]);
         BMPC_UNROLL
         for (int v = 0; v < 3; v++) { E.put(r2[v][0]); E.put(r2[v][1]); }
-    }
-    // ---- dynamics linearisation data, defect ----
-    BMPC_UNROLL
-    for (int a = 0; a < 3; a++)
-        BMPC_UNROLL
-        for (int j = 0; j < 7; j++) E.put(G[3 + a][j]);
-    BMPC_UNROLL
-    for (int a = 0; a < 3; a++)
-        BMPC_UNROLL
-        for (int j = 0; j < 7; j++) E.put(S.K.zx[j][a]);
-    {
-        double sz[3] = {0, 0, 0}, sufz[7][3];
-        BMPC_UNROLL
-        for (int j = 6; j >= 0; j--)
-            BMPC_UNROLL
-            for (int a = 0; a < 3; a++) { sz[a] += S.K.zx[j][a] * y2[Z_DQ + j]; sufz[j][a] = sz[a]; }
-        // sufz[m] for m = 1..7 (sufz[7] = 0)
-        BMPC_UNROLL
-        for (int mm = 1; mm < 8; mm++)
-            BMPC_UNROLL
-            for (int a = 0; a < 3; a++) E.put(mm < 7 ? sufz[mm < 7 ? mm : 0][a] : 0.0);
     }
     double prim = R.prim;
     {

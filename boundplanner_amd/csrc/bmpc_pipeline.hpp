@@ -23,12 +23,12 @@ namespace bmpc {
 constexpr int F_CD = 0;                 // [c<5][i<7]    W[q_i][d_c]
 constexpr int F_P17 = F_CD + 35;        // [i<17]{C3[PS], C3[RS], C3[D5], D, g0, g1, gz} of position pos17(i)
 constexpr int F_H17 = F_P17 + 119;      // columns j=0..16, rows i<=j   (q, dq, pi) block
-constexpr int F_DGR = F_H17 + 153;      // [dg positions 14..37]{D, g0, g1, gz}: ddq, u, rs, drs, ps, dps, d
+constexpr int F_EW = F_H17 + 153;       // G_ang[3][7], J_ang[3][7]   (emitted while k_eval still holds the kinematic columns)
+constexpr int F_SUFZ = F_EW + 42;       // sufz[1..7][3] = sum_{j>=m} z_j dq_j
+constexpr int F_DGR = F_SUFZ + 21;      // [dg positions 14..37]{D, g0, g1, gz}: ddq, u, rs, drs, ps, dps, d
 constexpr int F_DZ2 = F_DGR + 96;       // zeta-diagonal rows (k == 1): sigma of rs~_1, ps~_1
 constexpr int F_GZ2 = F_DZ2 + 2;        // [r0, r1, zz][2]
-constexpr int F_EW = F_GZ2 + 6;         // G_ang[3][7], J_ang[3][7]
-constexpr int F_SUFZ = F_EW + 42;       // sufz[1..7][3] = sum_{j>=m} z_j dq_j
-constexpr int F_RDEF = F_SUFZ + 21;     // dynamics defect (32)
+constexpr int F_RDEF = F_GZ2 + 6;       // dynamics defect (32)
 constexpr int F_MAIN_END = F_RDEF + 32; // 506: written by k_eval (padded to 512)
 constexpr int F_CQP = 512;              // written by k_curv: [i][a] q_i x pi_a block of the sigmoid-weighted error terms' curvature
 constexpr int F_CQQ = F_CQP + 21;       // [a][b] second-order terms, q x q

@@ -26,6 +26,9 @@
 #define BMPC_OPAQUE_I(x) asm volatile("" : "+v"(x))
 // barrier after which the GLOBAL-memory writes of the workgroup's threads are visible to each other
 #define BMPC_FENCE_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+// nothing is scheduled across this point: keeps the loads of a later phase of a long kernel from being hoisted into an earlier one,
+// where they would only lengthen live ranges (the thread-per-pair kernels live at the edge of the register file)
+#define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define BMPC_LANE() ((int)threadIdx.x)
 // a value that is the same in every lane, moved to a scalar register (frees a vector register across calls)
 #define BMPC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)

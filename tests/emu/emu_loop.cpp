@@ -16,6 +16,7 @@ typedef double LDSD;
 #define BMPC_BLOCK() 0
 #define BMPC_NBLOCKS() 1
 #define BMPC_AS1
+#define BMPC_SCHED_FENCE() do {} while (0)
 #define BMPC_SINCOS(x, s, c) do { (s) = std::sin(x); (c) = std::cos(x); } while (0)
 using std::fmax;
 using std::fmin;
