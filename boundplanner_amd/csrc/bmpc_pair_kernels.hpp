@@ -684,11 +684,7 @@ BMPC_KBODY void k_pose_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
     }
     RowAcc R;
     R.init(&A, m.pi, m.valid, 0.0, tc, zcur);
-    {   // KKT partial sums so far (the collision-point rows, k_points)
-        GCD Sd = A.part + (size_t)PT_SIDE * A.NP + m.pi;
-        R.cmax = Sd[(size_t)(SD_KKT + 0) * A.NP]; R.csum = Sd[(size_t)(SD_KKT + 1) * A.NP]; R.cmin = Sd[(size_t)(SD_KKT + 2) * A.NP];
-        R.zsum = Sd[(size_t)(SD_KKT + 3) * A.NP]; R.prim = Sd[(size_t)(SD_KKT + 4) * A.NP]; R.nrows = Sd[(size_t)(SD_KKT + 5) * A.NP];
-    }
+    // (KKT partial sums of the pose rows only: k_points runs beside this kernel, k_eval combines the two)
     PoseAsm PO;
     PO.R = &R;
     PO.init(Hp, g12);
@@ -773,8 +769,12 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     PoseAsm PO;
     PO.R = &R;
     GCD Pz = A.part + (size_t)PT_POSE * A.NP + m.pi;
-    R.cmax = Pz[(size_t)(PZ_KKT + 0) * A.NP]; R.csum = Pz[(size_t)(PZ_KKT + 1) * A.NP]; R.cmin = Pz[(size_t)(PZ_KKT + 2) * A.NP];
-    R.zsum = Pz[(size_t)(PZ_KKT + 3) * A.NP]; R.prim = Pz[(size_t)(PZ_KKT + 4) * A.NP]; R.nrows = Pz[(size_t)(PZ_KKT + 5) * A.NP];
+    {   // KKT partial sums so far: collision-point rows (k_points) and pose rows (k_pose)
+        GCD Sd = A.part + (size_t)(PT_SIDE + SD_KKT) * A.NP + m.pi;
+        R.cmax = fmax(Sd[0], Pz[(size_t)(PZ_KKT + 0) * A.NP]); R.csum = Sd[A.NP] + Pz[(size_t)(PZ_KKT + 1) * A.NP];
+        R.cmin = fmin(Sd[2 * A.NP], Pz[(size_t)(PZ_KKT + 2) * A.NP]); R.zsum = Sd[3 * A.NP] + Pz[(size_t)(PZ_KKT + 3) * A.NP];
+        R.prim = fmax(Sd[4 * A.NP], Pz[(size_t)(PZ_KKT + 4) * A.NP]); R.nrows = Sd[5 * A.NP] + Pz[(size_t)(PZ_KKT + 5) * A.NP];
+    }
     // ---- collision-point results of k_points: q x d columns first, the rest where it is needed ----
     PointRes PA;
     PA.base = A.part + (size_t)PT_SIDE * A.NP + m.pi; PA.NP = A.NP;

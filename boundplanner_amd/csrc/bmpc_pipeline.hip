@@ -48,6 +48,19 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
     __shared__ double lds[EM_DOUBLES + 8];
     k_curv_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
+// Two pairs of kernels of a super-step do not depend on each other -- k_points / k_pose (both read the iterate, write disjoint side
+// fields) and k_eval / k_curv (disjoint fields of the stage record) -- and are launched as ONE grid each: the first nw workgroups
+// run one body, the rest the other.  Same work in the bulk regime, two launches fewer; in the straggler tail, where a launch costs
+// its single-thread latency, the two bodies run side by side (k_points 39 + k_pose 41 us -> 41, k_eval 113 + k_curv ~50 -> 113).
+// BMPC_SPLIT_LAUNCHES=1 in the environment keeps the four launches (per-kernel profiles).
+__global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_points_pose(PipeArgsH H, int nw) {
+    if ((int)blockIdx.x < nw) k_points_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+    else k_pose_body(DV(H), (int)blockIdx.x - nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+}
+__global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv(PipeArgsH H, int nw) {
+    if ((int)blockIdx.x < nw) k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+    else k_curv_body(DV(H), (int)blockIdx.x - nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+}
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
@@ -120,10 +133,16 @@ extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_ma
 // e0 / e1 (optional): events recorded around the Riccati launch (bmpc_debug_time_ric); *was_lat: which variant was launched
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int* was_lat) {
     const int nw = waves_for(A->N, n_act);
-    LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH_DYN(bmpc_k_pose, nw, 64, pair_lds_doubles(A->N, false));
-    LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
-    LAUNCH(bmpc_k_curv, nw, 64);
+    static const int split_launches = [] { const char* e = getenv("BMPC_SPLIT_LAUNCHES"); return e ? atoi(e) : 0; }();
+    if (split_launches) {
+        LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
+        LAUNCH_DYN(bmpc_k_pose, nw, 64, pair_lds_doubles(A->N, false));
+        LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
+        LAUNCH(bmpc_k_curv, nw, 64);
+    } else if (nw > 0) {
+        hipLaunchKernelGGL(bmpc_k_points_pose, dim3(2 * nw), dim3(64), pair_lds_doubles(A->N, false) * sizeof(double), st, *A, nw);
+        hipLaunchKernelGGL(bmpc_k_eval_curv, dim3(A->o.hess == 2 ? 2 * nw : nw), dim3(64), pair_lds_doubles(A->N, true) * sizeof(double), st, *A, nw);
+    }
     // BMPC_RIC_LAT_BELOW in the environment (read once): A/B runs and the test that the two variants agree bitwise
     static const int lat_below = [] { const char* e = getenv("BMPC_RIC_LAT_BELOW"); return e ? atoi(e) : BMPC_RIC_LAT_BELOW; }();
     if (e0) (void)hipEventRecord(e0, st);

@@ -39,15 +39,15 @@ def parse(path):
             solves.append(cur); cur = []
         cur.append((name, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
     solves.append(cur)
-    names = ["bmpc_k_points", "bmpc_k_pose", "bmpc_k_eval", "bmpc_k_curv", "bmpc_k_ric", "bmpc_k_ric_lat", "bmpc_k_fwd", "bmpc_k_step",
+    names = ["bmpc_k_points_pose", "bmpc_k_eval_curv", "bmpc_k_points", "bmpc_k_pose", "bmpc_k_eval", "bmpc_k_curv", "bmpc_k_ric", "bmpc_k_ric_lat", "bmpc_k_fwd", "bmpc_k_step",
              "bmpc_k_trial", "bmpc_k_accept"]      # (k_accept: builds before round 4)
-    print("B      " + " ".join(f"{n[7:]:>9s}" for n in names) + "   (us, first super-step of the solve; k_eval workgroups)")
+    print("B      " + " ".join(f"{n[7:]:>11s}" for n in names) + "   (us, first super-step of the solve; k_eval workgroups)")
     for B, sv in zip(SIZES, solves):
         d = collections.defaultdict(list)
         for n, us, wg in sv:
             if not d[n]: d[n].append(us)          # the first launch of each kernel = the first super-step
-        wg = max(w for n, _, w in sv if n == "bmpc_k_eval")
-        print(f"{B:6d} " + " ".join(f"{(sum(d[n]) / len(d[n]) if d[n] else 0):9.1f}" for n in names) + f"   {wg}")
+        wg = max([w for n, _, w in sv if n in ("bmpc_k_eval", "bmpc_k_eval_curv")] or [0])
+        print(f"{B:6d} " + " ".join(f"{(sum(d[n]) / len(d[n]) if d[n] else 0):11.1f}" for n in names) + f"   {wg}")
 
 
 if __name__ == "__main__":
