@@ -447,6 +447,9 @@ def main():
             "iters_equal_frac_of_both_converged": float(same_it.sum() / max(1, both.sum())),
             "max_abs_dx_vs_gpu_by_block": block_diffs(N, ro["x"][both], x_gpu[both]),
             "max_abs_dx_vs_gpu_by_block_same_iters": block_diffs(N, ro["x"][same_it], x_gpu[same_it]),
+            # the maxima above are heavy-tailed (single exact-Hessian iterations amplify rounding noise by up to 1e5, DESIGN.md
+            # section 5): per-instance max |dq| over the joint block, quantiles over the instances with equal iteration counts
+            "dq_vs_gpu_same_iters_median_p90_p99": [float(v) for v in np.quantile(np.abs(ro["x"][same_it][:, :7 * N] - x_gpu[same_it][:, :7 * N]).max(axis=1), [0.5, 0.9, 0.99])] if same_it.any() else None,
         }
     if rank == 0:
         print(json.dumps(out))

@@ -81,3 +81,25 @@ def test_emulated_backtracking_inside_k_trial_is_scheduling_only():
     for k in ("x", "g", "f", "iters", "status", "viol"):
         assert np.array_equal(r0[k], r9[k]) and np.array_equal(r0[k], r2[k]), k
     assert r9["steps"] <= r2["steps"] < r0["steps"]          # some trial was rejected: the backtracking instance waited for nobody
+
+
+def test_emulated_iterates_equal_the_oracles_iterate_for_iterate():
+    """The CPU-side counterpart of tests/test_iterate_parity.py (which runs the real kernels): the emulated device source and the
+    oracle stopped after k = 1, 2, 4, 8, 12 iterations are at the same point -- 1e-9 relative, per block -- and the oracle reports the
+    decisions of its last iteration consistently (bmpc_oracle_solve_batch_info).  Exact-Hessian iterations (from k ~ 8 on) included:
+    this is the comparison that exposed stale multipliers in the oracle's Hessian assembly in round 4."""
+    import iterate_parity_lib as IP
+    N, B = 10, 4
+    batch = scenes.make_batch(B, N, 1024, O.fk_batch, randomize_sets=True)
+    a = (batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    hess_seen = False
+    for k in (1, 2, 4, 8, 12):
+        r = E.solve_batch(N, *a, max_iter=k)
+        o = O.solve_batch_info(N, *a, nthreads=1, max_iter=k)
+        assert np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["status"], o["status"])
+        assert np.array_equal(o["info"][:, 0], o["iters"]) and np.array_equal(o["info"][:, 1], o["status"])
+        running = o["iters"] == k
+        rd = IP.rel_diff(N, r["x"], o["x"])
+        assert rd[running].max() <= (1e-12 if k == 1 else 1e-9), (k, rd)
+        hess_seen = hess_seen or bool((o["info"][running, 7] == 1).any())
+    assert hess_seen          # some instance has switched to the exact Hessian within twelve iterations
