@@ -15,7 +15,10 @@ namespace bmpc {
 #define BMPC_AS1
 #endif
 
-constexpr int NX = 32, NU = 9, NZ = 41, LDW = 42, LDP = 33;
+#ifndef BMPC_LDW
+#define BMPC_LDW 42
+#endif
+constexpr int NX = 32, NU = 9, NZ = 41, LDW = BMPC_LDW, LDP = 33;      // LDW: row stride of the stage matrix in LDS (even: 16-byte row reads; odd: no bank conflicts on column walks)
 constexpr int NSLOT = 208;      // inequality-row slots per stage
 constexpr int ZPAD = 48;        // padded stage vector length
 constexpr double BIGB = 1e19;

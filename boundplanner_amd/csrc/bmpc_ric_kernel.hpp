@@ -243,6 +243,7 @@ BMPC_INL void ric_phase_load_impl(RicArgs AH, LDSD* lds, int b, int lane, int k,
     {
         const bmpc_v2d z2 = {0.0, 0.0};
         for (int e = lane; e < NZ * LDW / 2; e += NT) *(LDSV2*)(RL(R_W) + 2 * e) = z2;
+        if ((NZ * LDW) % 2 != 0 && lane == 0) RL(R_W)[NZ * LDW - 1] = 0.0;
     }
     BMPC_SYNC();
     BMPC_UNROLL
@@ -606,8 +607,13 @@ BMPC_INL bool ric_phase_factor_impl(RicArgs AH, LDSD* lds, int b, int lane, int 
                 bmpc_v2d wa[NU], wb[NU];
                 BMPC_UNROLL
                 for (int l = 0; l < NU; l++) {
-                    wa[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0);
-                    wb[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0 + 2);
+                    if constexpr (LDW % 2 == 0) {
+                        wa[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0);
+                        wb[l] = *(const LDSV2*)(W + (NX + l) * LDW + i0 + 2);
+                    } else {          // (odd row stride: rows are not 16-byte aligned)
+                        wa[l][0] = W[(NX + l) * LDW + i0]; wa[l][1] = W[(NX + l) * LDW + i0 + 1];
+                        wb[l][0] = W[(NX + l) * LDW + i0 + 2]; wb[l][1] = W[(NX + l) * LDW + i0 + 3];
+                    }
                 }
                 double p0 = W[i0 * LDW + j], p1 = W[(i0 + 1) * LDW + j], p2 = W[(i0 + 2) * LDW + j], p3 = W[(i0 + 3) * LDW + j];
                 BMPC_UNROLL
