@@ -1,6 +1,7 @@
 // bmpc_pair_kernels.hpp -- the thread-per-(instance, stage) kernels of the pipeline:
 //   k_init   initial iterate from x0 (BoundMPC.py:412-416 warm/cold start vector), row slacks
-//   k_eval   accept the trial point, evaluate it, assemble the stage record for the Riccati sweep
+//   k_points collision-point rows; k_pose reference / error context, cost, pose rows -> pose-space sums (side array)
+//   k_eval   kinematic columns, chaining of the pose-space sums, diagonal rows, defect -> the stage record for the Riccati sweep
 //   k_step   row steps of the Newton direction, fraction-to-boundary partials, merit derivative
 //   k_trial  line-search trial points (+ the multipliers' update), filter test, backtracking
 //   k_out    solution in the reference layout (casadi_ocp_formulation.py:89-101), g, violation

@@ -706,7 +706,6 @@ BMPC_INL void ric_stage_adjoint_impl(RicArgs AH, LDSD* lds, int b, int lane, int
         if (lane < NX) { RL(R_lam)[lane] = gl; RL(R_acc)[lane] += fabs(gl); }
     }
 }
-template <int NT> BMPC_NOINL void ric_stage_adjoint(RicArgs AH, LDSD* lds, int b, int lane, int k, const int* tpk) { ric_stage_adjoint_impl<NT>(AH, lds, b, lane, k, tpk); }
 
 template <int NT> BMPC_NOINL void ric_phase_load(RicArgs AH, LDSD* lds, int b, int lane, int k, int hess_mode, const int* tpk) {
     ric_phase_load_impl<NT>(AH, lds, b, lane, k, hess_mode, tpk);
