@@ -1,8 +1,8 @@
-"""Generates the per-instance files behind tests/golden/bridge_N{10,15,20}.npz: solutions of BASELINE configs[1]/[2]-style
+"""Generates the per-instance files behind tests/golden/bridge_N{10,15,20,30}.npz: solutions of BASELINE configs[1]/[2]-style
 instances by INDEPENDENT third-party NLP methods (scipy SLSQP; scipy trust-constr where it converges) from the
 reference's cold start, on the pinned full-space NLP (tests/independent_nlp.py).  SURVEY.md 8(c) bridge (ii).
 
-SLSQP is a dense active-set SQP: one instance takes ~2 min at N=10, ~8 min at N=15 and ~35 min at N=20 on one core, so
+SLSQP is a dense active-set SQP: one instance takes ~2 min at N=10, ~8 min at N=15, ~35 min at N=20 and hours at N=30 on one core, so
 the instances are farmed out to worker processes and every finished instance is written at once:
     python tests/golden/gen/gen_bridge.py N first count [method]      # one worker: instances first..first+count-1
     python tests/golden/gen/gen_bridge.py verify N                    # where SLSQP and the interior-point oracle ended in DIFFERENT local
@@ -52,7 +52,7 @@ def main():
                   "moved q %.1e task %.1e" % (np.abs(s.x - r["x"])[:7 * N].max(), np.abs(s.x - r["x"])[28 * N:40 * N].max()), flush=True)
         return
     if sys.argv[1] == "collect":
-        for N in (10, 15, 20):
+        for N in (10, 15, 20, 30):
             for method in ("slsqp", "trust-constr"):
                 files = sorted(glob.glob(os.path.join(OUT, f"N{N}_*_{method}.npz")))
                 if not files:

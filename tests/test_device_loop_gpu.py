@@ -313,10 +313,10 @@ def _config4_loop(be, q_start, fs, fg, params, rows):
 
 
 def test_config4_closed_loop_full_size():
-    """BASELINE configs[4] at its full width (4096 rollouts, N=30, warm start as the reference, SURVEY 8(d) generator, seed
-    4096) through the device-resident loop: (1) every accepted step passes the reference's acceptance test; (2) a
+    """BASELINE configs[4] at its full size (4096 rollouts x 200 steps, N=30, warm start as the reference, SURVEY 8(d) generator,
+    seed 4096) through the device-resident loop: (1) every accepted step passes the reference's acceptance test; (2) a
     rollout's trajectory does not depend on the batch it is stepped in (the first 512 rollouts alone, bitwise);
-    (3) who reaches the path end (1024 rollouts, 110 steps).  The SURVEY generator draws goals from U(0.5 q_lim) and fixes the
+    (3) who reaches the path end (all 4096 rollouts after the 200 steps).  The SURVEY generator draws goals from U(0.5 q_lim) and fixes the
     end-effector set to the workspace box [-1,-1,0]-[1,1,1.2]; the iiwa reaches z = 1.43 there, so 49 % of the goal poses
     lie OUTSIDE the set the end effector must stay in.  Those rollouts stop at the box (their last solve is a KKT point with
     the set rows active: tools/closed_loop_device.py --diagnose, profiles/r02_closed_loop_diag.json) -- a property of the
@@ -324,7 +324,7 @@ def test_config4_closed_loop_full_size():
     from boundplanner_amd import scenes
     from boundplanner_amd.params import Q_LIM_LOWER, Q_LIM_UPPER
     from boundplanner_amd.solver import HipBoundMPC
-    N, R, steps = 30, 4096, 30
+    N, R, steps = 30, 4096, 200
     params = _params(N)
     be = HipBoundMPC(N, max_batch=R)
     rng = np.random.default_rng(4096)
@@ -336,7 +336,7 @@ def test_config4_closed_loop_full_size():
     it, st, viol, err, dead = (log[:, :, L[k]] for k in ("iters", "status", "viol", "error_count", "dead"))
     accepted = (err == 0) & (dead == 0)
     assert ((st[accepted] == 0) | (viol[accepted] < 1e-4)).all()
-    assert (err > 0).mean() < 0.01 and dead[-1].sum() <= 8
+    assert (err > 0).mean() < 1e-3 and dead[-1].sum() <= 8                # (observed: 8 failed solves of 819 200, nobody frozen)
     assert it[0].mean() > it[10:].mean()                     # the warm start pays: later steps are cheaper than the first
     print(f"configs[4], 4096 rollouts x {steps} steps: mean iterations {it.mean():.1f} (first step {it[0].mean():.1f}), failed steps "
           f"{(err > 0).mean():.4f}, frozen rollouts {int(dead[-1].sum())}")
@@ -345,9 +345,9 @@ def test_config4_closed_loop_full_size():
     log2 = sub.run(12)
     for k in ("q", "p_lie", "phi", "iters", "status"):
         assert np.array_equal(log2[:, :, L[k]], log[:12, :512, L[k]]), k
-    # (3) path end: the 1024 rollouts behind the first 512, long enough for the slow ones
-    rows = np.arange(512, 1536)
-    lg = _config4_loop(be, q_start, fs, fg, params, rows).run(110, log=True)[-1]
+    # (3) path end, all rollouts after the config's 200 steps
+    rows = np.arange(R)
+    lg = log[-1]
     reached = lg[:, L["phi"]] >= lg[:, L["phi_max"]] - 0.001
     pg = fg["ee_pos"][rows]
     inside = (np.abs(pg[:, :2]) < 0.98).all(axis=1) & (pg[:, 2] < 1.18) & (pg[:, 2] > 0.02)
@@ -355,7 +355,7 @@ def test_config4_closed_loop_full_size():
     q_end = lg[:, L["q"]]
     at_limit = (np.minimum(q_end - Q_LIM_LOWER, Q_LIM_UPPER - q_end) < 2e-3).any(axis=1)
     ok = inside & ~at_limit & (lg[:, L["dead"]] == 0)
-    print(f"  after 110 steps: at the path end {reached.mean():.3f}; goals inside the workspace box {inside.mean():.3f} -> at the end "
+    print(f"  after {steps} steps: at the path end {reached.mean():.3f}; goals inside the workspace box {inside.mean():.3f} -> at the end "
           f"{reached[ok].mean():.3f} (not at a joint limit); goals above z = 1.25 ({far_out.mean():.3f}) -> at the end {reached[far_out].mean():.3f}")
     # observed: 1.000 of the goals inside the box, 0.16 of the goals above z = 1.25 (the set rows are soft: pslack)
     assert reached[ok].mean() > 0.99 and reached[far_out].mean() < 0.3

@@ -349,7 +349,7 @@ def test_hip_matches_committed_slsqp_solutions(backends, golden_dir):
         assert (np.abs(r["f"] - d["f"]) <= 1e-5 * np.abs(d["f"])).all()
 
 
-@pytest.mark.parametrize("name", ["bridge_N10.npz", "bridge_N10_tc.npz", "bridge_N15.npz", "bridge_N20.npz"])
+@pytest.mark.parametrize("name", ["bridge_N10.npz", "bridge_N10_tc.npz", "bridge_N15.npz", "bridge_N20.npz", "bridge_N30.npz"])
 def test_hip_matches_bridge_solutions(backends, golden_dir, name):
     """SURVEY 8(c) bridge (ii) on the product path, widened (tests/golden/gen/gen_bridge.py): the HIP solve lands on the
     solutions independent scipy methods (SLSQP, trust-constr) found from the reference's cold start, or -- where the two

@@ -47,7 +47,7 @@ def test_oracle_matches_committed_slsqp_solutions_N10(golden_dir):
 
 
 # ---- the wider bridge: tests/golden/bridge_N*.npz (tests/golden/gen/gen_bridge.py) ----
-BRIDGE = ["bridge_N10.npz", "bridge_N10_tc.npz", "bridge_N15.npz", "bridge_N20.npz"]
+BRIDGE = ["bridge_N10.npz", "bridge_N10_tc.npz", "bridge_N15.npz", "bridge_N20.npz", "bridge_N30.npz"]
 
 
 def bridge_check(name, d, solve):
