@@ -421,6 +421,11 @@ def test_config0_plan_then_track_with_replanning_on_the_device_loop(golden_dir):
     from boundplanner_amd import mpc_data
     recs = loop.records()
     assert recs.shape[:2] == (10, 1)
+    # a caller's buffer that is too small for the recorded steps is refused, not overrun (bmpc_loop_records takes its capacity)
+    import ctypes
+    small = np.zeros((3, 1, recs.shape[2])); nst = ctypes.c_int(0)
+    assert loop.lib.bmpc_loop_records(loop._l, small.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 3, ctypes.byref(nst)) == 1
+    assert nst.value == 10 and not small.any()
     for k in range(10):                          # the trace of the run: one MPCData record per step, consistent with the log
         md = mpc_data.from_device_record(recs[k, 0], N)
         assert md["iterations"] == int(log[k, 0, L["iters"]]) and len(md["p"]) == N - 1 and len(md["dddq"]) == N
