@@ -18,7 +18,9 @@ namespace bmpc {
 #ifndef BMPC_LDW
 #define BMPC_LDW 42
 #endif
-constexpr int NX = 32, NU = 9, NZ = 41, LDW = BMPC_LDW, LDP = 33;      // LDW: row stride of the stage matrix in LDS (even: 16-byte row reads; odd: no bank conflicts on column walks)
+constexpr int NX = 32, NU = 9, NZ = 41, LDW = BMPC_LDW;      // LDW: row stride of the stage matrix in LDS (even: 16-byte row reads; odd: no bank conflicts on column walks)
+// the value-function Hessian P (32 x 32, symmetric) is held packed in LDS: lower triangle by rows (528 doubles instead of 32 x 33)
+constexpr int NPSYM = NX * (NX + 1) / 2;
 constexpr int NSLOT = 208;      // inequality-row slots per stage
 constexpr int ZPAD = 48;        // padded stage vector length
 constexpr double BIGB = 1e19;

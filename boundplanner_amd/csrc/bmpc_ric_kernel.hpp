@@ -12,7 +12,7 @@ namespace bmpc {
 
 // ---- LDS layout of k_ric (doubles) ----
 constexpr int R_P = 0;
-constexpr int R_W = R_P + NX * LDP;
+constexpr int R_W = R_P + NPSYM;
 constexpr int R_g0 = R_W + NZ * LDW;
 constexpr int R_g1 = R_g0 + ZPAD;
 constexpr int R_gz = R_g1 + ZPAD;
@@ -22,26 +22,39 @@ constexpr int R_pv1 = R_pv0 + NX;
 constexpr int R_vt0 = R_pv1 + NX;
 constexpr int R_vt1 = R_vt0 + NX;
 constexpr int R_rdef = R_vt1 + NX;
-constexpr int R_Kl = R_rdef + NX;           // 9 x 32
-constexpr int R_kf = R_Kl + NU * NX;        // 2 x 16
+constexpr int R_kf = R_rdef + NX;           // 2 x 16
 constexpr int R_Et = R_kf + 32;             // 3 x 41
 constexpr int R_Y = R_Et + 3 * NZ;          // 41 x 3
 constexpr int R_ew = R_Y + 3 * NZ;          // G_ang[3][7], J_ang[3][7]
 constexpr int R_sufz = R_ew + 42;           // [7][3]
 constexpr int R_dz2 = R_sufz + 24;          // sigma[2], r0[2], r1[2], zz[2]
 constexpr int R_r0 = R_dz2 + 8;
-constexpr int R_misc = R_r0 + NX;           // 48: junk targets of the scatter [0,32), phase timers [32,48)
-constexpr int R_acc = R_misc + 48;          // 2 x 48: per-lane |lambda| sums and dual-residual maxima (lanes < 41)
+#ifdef BMPC_PROFILE
+constexpr int R_MISC_DOUBLES = 48;          // junk targets of the scatter and of the record touches [0,32), phase timers [32,48)
+#else
+constexpr int R_MISC_DOUBLES = 32;
+#endif
+constexpr int R_misc = R_r0 + NX;
+constexpr int R_acc = R_misc + R_MISC_DOUBLES;   // 2 x 48: per-lane |lambda| sums and dual-residual maxima (lanes < 41)
 constexpr int R_park = R_acc + 96;          // 16: uniform scalars parked across the sweep calls
 constexpr int RIC_LDS_DOUBLES = R_park + 16;
+// the gains K (9 x 32) of a stage live from its factorisation to its Schur complement (both in the factor phase): they share the
+// coupling phase's R_Et, R_Y and the record's R_ew (read by the load and coupling phases, rewritten by the next stage's scatter)
+constexpr int R_Kl = R_Et;
+static_assert(R_Kl + NU * NX <= R_sufz, "gains fit the coupling scratch");
 // used before the backward sweep / by the forward start only: they share the coupling phase's R_Et, R_Y (246 doubles)
 constexpr int R_dx = R_Et;
 constexpr int R_x1fix = R_dx + NX;
 constexpr int R_dzeta = R_x1fix + NX;       // 48 (forward start: packed 8 x 8 factor)
 constexpr int R_dy = R_dzeta + ZPAD;        // 48 (forward start: right-hand side)
 static_assert(R_dy + ZPAD <= R_Y + 3 * NZ, "forward-start scratch fits the coupling scratch");
-// 31.6 KB: five workgroups per CU (160 KB of LDS), i.e. 10 wavefronts = 2.5 per SIMD, which needs <= 168 VGPRs
-static_assert(RIC_LDS_DOUBLES * 8 <= 32768, "k_ric LDS: 5 workgroups per CU");
+// 24.8 KB (31.6 KB with P as 32 x 33 and gains of their own, rounds 1-4: five workgroups per CU): SIX workgroups per CU (160 KB of
+// LDS), i.e. 12 wavefronts = 3 per SIMD, which needs <= 168 VGPRs
+#ifndef BMPC_PROFILE
+static_assert(RIC_LDS_DOUBLES * 8 <= 26624, "k_ric LDS: 6 workgroups per CU");
+#endif
+// P[r][c] in the packed lower triangle
+BMPC_HD constexpr int psym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 
 // scatter table entry of one record field: pass (0 none, 1 store, 2 add, 3 add when hess_mode),
 // LDS offsets of the target and of its symmetric mirror (-1 = none)
@@ -373,12 +386,11 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
                 et[a] = v;
             }
             PhiCol pc = phi_col(c, dc);
-            const LDSD* Pp = RL(R_P) + Z_PI * LDP + Z_PI;
             double pr[3][3], pp[3][3];
             BMPC_UNROLL
             for (int a = 0; a < 3; a++) {
-                pr[0][a] = RL(R_P)[pc.i0 * LDP + Z_PI + a]; pr[1][a] = RL(R_P)[pc.i1 * LDP + Z_PI + a]; pr[2][a] = RL(R_P)[pc.i2 * LDP + Z_PI + a];
-                pp[0][a] = Pp[a]; pp[1][a] = Pp[LDP + a]; pp[2][a] = Pp[2 * LDP + a];
+                pr[0][a] = RL(R_P)[psym(pc.i0, Z_PI + a)]; pr[1][a] = RL(R_P)[psym(pc.i1, Z_PI + a)]; pr[2][a] = RL(R_P)[psym(pc.i2, Z_PI + a)];
+                pp[0][a] = RL(R_P)[psym(Z_PI, Z_PI + a)]; pp[1][a] = RL(R_P)[psym(Z_PI + 1, Z_PI + a)]; pp[2][a] = RL(R_P)[psym(Z_PI + 2, Z_PI + a)];
             }
             BMPC_UNROLL
             for (int a = 0; a < 3; a++) {
@@ -391,7 +403,7 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
             const int r = lane - (NT - 32);
             double v = RL(R_pv0)[r];
             BMPC_UNROLL
-            for (int j = 0; j < NX; j++) v += RL(R_P)[r * LDP + j] * RL(R_rdef)[j];
+            for (int j = 0; j < NX; j++) v += RL(R_P)[psym(r, j)] * RL(R_rdef)[j];
             RL(R_vt0)[r] = v;
         }
         BMPC_SYNC();
@@ -422,7 +434,7 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
                 BMPC_UNROLL
                 for (int r = 0; r < 3; r++)
                     BMPC_UNROLL
-                    for (int s2 = 0; s2 < 3; s2++) Pb[r][s2] = P[(7 * r + aA) * LDP + 7 * s2 + bA];
+                    for (int s2 = 0; s2 < 3; s2++) Pb[r][s2] = P[psym(7 * r + aA, 7 * s2 + bA)];
                 BMPC_UNROLL
                 for (int gi = 0; gi < 4; gi++)
                     BMPC_UNROLL
@@ -437,7 +449,7 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
                 slB[u] = (cB[u] == Z_RS || cB[u] == Z_PS);
                 cwB[u] = (cB[u] == Z_RS) ? Z_DRS : Z_DPS;
                 if (hasB[u]) {
-                    pB[u][0] = P[aB[u] * LDP + cB[u]]; pB[u][1] = P[(7 + aB[u]) * LDP + cB[u]]; pB[u][2] = P[(14 + aB[u]) * LDP + cB[u]];
+                    pB[u][0] = P[psym(cB[u], aB[u])]; pB[u][1] = P[psym(cB[u], 7 + aB[u])]; pB[u][2] = P[psym(cB[u], 14 + aB[u])];
                     BMPC_UNROLL
                     for (int gi = 0; gi < 4; gi++) {
                         const int r = gpos[gi] + aB[u];
@@ -455,7 +467,7 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
                 s1C[u] = (c1C[u] == Z_RS || c1C[u] == Z_PS); s2C[u] = (c2C[u] == Z_RS || c2C[u] == Z_PS);
                 w1C[u] = (c1C[u] == Z_RS) ? Z_DRS : Z_DPS; w2C[u] = (c2C[u] == Z_RS) ? Z_DRS : Z_DPS;
                 if (hasC[u]) {
-                    vC[u] = P[c1C[u] * LDP + c2C[u]];
+                    vC[u] = P[psym(c1C[u], c2C[u])];
                     aC[u][0] = W[c1C[u] * LDW + c2C[u]];
                     aC[u][1] = s2C[u] ? W[c1C[u] * LDW + w2C[u]] : 0.0;
                     aC[u][2] = s1C[u] ? W[w1C[u] * LDW + c2C[u]] : 0.0;
@@ -618,8 +630,12 @@ BMPC_INL bool ric_phase_factor_impl(RicArgs AH, LDSD* lds, int b, int lane, int 
                 double p0 = W[i0 * LDW + j], p1 = W[(i0 + 1) * LDW + j], p2 = W[(i0 + 2) * LDW + j], p3 = W[(i0 + 3) * LDW + j];
                 BMPC_UNROLL
                 for (int l = 0; l < NU; l++) { p0 += wa[l][0] * kj[l]; p1 += wa[l][1] * kj[l]; p2 += wb[l][0] * kj[l]; p3 += wb[l][1] * kj[l]; }
-                RL(R_P)[i0 * LDP + j] = p0; RL(R_P)[(i0 + 1) * LDP + j] = p1;
-                RL(R_P)[(i0 + 2) * LDP + j] = p2; RL(R_P)[(i0 + 3) * LDP + j] = p3;
+                // (P is symmetric up to rounding: the lower triangle is kept)
+                const int pb = i0 * (i0 + 1) / 2 + j;
+                if (i0 >= j) RL(R_P)[pb] = p0;
+                if (i0 + 1 >= j) RL(R_P)[pb + i0 + 1] = p1;
+                if (i0 + 2 >= j) RL(R_P)[pb + 2 * i0 + 3] = p2;
+                if (i0 + 3 >= j) RL(R_P)[pb + 3 * i0 + 6] = p3;
             }
         }
         // pv = g_x + W_xu kf (two right-hand sides)
@@ -817,13 +833,13 @@ BMPC_NOINL bool ric_forward(RicArgs AH, LDSD* lds, int b, int lane) {
         for (int i = 0; i < 8; i++) {
             double s = RL(R_pv0)[24 + i] + mu * RL(R_pv1)[24 + i];
 #pragma unroll 4
-            for (int j = 0; j < 24; j++) s += RL(R_P)[(24 + i) * LDP + j] * RL(R_r0)[j];
+            for (int j = 0; j < 24; j++) s += RL(R_P)[psym(24 + i, j)] * RL(R_r0)[j];
             rhs[i] = -s;
         }
 #define PF(i, j) Pf[(i) * ((i) + 1) / 2 + (j)]
         BMPC_UNROLL
         for (int j = 0; j < 8; j++) {
-            double d = RL(R_P)[(24 + j) * LDP + 24 + j];
+            double d = RL(R_P)[psym(24 + j, 24 + j)];
             BMPC_UNROLL
             for (int l = 0; l < j; l++) d -= PF(j, l) * PF(j, l);
             if (!(d > 0)) { ok = false; d = 1.0; }
@@ -831,7 +847,7 @@ BMPC_NOINL bool ric_forward(RicArgs AH, LDSD* lds, int b, int lane) {
             PF(j, j) = d;
             BMPC_UNROLL
             for (int i = j + 1; i < 8; i++) {
-                double s = RL(R_P)[(24 + i) * LDP + 24 + j];
+                double s = RL(R_P)[psym(24 + i, 24 + j)];
                 BMPC_UNROLL
                 for (int l = 0; l < j; l++) s -= PF(i, l) * PF(j, l);
                 PF(i, j) = s / d;
