@@ -64,10 +64,13 @@ __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv(PipeArgsH 
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
+#ifndef BMPC_RIC_WPE
+#define BMPC_RIC_WPE 3      // wavefronts per SIMD the throughput variant is compiled for
+#endif
 // disable_tail_calls: a call site marked `tail` (LLVM marks every call that is handed no pointer into the caller's stack frame)
 // makes the callee save and restore the 64 callee-saved VGPRs it uses (the register-usage propagation that lets the sweeps clobber
 // them is skipped for functions with such call sites): 128 scratch accesses per lane and sweep
-__global__ __launch_bounds__(BMPC_RIC_NT, 3) __attribute__((disable_tail_calls)) void bmpc_k_ric(PipeArgsH H) {          // throughput variant: 5 workgroups per CU (2.5 wavefronts / SIMD)
+__global__ __launch_bounds__(BMPC_RIC_NT, BMPC_RIC_WPE) __attribute__((disable_tail_calls)) void bmpc_k_ric(PipeArgsH H) {          // throughput variant: 6 workgroups per CU (3 wavefronts / SIMD)
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
     k_ric_body<BMPC_RIC_NT, true>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }

@@ -57,6 +57,7 @@ __device__ __forceinline__ double bmpc_rcp(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 #define BMPC_RCP(x) bmpc_rcp(x)
+#define BMPC_MUL24(a, b) __mul24((a), (b))       // full-rate 24-bit integer multiply (v_mul_lo_u32 runs at a quarter of the rate)
 // sin and cos of a joint angle together: ONE Cody-Waite reduction by pi/2 (two-term, exact to 1e-16 for the |x| < 1e5 that joint
 // angles and line-search trial points stay within) and the fdlibm kernel polynomials on [-pi/4, pi/4] -- ~45 instructions for the
 // pair, against ~260 for the library's separate sin(x), cos(x) with their large-argument paths (14 calls per kinematic chain, which

@@ -6,6 +6,7 @@
 // gains go to a per-pair scratch record that the forward recursion reads back.
 // Also here: the per-instance control kernels of the filter line search.
 #pragma once
+#include <type_traits>
 #include "bmpc_pipeline.hpp"
 
 namespace bmpc {
@@ -37,7 +38,10 @@ constexpr int R_MISC_DOUBLES = 32;
 constexpr int R_misc = R_r0 + NX;
 constexpr int R_acc = R_misc + R_MISC_DOUBLES;   // 2 x 48: per-lane |lambda| sums and dual-residual maxima (lanes < 41)
 constexpr int R_park = R_acc + 96;          // 16: uniform scalars parked across the sweep calls
-constexpr int RIC_LDS_DOUBLES = R_park + 16;
+#ifndef BMPC_RIC_LDS_PAD
+#define BMPC_RIC_LDS_PAD 0      // (experiments: padding that lowers the number of resident workgroups)
+#endif
+constexpr int RIC_LDS_DOUBLES = R_park + 16 + BMPC_RIC_LDS_PAD;
 // the gains K (9 x 32) of a stage live from its factorisation to its Schur complement (both in the factor phase): they share the
 // coupling phase's R_Et, R_Y and the record's R_ew (read by the load and coupling phases, rewritten by the next stage's scatter)
 constexpr int R_Kl = R_Et;
@@ -50,11 +54,13 @@ constexpr int R_dy = R_dzeta + ZPAD;        // 48 (forward start: right-hand sid
 static_assert(R_dy + ZPAD <= R_Y + 3 * NZ, "forward-start scratch fits the coupling scratch");
 // 24.8 KB (31.6 KB with P as 32 x 33 and gains of their own, rounds 1-4: five workgroups per CU): SIX workgroups per CU (160 KB of
 // LDS), i.e. 12 wavefronts = 3 per SIMD, which needs <= 168 VGPRs
-#ifndef BMPC_PROFILE
+#if !defined(BMPC_PROFILE) && BMPC_RIC_LDS_PAD == 0
 static_assert(RIC_LDS_DOUBLES * 8 <= 26624, "k_ric LDS: 6 workgroups per CU");
 #endif
 // P[r][c] in the packed lower triangle
-BMPC_HD constexpr int psym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+BMPC_INL int ptri(int i) { return BMPC_MUL24(i, i + 1) >> 1; }            // offset of row i
+BMPC_INL int psym_hl(int hi, int lo) { return ptri(hi) + lo; }             // hi >= lo known
+BMPC_INL int psym(int r, int c) { return r >= c ? ptri(r) + c : ptri(c) + r; }
 
 // scatter table entry of one record field: pass (0 none, 1 store, 2 add, 3 add when hess_mode),
 // LDS offsets of the target and of its symmetric mirror (-1 = none)
@@ -323,38 +329,53 @@ BMPC_INL void ric_phase_load_impl(RicArgs AH, LDSD* lds, int b, int lane, int k,
         BMPC_SYNC();
     }
     RPROF(1);
-    // ---- natural -> zeta coordinates: H = T^T Hy T.  Column pass, then row pass (+ the three
-    // gradient vectors); offsets precomputed per lane, every lane gathers the operands of all its
-    // entries before it stores ----
-    BMPC_UNROLL
-    for (int pass = 0; pass < 2; pass++) {
-        double s0[NE2], s1[NE2], s2[NE2], d0[NE2];
-        int od[NE2];
-        bool ij[NE2];
+    // ---- natural -> zeta coordinates: H = T^T Hy T.  Column pass (W[i][u_t] += c3 W[i][q_t] + c2 W[i][dq_t] + c1 W[i][ddq_t], the
+    // two slack columns likewise), then row pass (+ the three gradient vectors).  Lane l of each wavefront owns row (column) i = l;
+    // the nine transformed positions t are split between the wavefronts, so that every offset is an immediate: the kernel is bound by
+    // instruction issue, not by lanes (round 4: entries dealt out evenly over all lanes cost ~25 index instructions each) ----
+    {
+        const int wl = lane & 63, wv = lane >> 6;
         BMPC_UNROLL
-        for (int m = 0; m < NE2; m++) {
-            // entry e: (i, t) of the 41 x 9 grid (column pass: row i, transformed column t; row pass:
-            // column i, transformed row t), then the 27 vector entries (row pass only); branch-free
-            const int e = lane + NT * m;
-            const bool inw = e < NZ * 9, inv = !inw && (e < NZ * 9 + 27) && pass == 1;
-            const int ev = inw ? e : (inv ? e - NZ * 9 : 0);
-            const int i = ev / 9, t = ev - 9 * i;
-            const bool isj = t < 7;
-            const int sp = isj ? Z_Q + t : (t == 7 ? Z_RS : Z_PS), dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
-            // W entries: offset of (row, col); vector entries: i selects g0 / g1 / gz
-            const int str = pass ? LDW : 1, base = pass ? R_W + i : R_W + i * LDW;
-            const int vb = (i == 0 ? R_g0 : i == 1 ? R_g1 : R_gz);
-            int o_d = inw ? base + dp * str : vb + dp, o_s = inw ? base + sp * str : vb + sp;
-            const int st7 = inw ? 7 * str : 7;
-            if (!inw && !inv) { o_d = junk; o_s = junk; }
-            od[m] = o_d; ij[m] = isj;
-            d0[m] = lds[o_d]; s0[m] = lds[o_s];
-            s1[m] = lds[isj && (inw || inv) ? o_s + st7 : o_s]; s2[m] = lds[isj && (inw || inv) ? o_s + 2 * st7 : o_s];
+        for (int pass = 0; pass < 2; pass++) {
+            const int str = pass ? LDW : 1;
+            if (wl < NZ) {
+                LDSD* bp = RL(R_W) + (pass ? wl : wl * LDW);
+                auto run = [&](auto T0c, auto T1c) {
+                    constexpr int T0 = decltype(T0c)::value, T1 = decltype(T1c)::value;
+                    double d0[T1 - T0], s0[T1 - T0], s1[T1 - T0], s2[T1 - T0];
+                    BMPC_UNROLL
+                    for (int t = T0; t < T1; t++) {
+                        const bool isj = t < 7;
+                        const int sp = isj ? Z_Q + t : (t == 7 ? Z_RS : Z_PS), dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
+                        d0[t - T0] = bp[dp * str]; s0[t - T0] = bp[sp * str];
+                        if (isj) { s1[t - T0] = bp[(sp + 7) * str]; s2[t - T0] = bp[(sp + 14) * str]; }
+                    }
+                    BMPC_UNROLL
+                    for (int t = T0; t < T1; t++) {
+                        const bool isj = t < 7;
+                        const int dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
+                        if (isj) bp[dp * str] = d0[t - T0] + dc.c3 * s0[t - T0] + dc.c2 * s1[t - T0] + dc.c1 * s2[t - T0];
+                        else bp[dp * str] = d0[t - T0] + (0.5 * dc.dt) * s0[t - T0];
+                    }
+                };
+                if constexpr (NT == 64) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+                else if (wv == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+                else run(std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
+            } else if (pass == 1) {
+                // the 27 entries of the three gradient vectors: one per lane among the lanes without a column
+                constexpr int FREE = 64 - NZ;
+                static_assert(FREE * (NT / 64) >= 27 || NT == 64, "vector entries: one per free lane");
+                for (int ev = (wl - NZ) + FREE * wv; ev < 27; ev += FREE * (NT / 64)) {
+                    const int i = ev / 9, t = ev - 9 * i;
+                    const bool isj = t < 7;
+                    const int sp = isj ? Z_Q + t : (t == 7 ? Z_RS : Z_PS), dp = isj ? Z_U + t : (t == 7 ? Z_DRS : Z_DPS);
+                    LDSD* vb = RL(i == 0 ? R_g0 : i == 1 ? R_g1 : R_gz);
+                    const double d0 = vb[dp], s0 = vb[sp], s1 = vb[isj ? sp + 7 : sp], s2 = vb[isj ? sp + 14 : sp];
+                    vb[dp] = isj ? d0 + dc.c3 * s0 + dc.c2 * s1 + dc.c1 * s2 : d0 + (0.5 * dc.dt) * s0;
+                }
+            }
+            BMPC_SYNC();
         }
-        BMPC_UNROLL
-        for (int m = 0; m < NE2; m++)
-            lds[od[m]] = d0[m] + (ij[m] ? dc.c3 : 0.5 * dc.dt) * s0[m] + (ij[m] ? dc.c2 : 0.0) * s1[m] + (ij[m] ? dc.c1 : 0.0) * s2[m];
-        BMPC_SYNC();
     }
     if (k == 1 && lane < 2) {   // zeta-diagonal rows rs~_1, ps~_1 >= 0
         int pos = lane ? Z_PS : Z_RS;
@@ -402,8 +423,9 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
         if (lane >= NT - 32) {
             const int r = lane - (NT - 32);
             double v = RL(R_pv0)[r];
+            const int tr = ptri(r);
             BMPC_UNROLL
-            for (int j = 0; j < NX; j++) v += RL(R_P)[psym(r, j)] * RL(R_rdef)[j];
+            for (int j = 0; j < NX; j++) v += RL(R_P)[j <= r ? tr + j : j * (j + 1) / 2 + r] * RL(R_rdef)[j];
             RL(R_vt0)[r] = v;
         }
         BMPC_SYNC();
@@ -434,7 +456,7 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
                 BMPC_UNROLL
                 for (int r = 0; r < 3; r++)
                     BMPC_UNROLL
-                    for (int s2 = 0; s2 < 3; s2++) Pb[r][s2] = P[psym(7 * r + aA, 7 * s2 + bA)];
+                    for (int s2 = 0; s2 < 3; s2++) Pb[r][s2] = P[r > s2 ? psym_hl(7 * r + aA, 7 * s2 + bA) : r < s2 ? psym_hl(7 * s2 + bA, 7 * r + aA) : psym(7 * r + aA, 7 * r + bA)];
                 BMPC_UNROLL
                 for (int gi = 0; gi < 4; gi++)
                     BMPC_UNROLL
@@ -449,7 +471,7 @@ BMPC_INL void ric_phase_couple_impl(RicArgs AH, LDSD* lds, int lane) {
                 slB[u] = (cB[u] == Z_RS || cB[u] == Z_PS);
                 cwB[u] = (cB[u] == Z_RS) ? Z_DRS : Z_DPS;
                 if (hasB[u]) {
-                    pB[u][0] = P[psym(cB[u], aB[u])]; pB[u][1] = P[psym(cB[u], 7 + aB[u])]; pB[u][2] = P[psym(cB[u], 14 + aB[u])];
+                    pB[u][0] = P[psym_hl(cB[u], aB[u])]; pB[u][1] = P[psym_hl(cB[u], 7 + aB[u])]; pB[u][2] = P[psym_hl(cB[u], 14 + aB[u])];      // (cB >= 21 > 14 + aB)
                     BMPC_UNROLL
                     for (int gi = 0; gi < 4; gi++) {
                         const int r = gpos[gi] + aB[u];
@@ -631,7 +653,7 @@ BMPC_INL bool ric_phase_factor_impl(RicArgs AH, LDSD* lds, int b, int lane, int 
                 BMPC_UNROLL
                 for (int l = 0; l < NU; l++) { p0 += wa[l][0] * kj[l]; p1 += wa[l][1] * kj[l]; p2 += wb[l][0] * kj[l]; p3 += wb[l][1] * kj[l]; }
                 // (P is symmetric up to rounding: the lower triangle is kept)
-                const int pb = i0 * (i0 + 1) / 2 + j;
+                const int pb = ptri(i0) + j;
                 if (i0 >= j) RL(R_P)[pb] = p0;
                 if (i0 + 1 >= j) RL(R_P)[pb + i0 + 1] = p1;
                 if (i0 + 2 >= j) RL(R_P)[pb + 2 * i0 + 3] = p2;

@@ -28,6 +28,7 @@ typedef double bmpc_v2d __attribute__((vector_size(16)));
 typedef bmpc_v2d LDSV2;
 #define BMPC_RSQRT(x) (1.0 / std::sqrt(x))
 #define BMPC_RCP(x) (1.0 / (x))
+#define BMPC_MUL24(a, b) ((a) * (b))
 #define BMPC_SCHED_FENCE() do {} while (0)
 #define BMPC_SINCOS(x, s, c) do { (s) = std::sin(x); (c) = std::cos(x); } while (0)
 #define BMPC_LDS_ADD(ptr, v) (*(ptr) += (v))
