@@ -35,6 +35,9 @@ constexpr int P_SPLIT = 0, P_SLACKS0 = 5, P_IWREF = 11, P_DTAU = 14, P_DTAU_PAR 
               P_PREF = 88, P_DPREF = 112, P_DPN = 136, P_BP1 = 148, P_BP2 = 160, P_BR1 = 172,
               P_BR2 = 184, P_ERB = 196, P_W = 220, P_PHIMAX = 231, P_V1 = 232, P_V2 = 244,
               P_V3 = 256, P_ASET = 275, P_BSET = 455, P_ASETJ = 515, P_BSETJ = 785, NPAR = 875;
+// per-instance block of the staged parameter vectors in LDS (stage_params): the NPAR parameters, then the activity masks of the
+// 15-row halfspace sets (bit rr set: row rr is a constraint; padding rows a = 0, b > 0 are none): six collision-point sets, four EE sets
+constexpr int PL_MASKJ = NPAR, PL_MASKE = NPAR + 6, NPARL = NPAR + 10;
 // LDS copy of the parameter vector: [0,275) verbatim, then a_set_joints (270) and b_set_joints (90);
 // the EE sets a_set/b_set stay in global memory (read by two row slots per stage only)
 constexpr int SP_ASETJ = 275, SP_BSETJ = 545, NSP = 635;

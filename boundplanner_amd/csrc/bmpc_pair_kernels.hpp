@@ -75,8 +75,8 @@ struct InitVisitor {
     BMPC_INL void diag(int s, int, double, double h) { set(s, h); }
     BMPC_INL void zdiag(int s, int, double, double h) { set(s, h); }
     BMPC_INL void pose(int s, const double*, int, double h) { set(s, h); }
-    template <int S0, int CNT> BMPC_INL void group() {}
-    template <int C> BMPC_INL void point_begin() {}
+    template <int S0, int CNT> BMPC_INL void group(unsigned) {}
+    template <int C> BMPC_INL void point_begin(unsigned) {}
     template <int C> BMPC_INL void point(int s, const double*, double h) { set(s, h); }
     template <int C> BMPC_INL void point_end() {}
 };
@@ -242,9 +242,12 @@ struct PointAsm {
         for (int i = 0; i < 7; i++) { gq0[i] = 0; gq1[i] = 0; gqz[i] = 0; }
     }
     BMPC_INL void skip(int) {}
-    template <int C> BMPC_INL void point_begin() {
+    template <int C> BMPC_INL void point_begin(unsigned act) {
         BMPC_UNROLL
-        for (int i = 0; i < 15; i++) { size_t o = (size_t)(S_COL + 15 * C + i) * R->A->NP + R->pi; pt[i] = R->tc[o]; pz[i] = R->zc[o]; }
+        for (int i = 0; i < 15; i++) {       // (row data of constraint rows only)
+            size_t o = (size_t)(S_COL + 15 * C + i) * R->A->NP + R->pi;
+            if ((act >> i) & 1u) { pt[i] = R->tc[o]; pz[i] = R->zc[o]; } else { pt[i] = 1.0; pz[i] = 0.0; }
+        }
         BMPC_UNROLL
         for (int i = 0; i < 6; i++) M3[i] = 0;
         BMPC_UNROLL
@@ -1128,10 +1131,13 @@ struct StepVisitor {
     double gt[ROW_GROUP_MAX], gz[ROW_GROUP_MAX];     // slack t and multiplier z of the current row group, loaded in one batch
     double rp, rdn, rdd, dbar;                        // max(-dt/t), max(-dz/z) as the fraction rdn / rdd (one division per pair
                                                       // instead of one per row), -mu sum dt/t over the rows of this pair
-    template <int S0, int CNT> BMPC_INL void group() {
+    template <int S0, int CNT> BMPC_INL void group(unsigned act) {      // bit i of act: slot S0 + i may be a constraint row (else: not loaded)
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
         BMPC_UNROLL
-        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gz[i] = zc[o]; }
+        for (int i = 0; i < CNT; i++) {
+            size_t o = (size_t)(S0 + i) * A->NP + pi;
+            if ((act >> i) & 1u) { gt[i] = tc[o]; gz[i] = zc[o]; } else { gt[i] = 1.0; gz[i] = 0.0; }
+        }
     }
     BMPC_INL void fin(int s, double h, double adot) {
         // row step: t + dt = c = -h - a.d (stored in A.dt: k_trial subtracts t again), dz_row = (mu - t z - z dt) / t = (mu - z c) / t
@@ -1156,7 +1162,7 @@ struct StepVisitor {
         else if (sel == 3) adot -= dy[Z_D + 5];
         fin(s, h, adot);
     }
-    template <int C> BMPC_INL void point_begin() { group<S_COL + 15 * C, 15>(); }
+    template <int C> BMPC_INL void point_begin(unsigned act) { group<S_COL + 15 * C, 15>(act); }
     template <int C> BMPC_INL void point(int s, const double* a, double h) {
         fin(s, h, a[0] * dpt[C][0] + a[1] * dpt[C][1] + a[2] * dpt[C][2] - dy[Z_D + C]);
     }
@@ -1268,12 +1274,15 @@ struct TrialVisitor {
     double thr;                                       // row part of theta
     double lp; int le;                                // sum log t of the trial point as log of the running product lp * 2^le
                                                       // (mantissa renormalised every row: one log per pair instead of one per row)
-    template <int S0, int CNT> BMPC_INL void group() {
+    template <int S0, int CNT> BMPC_INL void group(unsigned act) {      // bit i of act: slot S0 + i may be a constraint row (else: not loaded)
         static_assert(CNT <= ROW_GROUP_MAX, "row group size");
         // (z is loaded with t and c, one memory round trip per group, also by the later trials of a search, which do not use it)
         double gz[CNT];
         BMPC_UNROLL
-        for (int i = 0; i < CNT; i++) { size_t o = (size_t)(S0 + i) * A->NP + pi; gt[i] = tc[o]; gc[i] = A->dt[o]; gz[i] = zc[o]; }
+        for (int i = 0; i < CNT; i++) {
+            size_t o = (size_t)(S0 + i) * A->NP + pi;
+            if ((act >> i) & 1u) { gt[i] = tc[o]; gc[i] = A->dt[o]; gz[i] = zc[o]; } else { gt[i] = 1.0; gc[i] = 1.0; gz[i] = 0.0; }
+        }
         if (dual) {
             // a slot is live iff z > 0 (inactive slots keep t = 1, z = 0 in both copies from k_init); done here, on the whole
             // group at once, so that no multiplier stays in a register while the group's rows are walked
@@ -1296,7 +1305,7 @@ struct TrialVisitor {
     BMPC_INL void diag(int s, int, double, double h) { fin(s, h); }
     BMPC_INL void zdiag(int s, int, double, double h) { fin(s, h); }
     BMPC_INL void pose(int s, const double*, int, double h) { fin(s, h); }
-    template <int C> BMPC_INL void point_begin() { group<S_COL + 15 * C, 15>(); }
+    template <int C> BMPC_INL void point_begin(unsigned act) { group<S_COL + 15 * C, 15>(act); }
     template <int C> BMPC_INL void point(int s, const double*, double h) { fin(s, h); }
     template <int C> BMPC_INL void point_end() {}
 };
@@ -1313,7 +1322,7 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
     // super-step) -- until each of its instances has an accepted point.  Rounds 1-2 (and trial_repeats = 0) tested in k_accept
     // and gave a rejected instance its next trial one super-step later, after the evaluation and Riccati passes of everybody
     // else.  Scheduling only: an instance sees the same sequence of trials either way.
-    LDSD* ended = lds_par + (size_t)ipw * NPAR;          // [IPW_MAX] 1: the instance's line search has ended (or no such instance)
+    LDSD* ended = lds_par + (size_t)ipw * NPARL;          // [IPW_MAX] 1: the instance's line search has ended (or no such instance)
     if (lane < IPW_MAX) ended[lane] = (lane < ipw && wave * ipw + lane < count) ? 0.0 : 1.0;
     BMPC_SYNC();
     const int flip = A.st[m.b].flip;                     // (flipped by the accepting test: read once, the instance is dead then)
@@ -1324,7 +1333,7 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
         BMPC_OPAQUE_I(b); BMPC_OPAQUE_I(k); BMPC_OPAQUE_I(li);
         const size_t pi = pair_of(A, b, k);
         const bool term = (k == N - 1);
-        PGP pg = lds_par + li * NPAR;
+        PGP pg = lds_par + li * NPARL;
         GCD lbx = A.lbx + (size_t)A.src[b] * n_w;
         GCD ubx = A.ubx + (size_t)A.src[b] * n_w;
         GCD zc = cur_zeta(A, flip);
@@ -1397,8 +1406,8 @@ struct OutVisitor {
     BMPC_INL void diag(int, int, double, double) {}     // box bounds are not part of g / viol
     BMPC_INL void zdiag(int, int, double, double) {}
     BMPC_INL void pose(int s, const double*, int, double h) { rowv(s, h, (s >= S_ROTL && s < S_COL) || (s >= S_TROTL)); }
-    template <int S0, int CNT> BMPC_INL void group() {}
-    template <int C_> BMPC_INL void point_begin() {}
+    template <int S0, int CNT> BMPC_INL void group(unsigned) {}
+    template <int C_> BMPC_INL void point_begin(unsigned) {}
     template <int C_> BMPC_INL void point(int s, const double*, double h) { rowv(s, h, false); }
     template <int C_> BMPC_INL void point_end() {}
 };
@@ -1526,8 +1535,8 @@ struct MultVisitor {
         for (int c = 0; c < 6; c++) bz[c] += z * a[c];
         if (sel == 1) sPS -= z; else if (sel == 2) sRS -= z; else if (sel == 3) sD[5] -= z;
     }
-    template <int S0, int CNT> BMPC_INL void group() {}
-    template <int C> BMPC_INL void point_begin() {}
+    template <int S0, int CNT> BMPC_INL void group(unsigned) {}
+    template <int C> BMPC_INL void point_begin(unsigned) {}
     template <int C> BMPC_INL void point(int s, const double* a, double) {
         const double z = zrow(s);
         lg[s - S_EE] = z;

@@ -204,6 +204,25 @@ BMPC_HD int waves_for(int N, int count) { int ipw = ipw_of(N); return (count + i
 // stage the parameter vectors of this wavefront's instances: lds_par[li][NPAR]; returns the calling
 // lane's copy.  All 64 lanes must call it (contains a barrier).
 // BATCHED: three instances at a time, all loads issued before the first LDS store (the plain loop is kept for A/B runs)
+// activity masks of the halfspace sets of the staged instances (PL_MASKJ, PL_MASKE): computed once per wavefront; the row walkers
+// test a bit instead of four parameters per row, and the visitors load the row data (t, z, c) of constraint rows only -- on
+// BASELINE configs[2] 60 % of the 90 collision-point slots are padding
+BMPC_INL void stage_masks(LDSD* lds_par, int ipw, int wave, int lane, int count) {
+    for (int e = lane; e < ipw * 10; e += 64) {
+        const int li = e / 10, c = e - 10 * li;
+        if (wave * ipw + li < count) {
+            PGP pg = lds_par + li * NPARL;
+            unsigned mk = 0;
+            for (int rr = 0; rr < 15; rr++) {
+                PGP a = c < 6 ? pg + P_ASETJ + 45 * c : pg + P_ASET + 45 * (c - 6);
+                const double bb = c < 6 ? pg[P_BSETJ + rr * 6 + c] + pg[P_SLACKS0 + c] : pg[P_BSET + rr * 4 + (c - 6)];
+                if (!(a[rr] == 0 && a[rr + 15] == 0 && a[rr + 30] == 0 && bb > 0)) mk |= 1u << rr;
+            }
+            lds_par[li * NPARL + NPAR + c] = (double)mk;
+        }
+    }
+    BMPC_SYNC();
+}
 template <bool BATCHED = true>
 BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int lane, const PairMap& m, LDSD* lds_par) {
     const int ipw = ipw_of(A.N);
@@ -212,11 +231,12 @@ BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int 
             const int e = wave * ipw + li;
             if (e < count) {
                 GCD src = A.p + (size_t)A.src[list ? list[e] : e] * NPAR;
-                for (int i = lane; i < NPAR; i += 64) lds_par[li * NPAR + i] = src[i];
+                for (int i = lane; i < NPAR; i += 64) lds_par[li * NPARL + i] = src[i];
             }
         }
         BMPC_SYNC();
-        return lds_par + m.li * NPAR;
+        stage_masks(lds_par, ipw, wave, lane, count);
+        return lds_par + m.li * NPARL;
     }
     // three instances at a time: all their loads are issued before the first LDS store (one memory round trip per chunk)
     constexpr int NJ = (NPAR + 63) / 64;
@@ -235,13 +255,14 @@ BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int 
             const int li = l0 + c, e = wave * ipw + li;
             if (li < ipw && e < count)
                 BMPC_UNROLL
-                for (int j = 0; j < NJ; j++) { const int i = lane + 64 * j; if (i < NPAR) lds_par[li * NPAR + i] = v[c][j]; }
+                for (int j = 0; j < NJ; j++) { const int i = lane + 64 * j; if (i < NPAR) lds_par[li * NPARL + i] = v[c][j]; }
         }
     }
     BMPC_SYNC();
-    return lds_par + m.li * NPAR;
+    stage_masks(lds_par, ipw, wave, lane, count);
+    return lds_par + m.li * NPARL;
 }
-BMPC_HD size_t pair_lds_doubles(int N, bool with_tile) { return (size_t)ipw_of(N) * NPAR + (with_tile ? EM_DOUBLES_C + 8 : 0); }
+BMPC_HD size_t pair_lds_doubles(int N, bool with_tile) { return (size_t)ipw_of(N) * NPARL + (with_tile ? EM_DOUBLES_C + 8 : 0); }
 
 // ------------------------------------------------------------------------------------------
 // coalesced AoS output of per-thread records: 16 fields at a time through an LDS tile

@@ -406,16 +406,18 @@ constexpr int ROW_GROUP_MAX = 28;
 template <class V, int C0>
 BMPC_INL void walk_points(PGP pg, const KinT& K, const SegCtx& C, V& v) {
     if constexpr (C0 < 6) {
-        v.template point_begin<C0>();
+        // (row rr is a constraint unless a == 0 and b + slacks0 > 0: bit rr of the set's activity mask, stage_masks)
+        const unsigned act = (unsigned)pg[PL_MASKJ + C0];
+        v.template point_begin<C0>(act);
         PGP a = pg + P_ASETJ + 45 * C0;
         const double* pc = kin_point<C0>(K);
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
-            double a3[3] = {a[rr], a[rr + 15], a[rr + 30]};
-            double bb = pg[P_BSETJ + rr * 6 + C0];
-            if (!(a3[0] == 0 && a3[1] == 0 && a3[2] == 0 && bb + pg[P_SLACKS0 + C0] > 0))
+            if ((act >> rr) & 1u) {
+                double a3[3] = {a[rr], a[rr + 15], a[rr + 30]};
+                double bb = pg[P_BSETJ + rr * 6 + C0];
                 v.template point<C0>(S_COL + 15 * C0 + rr, a3, a3[0] * pc[0] + a3[1] * pc[1] + a3[2] * pc[2] - bb - C.sl[C0]);
-            else v.skip(S_COL + 15 * C0 + rr);
+            } else v.skip(S_COL + 15 * C0 + rr);
         }
         v.template point_end<C0>();
         walk_points<V, C0 + 1>(pg, K, C, v);
@@ -431,7 +433,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
     // cost one memory round trip each (the thread-per-pair kernels run one wavefront per SIMD: nothing hides it)
     BMPC_UNROLL
     for (int half = 0; half < 2; half++) {
-        if (half == 0) v.template group<0, 28>(); else v.template group<28, 28>();
+        if (half == 0) v.template group<0, 28>(~0u); else v.template group<28, 28>(~0u);
         double ubv[14], lbv[14];
         BMPC_UNROLL
         for (int i = 0; i < 14; i++) {
@@ -450,7 +452,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         }
     }
     // rs, drs, ps, dps >= 0 (Q6)
-    v.template group<S_NONNEG, S_EE - S_NONNEG>();
+    v.template group<S_NONNEG, S_EE - S_NONNEG>(k == 1 ? ~0u : 0xfu);         // (the eight slots from S_RS1 on exist at stage 1 only)
     v.diag(S_NONNEG + 0, Z_RS, -1.0, -y[Z_RS]);
     v.diag(S_NONNEG + 1, Z_DRS, -1.0, -y[Z_DRS]);
     v.diag(S_NONNEG + 2, Z_PS, -1.0, -y[Z_PS]);
@@ -465,13 +467,14 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         for (int i = 0; i < 8; i++) v.skip(S_RS1 + i);
     }
     // EE in current set (ocp :304)
-    v.template group<S_EE, S_COL - S_EE>();
     {
+        const unsigned act = (unsigned)pg[PL_MASKE + C.s];
+        v.template group<S_EE, S_COL - S_EE>(act | ~0x7fffu);
         PGP a = pg + P_ASET + 45 * C.s;
         BMPC_UNROLL
         for (int rr = 0; rr < 15; rr++) {
-            double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = pg[P_BSET + rr * 4 + C.s];
-            if (!(a0 == 0 && a1 == 0 && a2 == 0 && bb > 0)) {
+            if ((act >> rr) & 1u) {
+                double a0 = a[rr], a1 = a[rr + 15], a2 = a[rr + 30], bb = pg[P_BSET + rr * 4 + C.s];
                 double a6[6] = {a0, a1, a2, 0, 0, 0};
                 v.pose(S_EE + rr, a6, 1, a0 * C.pose[0] + a1 * C.pose[1] + a2 * C.pose[2] - bb - y[Z_PS]);
             } else v.skip(S_EE + rr);
@@ -489,7 +492,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
     // collision points (ocp :323-330)
     walk_points<V, 0>(pg, K, C, v);
     // phi cap (ocp :332)
-    if (term) v.template group<S_PHI, S_END - S_PHI>(); else v.template group<S_PHI, 1>();      // (the 21 terminal slots exist at the last stage only)
+    if (term) v.template group<S_PHI, S_END - S_PHI>(~0u); else v.template group<S_PHI, 1>(~0u);      // (the 21 terminal slots exist at the last stage only)
     {
         double a6[6] = {C.dpp[0], C.dpp[1], C.dpp[2], 0, 0, 0};
         v.pose(S_PHI, a6, 0, C.phi - (C.phiend + 0.005));
