@@ -956,7 +956,7 @@ BMPC_KBODY void k_points_body(const PipeArgs& A, int wave, int lane, LDSD* lds_p
     PointAsm PA;
     PA.R = &R; PA.K = &K;
     PA.init();
-    walk_points<PointAsm, 0>(pg, K, C, PA);
+    walk_points<PointAsm, 0>(pg, K, C.sl, PA);
     if (!m.valid) return;
     GD Sd = A.part + (size_t)PT_SIDE * A.NP + m.pi;
     BMPC_UNROLL
@@ -1310,50 +1310,44 @@ struct TrialVisitor {
     template <int C> BMPC_INL void point_end() {}
 };
 
-BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) {
-    const int count = A.L.cnt[2], N = A.N;
-    if (wave * ipw_of(N) >= count) return;
-    const PairMap m = pair_map(A, A.L.trial, count, wave, lane);
-    const int n_w = 44 * N + 6, ipw = ipw_of(N);
+// One part (ROLES: stage.hpp WR_*) of the trial point of pair (b, k): trial slacks, multiplier update, the part's share of theta and of
+// sum log t; WR_POSE also writes the trial zeta and adds the dynamics defect and the objective.
+struct TrialPart { double f, th, thr, lp; int le; };
+template <int ROLES>
+BMPC_INL void trial_part(const PipeArgs& A, PGP pg, int b, int k, size_t pi, bool live, bool dual, double alpha, int flip, TrialPart& R) {
+    const int N = A.N, n_w = 44 * N + 6;
+    const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
-    (void)stage_params(A, A.L.trial, count, wave, lane, m, lds_par);
-    // The pairs of an instance are lanes of this wavefront, so the filter test of a trial point needs nobody else: the
-    // wavefront backtracks by itself -- trial, test, half the step length, again (at most 1 + trial_repeats trials per
-    // super-step) -- until each of its instances has an accepted point.  Rounds 1-2 (and trial_repeats = 0) tested in k_accept
-    // and gave a rejected instance its next trial one super-step later, after the evaluation and Riccati passes of everybody
-    // else.  Scheduling only: an instance sees the same sequence of trials either way.
-    LDSD* ended = lds_par + (size_t)ipw * NPARL;          // [IPW_MAX] 1: the instance's line search has ended (or no such instance)
-    if (lane < IPW_MAX) ended[lane] = (lane < ipw && wave * ipw + lane < count) ? 0.0 : 1.0;
-    BMPC_SYNC();
-    const int flip = A.st[m.b].flip;                     // (flipped by the accepting test: read once, the instance is dead then)
-    for (int round = 0;; round++) {
-        // the lane's coordinates pass through an opaque copy every round: everything below is recomputed from them, so the
-        // compiler cannot hoist the (hundreds of) round-invariant parameter loads out of the loop into registers it does not have
-        int b = m.b, k = m.k, li = m.li;
-        BMPC_OPAQUE_I(b); BMPC_OPAQUE_I(k); BMPC_OPAQUE_I(li);
-        const size_t pi = pair_of(A, b, k);
-        const bool term = (k == N - 1);
-        PGP pg = lds_par + li * NPARL;
-        GCD lbx = A.lbx + (size_t)A.src[b] * n_w;
-        GCD ubx = A.ubx + (size_t)A.src[b] * n_w;
-        GCD zc = cur_zeta(A, flip);
+    GCD lbx = A.lbx + (size_t)A.src[b] * n_w;
+    GCD ubx = A.ubx + (size_t)A.src[b] * n_w;
+    GCD zc = cur_zeta(A, flip);
+    StagePoint S;
+    BMPC_UNROLL
+    for (int i = 0; i < NZ; i++) S.zeta[i] = zc[(size_t)i * A.NP + pi] + alpha * A.dz[(size_t)i * A.NP + pi];
+    if constexpr ((ROLES & WR_POSE) != 0) {
         GD zo = oth_zeta(A, flip);
-        double iw0[3];
-        BMPC_UNROLL
-        for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
-        const bool live = m.valid && ended[li] == 0.0;
-        const double alpha = live ? A.st[b].alpha : 0.0;
-        StagePoint S;
-        BMPC_UNROLL
-        for (int i = 0; i < NZ; i++) S.zeta[i] = zc[(size_t)i * A.NP + pi] + alpha * A.dz[(size_t)i * A.NP + pi];
         if (live)
             BMPC_UNROLL
             for (int i = 0; i < NZ; i++) zo[(size_t)i * A.NP + pi] = S.zeta[i];
-        stage_point(A, pg, iw0, k, dc, S);
-        TrialVisitor V;
-        V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
-        V.dual = live && round == 0; V.ad = A.st[b].ad; V.mu = A.st[b].mu; V.zc = cur_z(A, flip); V.zn_out = oth_z(A, flip);
-        walk_rows(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    }
+    nat_all(S.zeta, dc, S.y);
+    if constexpr ((ROLES & (WR_POSE | WR_PT0 | WR_PT1)) != 0) kin_chain(A.rc, S.y + Z_Q, S.K);
+    if constexpr ((ROLES & WR_POSE) != 0) {
+        double iw0[3];
+        BMPC_UNROLL
+        for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
+        kin_jlin(S.K, S.Jl);
+        kin_vel(S.K, S.Jl, S.y + Z_DQ, S.C.v);
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) { S.C.pose[a] = S.K.pee[a]; S.C.pose[3 + a] = S.y[Z_PI + a] + 0.5 * dc.dt * S.C.v[3 + a]; }
+        seg_ctx_eval(pg, A.N, k, S.y, iw0, S.C);          // (= stage_point)
+    }
+    TrialVisitor V;
+    V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
+    V.dual = dual; V.ad = A.st[b].ad; V.mu = A.st[b].mu; V.zc = cur_z(A, flip); V.zn_out = oth_z(A, flip);
+    walk_rows<TrialVisitor, ROLES>(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    R.thr = V.thr; R.lp = V.lp; R.le = V.le; R.th = 0.0; R.f = 0.0;
+    if constexpr ((ROLES & WR_POSE) != 0) {
         double th = 0;     // dynamics / initial-state part of theta
         if (!term) {
             double zn[NX], rdef[NX];
@@ -1369,20 +1363,86 @@ BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_pa
             BMPC_UNROLL
             for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
         }
-        if (live) {
+        R.th = th; R.f = S.C.fv;
+    }
+}
+
+// NW = 1: one wavefront per group of pairs walks all rows (rounds 1-4).  NW = 4 (round 4): a workgroup of four wavefronts per group
+// of pairs, each wavefront one part of the walk -- pose rows + defect + objective / box rows / collision points 0-2 / 3-5.  No
+// wavefront holds the natural coordinates, the reference context AND the point positions: the parts fit half the register file (two
+// workgroups per CU instead of one wavefront per SIMD that spills), and a pair's dependent memory round trips -- one per row group --
+// run side by side in the four wavefronts instead of one after the other.  tid = thread index in the workgroup.
+template <int NW>
+BMPC_KBODY void k_trial_body_t(const PipeArgs& A, int wave, int tid, LDSD* lds_par) {
+    static_assert(NW == 1 || NW == 4, "parts of the trial walk");
+    const int count = A.L.cnt[2], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    const int lane = tid & 63, role = tid >> 6;
+    const PairMap m = pair_map(A, A.L.trial, count, wave, lane);
+    const int ipw = ipw_of(N);
+    (void)stage_params<true, 64 * NW>(A, A.L.trial, count, wave, tid, m, lds_par);
+    // The pairs of an instance are lanes of this wavefront, so the filter test of a trial point needs nobody else: the
+    // wavefront backtracks by itself -- trial, test, half the step length, again (at most 1 + trial_repeats trials per
+    // super-step) -- until each of its instances has an accepted point.  Rounds 1-2 (and trial_repeats = 0) tested in k_accept
+    // and gave a rejected instance its next trial one super-step later, after the evaluation and Riccati passes of everybody
+    // else.  Scheduling only: an instance sees the same sequence of trials either way.
+    LDSD* ended = lds_par + (size_t)ipw * NPARL;         // [IPW_MAX] 1: the instance's line search has ended (or no such instance)
+    LDSD* comb = ended + IPW_MAX;                        // NW == 4: [part][lane][TRIAL_COMB] partial results of the parts
+    if (tid < IPW_MAX) ended[tid] = (tid < ipw && wave * ipw + tid < count) ? 0.0 : 1.0;
+    BMPC_SYNC();
+    const int flip = A.st[m.b].flip;                     // (flipped by the accepting test: read once, the instance is dead then)
+    for (int round = 0;; round++) {
+        // the lane's coordinates pass through an opaque copy every round: everything below is recomputed from them, so the
+        // compiler cannot hoist the (hundreds of) round-invariant parameter loads out of the loop into registers it does not have
+        int b = m.b, k = m.k, li = m.li;
+        BMPC_OPAQUE_I(b); BMPC_OPAQUE_I(k); BMPC_OPAQUE_I(li);
+        const size_t pi = pair_of(A, b, k);
+        PGP pg = lds_par + li * NPARL;
+        const bool live = m.valid && ended[li] == 0.0;
+        const double alpha = live ? A.st[b].alpha : 0.0;
+        TrialPart R;
+        if constexpr (NW == 1) trial_part<WR_ALL>(A, pg, b, k, pi, live, live && round == 0, alpha, flip, R);
+        else {
+            TrialPart Q;
+#ifdef BMPC_TRIAL_ONLY      // (register-need experiments: one part only)
+            Q.thr = 0; Q.lp = 1; Q.le = 0; Q.th = 0; Q.f = 0;
+            if (role == 0) trial_part<BMPC_TRIAL_ONLY>(A, pg, b, k, pi, live, live && round == 0, alpha, flip, Q);
+#else
+            if (role == 0) trial_part<WR_POSE>(A, pg, b, k, pi, live, live && round == 0, alpha, flip, Q);
+            else if (role == 1) trial_part<WR_BOX>(A, pg, b, k, pi, live, live && round == 0, alpha, flip, Q);
+            else if (role == 2) trial_part<WR_PT0>(A, pg, b, k, pi, live, live && round == 0, alpha, flip, Q);
+            else trial_part<WR_PT1>(A, pg, b, k, pi, live, live && round == 0, alpha, flip, Q);
+#endif
+            LDSD* c = comb + (size_t)(role * 64 + lane) * TRIAL_COMB;
+            c[0] = Q.thr; c[1] = Q.lp; c[2] = (double)Q.le;
+            if (role == 0) { c[3] = Q.th; c[4] = Q.f; }
+            BMPC_SYNC();
+            // the parts' shares in part order (fixed: the result does not depend on which wavefront finished first)
+            R.thr = 0.0; R.lp = 1.0; R.le = 0;
+            if (role == 0) {
+                BMPC_UNROLL
+                for (int r = 0; r < NW; r++) {
+                    const LDSD* cr = comb + (size_t)(r * 64 + lane) * TRIAL_COMB;
+                    R.thr += cr[0]; R.lp *= cr[1]; R.le += (int)cr[2];
+                }
+                R.th = c[3]; R.f = c[4];
+            }
+        }
+        if (live && role == 0) {
             GD P = A.part + pi;
-            P[PT_F1 * A.NP] = S.C.fv; P[PT_TH1 * A.NP] = th + V.thr;
-            P[PT_LS1 * A.NP] = log(V.lp) + (double)V.le * 0.69314718055994530942;
+            P[PT_F1 * A.NP] = R.f; P[PT_TH1 * A.NP] = R.th + R.thr;
+            P[PT_LS1 * A.NP] = log(R.lp) + (double)R.le * 0.69314718055994530942;
         }
         const bool last = round >= A.o.trial_repeats;
         BMPC_FENCE_SYNC();
-        if (live && k == 1 && (ls_instance(A, b, last) || last)) ended[li] = 1.0;
+        if (live && role == 0 && k == 1 && (ls_instance(A, b, last) || last)) ended[li] = 1.0;
         BMPC_FENCE_SYNC();
         bool left = false;
         for (int q = 0; q < ipw; q++) left = left || (ended[q] == 0.0);
         if (!left) break;
     }
 }
+BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) { k_trial_body_t<1>(A, wave, lane, lds_par); }
 
 // ------------------------------------------------------------------------------------------
 // k_out: x in the reference layout, constraint vector g, violation partials

@@ -17,8 +17,11 @@ using namespace bmpc;
 #ifndef BMPC_EVAL_WPS
 #define BMPC_EVAL_WPS BMPC_PAIR_WPS
 #endif
+#ifndef BMPC_TRIAL_NW
+#define BMPC_TRIAL_NW 1      // wavefronts per group of pairs in k_trial: 1 = one walks all rows, 4 = one part of the walk each (measured, not kept: EXPERIMENTS.md)
+#endif
 #ifndef BMPC_TRIAL_WPS
-#define BMPC_TRIAL_WPS BMPC_PAIR_WPS
+#define BMPC_TRIAL_WPS (BMPC_TRIAL_NW == 4 ? 2 : BMPC_PAIR_WPS)
 #endif
 #ifndef BMPC_STEP_WPS
 #define BMPC_STEP_WPS BMPC_PAIR_WPS
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(64, BMPC_STEP_WPS) void bmpc_k_step(PipeArgsH H) { 
 __global__ __launch_bounds__(64) void bmpc_k_init_fin(PipeArgsH H) { k_init_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64) void bmpc_k_admit(PipeArgsH H) { k_admit_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ void bmpc_k_pool_reset(PipeArgsH H, int done_too) { if (threadIdx.x == 0 && blockIdx.x == 0) k_pool_reset_body(DV(H), done_too != 0); }
-__global__ __launch_bounds__(64, BMPC_TRIAL_WPS) void bmpc_k_trial(PipeArgsH H) { k_trial_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64 * BMPC_TRIAL_NW, BMPC_TRIAL_WPS) void bmpc_k_trial(PipeArgsH H) {
+    k_trial_body_t<BMPC_TRIAL_NW>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+}
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_mult(PipeArgsH H) { k_mult_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
@@ -158,7 +163,7 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     // (BMPC_TRIAL_REPEATS in the environment, read once, overrides bmpc_opts.trial_repeats: A/B runs)
     static const int env_repeats = [] { const char* e = getenv("BMPC_TRIAL_REPEATS"); return e ? atoi(e) : -1; }();
     if (env_repeats >= 0) A->o.trial_repeats = env_repeats;
-    LAUNCH_DYN(bmpc_k_trial, nw, 64, pair_lds_doubles(A->N, false) + IPW_MAX);      // trial points (+ multiplier update) + filter test, backtracking inside
+    LAUNCH_DYN(bmpc_k_trial, nw, 64 * BMPC_TRIAL_NW, trial_lds_doubles(A->N, BMPC_TRIAL_NW));      // trial points (+ multiplier update) + filter test, backtracking inside
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
     t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;

@@ -207,8 +207,9 @@ BMPC_HD int waves_for(int N, int count) { int ipw = ipw_of(N); return (count + i
 // activity masks of the halfspace sets of the staged instances (PL_MASKJ, PL_MASKE): computed once per wavefront; the row walkers
 // test a bit instead of four parameters per row, and the visitors load the row data (t, z, c) of constraint rows only -- on
 // BASELINE configs[2] 60 % of the 90 collision-point slots are padding
+template <int NTHR = 64>
 BMPC_INL void stage_masks(LDSD* lds_par, int ipw, int wave, int lane, int count) {
-    for (int e = lane; e < ipw * 10; e += 64) {
+    for (int e = lane; e < ipw * 10; e += NTHR) {
         const int li = e / 10, c = e - 10 * li;
         if (wave * ipw + li < count) {
             PGP pg = lds_par + li * NPARL;
@@ -223,7 +224,8 @@ BMPC_INL void stage_masks(LDSD* lds_par, int ipw, int wave, int lane, int count)
     }
     BMPC_SYNC();
 }
-template <bool BATCHED = true>
+// NTHR: threads of the workgroup (all of them must call it; `lane` = thread index in the workgroup)
+template <bool BATCHED = true, int NTHR = 64>
 BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int lane, const PairMap& m, LDSD* lds_par) {
     const int ipw = ipw_of(A.N);
     if constexpr (!BATCHED) {
@@ -231,15 +233,15 @@ BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int 
             const int e = wave * ipw + li;
             if (e < count) {
                 GCD src = A.p + (size_t)A.src[list ? list[e] : e] * NPAR;
-                for (int i = lane; i < NPAR; i += 64) lds_par[li * NPARL + i] = src[i];
+                for (int i = lane; i < NPAR; i += NTHR) lds_par[li * NPARL + i] = src[i];
             }
         }
         BMPC_SYNC();
-        stage_masks(lds_par, ipw, wave, lane, count);
+        stage_masks<NTHR>(lds_par, ipw, wave, lane, count);
         return lds_par + m.li * NPARL;
     }
     // three instances at a time: all their loads are issued before the first LDS store (one memory round trip per chunk)
-    constexpr int NJ = (NPAR + 63) / 64;
+    constexpr int NJ = (NPAR + NTHR - 1) / NTHR;
     for (int l0 = 0; l0 < ipw; l0 += 3) {
         double v[3][NJ];
         BMPC_UNROLL
@@ -248,20 +250,22 @@ BMPC_INL PGP stage_params(const PipeArgs& A, GCI list, int count, int wave, int 
             const bool on = li < ipw && e < count;
             GCD src = A.p + (size_t)A.src[on ? (list ? list[e] : e) : (list ? list[wave * ipw] : wave * ipw)] * NPAR;
             BMPC_UNROLL
-            for (int j = 0; j < NJ; j++) { const int i = lane + 64 * j; v[c][j] = (i < NPAR) ? src[i] : 0.0; }
+            for (int j = 0; j < NJ; j++) { const int i = lane + NTHR * j; v[c][j] = (i < NPAR) ? src[i] : 0.0; }
         }
         BMPC_UNROLL
         for (int c = 0; c < 3; c++) {
             const int li = l0 + c, e = wave * ipw + li;
             if (li < ipw && e < count)
                 BMPC_UNROLL
-                for (int j = 0; j < NJ; j++) { const int i = lane + 64 * j; if (i < NPAR) lds_par[li * NPARL + i] = v[c][j]; }
+                for (int j = 0; j < NJ; j++) { const int i = lane + NTHR * j; if (i < NPAR) lds_par[li * NPARL + i] = v[c][j]; }
         }
     }
     BMPC_SYNC();
-    stage_masks(lds_par, ipw, wave, lane, count);
+    stage_masks<NTHR>(lds_par, ipw, wave, lane, count);
     return lds_par + m.li * NPARL;
 }
+constexpr int TRIAL_COMB = 5;      // partial results of one part of a trial point (k_trial with four wavefronts per group of pairs)
+BMPC_HD size_t trial_lds_doubles(int N, int nw) { return (size_t)ipw_of(N) * NPARL + IPW_MAX + (nw > 1 ? (size_t)nw * 64 * TRIAL_COMB : 0); }
 BMPC_HD size_t pair_lds_doubles(int N, bool with_tile) { return (size_t)ipw_of(N) * NPARL + (with_tile ? EM_DOUBLES_C + 8 : 0); }
 
 // ------------------------------------------------------------------------------------------

@@ -403,9 +403,9 @@ BMPC_HD constexpr int row_group_base(int s) {
 }
 constexpr int ROW_GROUP_MAX = 28;
 
-template <class V, int C0>
-BMPC_INL void walk_points(PGP pg, const KinT& K, const SegCtx& C, V& v) {
-    if constexpr (C0 < 6) {
+template <class V, int C0, int CEND = 6>
+BMPC_INL void walk_points(PGP pg, const KinT& K, const double* sl, V& v) {
+    if constexpr (C0 < CEND) {
         // (row rr is a constraint unless a == 0 and b + slacks0 > 0: bit rr of the set's activity mask, stage_masks)
         const unsigned act = (unsigned)pg[PL_MASKJ + C0];
         v.template point_begin<C0>(act);
@@ -416,18 +416,22 @@ BMPC_INL void walk_points(PGP pg, const KinT& K, const SegCtx& C, V& v) {
             if ((act >> rr) & 1u) {
                 double a3[3] = {a[rr], a[rr + 15], a[rr + 30]};
                 double bb = pg[P_BSETJ + rr * 6 + C0];
-                v.template point<C0>(S_COL + 15 * C0 + rr, a3, a3[0] * pc[0] + a3[1] * pc[1] + a3[2] * pc[2] - bb - C.sl[C0]);
+                v.template point<C0>(S_COL + 15 * C0 + rr, a3, a3[0] * pc[0] + a3[1] * pc[1] + a3[2] * pc[2] - bb - sl[C0]);
             } else v.skip(S_COL + 15 * C0 + rr);
         }
         v.template point_end<C0>();
-        walk_points<V, C0 + 1>(pg, K, C, v);
+        walk_points<V, C0 + 1, CEND>(pg, K, sl, v);
     }
 }
 
-template <class V>
+// ROLES: which parts of the walk run (the wave-specialised kernels give each wavefront of a workgroup one part: the parts need
+// different inputs -- natural coordinates only / reference context / collision-point positions -- so no wavefront holds them all)
+constexpr int WR_BOX = 1, WR_POSE = 2, WR_PT0 = 4, WR_PT1 = 8, WR_ALL = 15;
+template <class V, int ROLES = WR_ALL>
 BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
                         const double* zeta, const KinT& K, const SegCtx& C, V& v) {
     const bool term = (k == N - 1);
+  if constexpr ((ROLES & WR_BOX) != 0) {
     // box bounds on q, dq, ddq, u (BoundMPC.py:171-186, 544-589)
     // the bounds of 14 positions are loaded in one batch: the walk is conditional, so loads issued where they are used
     // cost one memory round trip each (the thread-per-pair kernels run one wavefront per SIMD: nothing hides it)
@@ -466,6 +470,8 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         BMPC_UNROLL
         for (int i = 0; i < 8; i++) v.skip(S_RS1 + i);
     }
+  }
+  if constexpr ((ROLES & WR_POSE) != 0) {
     // EE in current set (ocp :304)
     {
         const unsigned act = (unsigned)pg[PL_MASKE + C.s];
@@ -489,8 +495,16 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         v.pose(S_ROTU + m, au, 2, C.proj[m] - C.ub[m] - y[Z_RS]);
         v.pose(S_ROTL + m, al, 2, -(C.proj[m] - C.lb[m] + y[Z_RS]));
     }
+  }
     // collision points (ocp :323-330)
-    walk_points<V, 0>(pg, K, C, v);
+    if constexpr ((ROLES & WR_PT0) != 0 || (ROLES & WR_PT1) != 0) {
+        double sl[6];
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) sl[i] = pg[P_SLACKS0 + i] + y[Z_D + i];        // (= C.sl, seg_ctx_eval)
+        if constexpr ((ROLES & WR_PT0) != 0) walk_points<V, 0, 3>(pg, K, sl, v);
+        if constexpr ((ROLES & WR_PT1) != 0) walk_points<V, 3, 6>(pg, K, sl, v);
+    }
+  if constexpr ((ROLES & WR_POSE) != 0) {
     // phi cap (ocp :332)
     if (term) v.template group<S_PHI, S_END - S_PHI>(~0u); else v.template group<S_PHI, 1>(~0u);      // (the 21 terminal slots exist at the last stage only)
     {
@@ -529,6 +543,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         BMPC_UNROLL
         for (int i = 0; i < 21; i++) v.skip(S_TSET + i);
     }
+  }
 }
 
 }  // namespace bmpc
