@@ -1331,24 +1331,24 @@ BMPC_INL void trial_part(const PipeArgs& A, PGP pg, int b, int k, size_t pi, boo
             for (int i = 0; i < NZ; i++) zo[(size_t)i * A.NP + pi] = S.zeta[i];
     }
     nat_all(S.zeta, dc, S.y);
+    TrialVisitor V;
+    V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
+    V.dual = dual; V.ad = A.st[b].ad; V.mu = A.st[b].mu; V.zc = cur_z(A, flip); V.zn_out = oth_z(A, flip);
+    // The walk in three phases, each with its own inputs: the box rows need the natural coordinates only and run BEFORE kinematics
+    // and reference context exist; the pose rows need the context; the collision points need the joint origins only.  (One walk
+    // over everything kept coordinates, context and kinematics alive through all row groups: the kernel's spills.)
+    if constexpr ((ROLES & WR_BOX) != 0) walk_rows<TrialVisitor, WR_BOX>(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    BMPC_SCHED_FENCE();
     if constexpr ((ROLES & (WR_POSE | WR_PT0 | WR_PT1)) != 0) kin_chain(A.rc, S.y + Z_Q, S.K);
+    R.th = 0.0; R.f = 0.0;
     if constexpr ((ROLES & WR_POSE) != 0) {
         double iw0[3];
         BMPC_UNROLL
         for (int c = 0; c < 3; c++) iw0[c] = lbx[28 * N + (3 + c) * N];
         kin_jlin(S.K, S.Jl);
         kin_vel(S.K, S.Jl, S.y + Z_DQ, S.C.v);
-        BMPC_UNROLL
-        for (int a = 0; a < 3; a++) { S.C.pose[a] = S.K.pee[a]; S.C.pose[3 + a] = S.y[Z_PI + a] + 0.5 * dc.dt * S.C.v[3 + a]; }
-        seg_ctx_eval(pg, A.N, k, S.y, iw0, S.C);          // (= stage_point)
-    }
-    TrialVisitor V;
-    V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
-    V.dual = dual; V.ad = A.st[b].ad; V.mu = A.st[b].mu; V.zc = cur_z(A, flip); V.zn_out = oth_z(A, flip);
-    walk_rows<TrialVisitor, ROLES>(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
-    R.thr = V.thr; R.lp = V.lp; R.le = V.le; R.th = 0.0; R.f = 0.0;
-    if constexpr ((ROLES & WR_POSE) != 0) {
-        double th = 0;     // dynamics / initial-state part of theta
+        // dynamics / initial-state part of theta: here, before the reference context, so that zeta is dead while that is alive
+        double th = 0;
         if (!term) {
             double zn[NX], rdef[NX];
             BMPC_UNROLL
@@ -1363,8 +1363,16 @@ BMPC_INL void trial_part(const PipeArgs& A, PGP pg, int b, int k, size_t pi, boo
             BMPC_UNROLL
             for (int i = 0; i < 24; i++) th += fabs(x1fix[i] - S.zeta[i]);
         }
+        BMPC_SCHED_FENCE();
+        BMPC_UNROLL
+        for (int a = 0; a < 3; a++) { S.C.pose[a] = S.K.pee[a]; S.C.pose[3 + a] = S.y[Z_PI + a] + 0.5 * dc.dt * S.C.v[3 + a]; }
+        seg_ctx_eval(pg, A.N, k, S.y, iw0, S.C);          // (= stage_point)
+        walk_rows<TrialVisitor, WR_POSE>(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
         R.th = th; R.f = S.C.fv;
     }
+    BMPC_SCHED_FENCE();
+    if constexpr ((ROLES & (WR_PT0 | WR_PT1)) != 0) walk_rows<TrialVisitor, ROLES & (WR_PT0 | WR_PT1)>(pg, lbx, ubx, N, k, S.y, S.zeta, S.K, S.C, V);
+    R.thr = V.thr; R.lp = V.lp; R.le = V.le;
 }
 
 // NW = 1: one wavefront per group of pairs walks all rows (rounds 1-4).  NW = 4 (round 4): a workgroup of four wavefronts per group

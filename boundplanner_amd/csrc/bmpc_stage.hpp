@@ -495,16 +495,7 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         v.pose(S_ROTU + m, au, 2, C.proj[m] - C.ub[m] - y[Z_RS]);
         v.pose(S_ROTL + m, al, 2, -(C.proj[m] - C.lb[m] + y[Z_RS]));
     }
-  }
-    // collision points (ocp :323-330)
-    if constexpr ((ROLES & WR_PT0) != 0 || (ROLES & WR_PT1) != 0) {
-        double sl[6];
-        BMPC_UNROLL
-        for (int i = 0; i < 6; i++) sl[i] = pg[P_SLACKS0 + i] + y[Z_D + i];        // (= C.sl, seg_ctx_eval)
-        if constexpr ((ROLES & WR_PT0) != 0) walk_points<V, 0, 3>(pg, K, sl, v);
-        if constexpr ((ROLES & WR_PT1) != 0) walk_points<V, 3, 6>(pg, K, sl, v);
-    }
-  if constexpr ((ROLES & WR_POSE) != 0) {
+    // (the pose rows of the walk come first, the collision points last: the reference context is dead by then)
     // phi cap (ocp :332)
     if (term) v.template group<S_PHI, S_END - S_PHI>(~0u); else v.template group<S_PHI, 1>(~0u);      // (the 21 terminal slots exist at the last stage only)
     {
@@ -544,6 +535,14 @@ BMPC_INL void walk_rows(PGP pg, GCD lbx, GCD ubx, int N, int k, const double* y,
         for (int i = 0; i < 21; i++) v.skip(S_TSET + i);
     }
   }
+    // collision points (ocp :323-330)
+    if constexpr ((ROLES & WR_PT0) != 0 || (ROLES & WR_PT1) != 0) {
+        double sl[6];
+        BMPC_UNROLL
+        for (int i = 0; i < 6; i++) sl[i] = pg[P_SLACKS0 + i] + y[Z_D + i];        // (= C.sl, seg_ctx_eval)
+        if constexpr ((ROLES & WR_PT0) != 0) walk_points<V, 0, 3>(pg, K, sl, v);
+        if constexpr ((ROLES & WR_PT1) != 0) walk_points<V, 3, 6>(pg, K, sl, v);
+    }
 }
 
 }  // namespace bmpc
