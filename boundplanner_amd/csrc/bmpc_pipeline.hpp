@@ -206,7 +206,7 @@ BMPC_HD int waves_for(int N, int count) { int ipw = ipw_of(N); return (count + i
 // BATCHED: three instances at a time, all loads issued before the first LDS store (the plain loop is kept for A/B runs)
 // activity masks of the halfspace sets of the staged instances (PL_MASKJ, PL_MASKE): computed once per wavefront; the row walkers
 // test a bit instead of four parameters per row, and the visitors load the row data (t, z, c) of constraint rows only -- on
-// BASELINE configs[2] 60 % of the 90 collision-point slots are padding
+// BASELINE configs[2] a fifth of the 90 collision-point slots is padding (12 of 15 rows per set on average)
 template <int NTHR = 64>
 BMPC_INL void stage_masks(LDSD* lds_par, int ipw, int wave, int lane, int count) {
     for (int e = lane; e < ipw * 10; e += NTHR) {
