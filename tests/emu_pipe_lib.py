@@ -13,19 +13,27 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 
 
-def build(force=False):
+def build(force=False, lib=LIB, defs=()):
     cs = os.path.join(ROOT, "boundplanner_amd", "csrc")
     deps = [SRC] + [os.path.join(cs, f) for f in os.listdir(cs) if f.endswith(".hpp")]
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call(["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas",
-                               "-o", LIB, SRC])
+    if force or not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.check_call(["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", *defs,
+                               "-o", lib, SRC])
+    return lib
+
+
+# build variants of the device source (kept behind build knobs; the product build uses the defaults)
+VARIANTS = {"trial4": ("-DEMU_TRIAL_NW=4",)}       # k_trial as a workgroup of four wavefronts, one part of the row walk each
 
 
 def solve_batch(N, x0, lbx, ubx, p, dt=0.1, tol=1e-5, max_iter=100, hess=2, hess_switch=1.0, mu_init=0.1,
                 kappa_mu=0.1, theta_mu=2.0, kappa_eps=1000.0, want_g=False, verbose=0, want_lam=False, slots=0,
-                mu_floor_k=1e4, dw0=1e-4, inertia_err=1e-2, inertia=2, stall_n=8, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0, trial_repeats=9):
-    build()
-    lib = ctypes.CDLL(LIB)
+                mu_floor_k=1e4, dw0=1e-4, inertia_err=1e-2, inertia=2, stall_n=8, gn_backoff=2, slack_reset=1, ls_alpha_mem=0.0, trial_repeats=9,
+                variant=None):
+    if variant is None:
+        lib = ctypes.CDLL(build())
+    else:
+        lib = ctypes.CDLL(build(lib=LIB.replace(".so", f"_{variant}.so"), defs=VARIANTS[variant]))
     n_w, n_g = 44 * N + 6, 147 * (N - 1) + 21
     lbx = np.where(np.isinf(lbx), -1e20, lbx); ubx = np.where(np.isinf(ubx), 1e20, ubx)
     x0, lbx, ubx, p = (np.ascontiguousarray(np.atleast_2d(a), float) for a in (x0, lbx, ubx, p))

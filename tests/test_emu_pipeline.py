@@ -103,3 +103,15 @@ def test_emulated_iterates_equal_the_oracles_iterate_for_iterate():
         assert rd[running].max() <= (1e-12 if k == 1 else 1e-9), (k, rd)
         hess_seen = hess_seen or bool((o["info"][running, 7] == 1).any())
     assert hess_seen          # some instance has switched to the exact Hessian within twelve iterations
+
+
+def test_emulated_four_wavefront_trial_kernel_agrees_with_the_default():
+    """-DBMPC_TRIAL_NW=4 (k_trial as a workgroup of four wavefronts, each one part of the row walk, partial sums combined through
+    LDS in part order): kept behind a build knob (EXPERIMENTS.md, slower on the GPU).  Same iteration counts, iterates equal to
+    rounding (the sums of theta and of log t are taken per part first)."""
+    N, B = 6, 5
+    batch = scenes.make_batch(B, N, 6, O.fk_batch, randomize_sets=True)
+    a = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
+    b = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], variant="trial4")
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
+    assert np.abs(a["x"] - b["x"]).max() < 1e-8
