@@ -322,7 +322,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     if (rc) return rc;
     const int N = h->o.N, cap = h->pipe_cap;
     PipeArgsH A;
-    A.B = B; A.N = N;
+    A.B = B; A.N = N; A.natt = 0; A.pad0_ = 0;
     A.o = SolverOpts{N, h->o.dt, h->o.tol, h->o.max_iter, h->o.hess, h->o.hess_switch,
                      h->o.mu_init, h->o.kappa_mu, h->o.theta_mu, h->o.kappa_eps,
                      h->o.mu_floor_k, h->o.dw0, h->o.inertia_err, h->o.ls_alpha_mem, h->o.inertia, h->o.stall_n, h->o.gn_backoff, h->o.slack_reset, h->o.trial_repeats};

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv(PipeArgsH 
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
+#ifndef BMPC_RIC_SPEC_BELOW
+#define BMPC_RIC_SPEC_BELOW 256     // live instances below which bmpc_k_ric_att + bmpc_k_ric_sel replace bmpc_k_ric_lat (2 .. 5 attempts per instance: <= 512 workgroups, two per CU)
+#endif
 #ifndef BMPC_RIC_WPE
 #define BMPC_RIC_WPE 3      // wavefronts per SIMD the throughput variant is compiled for
 #endif
@@ -80,6 +83,16 @@ __global__ __launch_bounds__(BMPC_RIC_NT, BMPC_RIC_WPE) __attribute__((disable_t
 __global__ __launch_bounds__(BMPC_RIC_NT, 1) __attribute__((disable_tail_calls)) void bmpc_k_ric_lat(PipeArgsH H) {      // latency variant for the straggler tail
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
     k_ric_body<BMPC_RIC_NT, false>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+// the speculative pair for the deep tail (few instances alive, each on a CU of its own): RIC_NATT factorisation attempts of every
+// instance side by side, then the selection + forward start (bmpc_ric_kernel.hpp)
+__global__ __launch_bounds__(BMPC_RIC_NT, 1) __attribute__((disable_tail_calls)) void bmpc_k_ric_att(PipeArgsH H) {
+    __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
+    k_ric_att_body<BMPC_RIC_NT, false>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+__global__ __launch_bounds__(BMPC_RIC_NT, 1) __attribute__((disable_tail_calls)) void bmpc_k_ric_sel(PipeArgsH H) {
+    __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
+    k_ric_body<BMPC_RIC_NT, false, true>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 #ifndef BMPC_RIC_LAT_BELOW
 #define BMPC_RIC_LAT_BELOW 512      // fewer active instances than this: the latency variant (every wavefront has a SIMD to itself anyway)
@@ -154,7 +167,16 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     // BMPC_RIC_LAT_BELOW in the environment (read once): A/B runs and the test that the two variants agree bitwise
     static const int lat_below = [] { const char* e = getenv("BMPC_RIC_LAT_BELOW"); return e ? atoi(e) : BMPC_RIC_LAT_BELOW; }();
     if (e0) (void)hipEventRecord(e0, st);
-    if (n_act < lat_below) LAUNCH(bmpc_k_ric_lat, n_act, BMPC_RIC_NT);
+    // BMPC_RIC_SPEC_BELOW (read once; 0 = never): below it the factorisation attempts of an iteration run side by side
+    static const int spec_below = [] { const char* e = getenv("BMPC_RIC_SPEC_BELOW"); return e ? atoi(e) : BMPC_RIC_SPEC_BELOW; }();
+    if (n_act < spec_below && n_act < lat_below && n_act > 0) {
+        // as many attempts per instance as fit the chip at two workgroups per CU
+        static const int natt_env = [] { const char* e = getenv("BMPC_RIC_NATT"); return e ? atoi(e) : 0; }();
+        int natt = natt_env > 0 ? natt_env : 512 / n_act;
+        A->natt = natt < 2 ? 2 : (natt > RIC_NATT ? RIC_NATT : natt);
+        LAUNCH(bmpc_k_ric_att, n_act * A->natt, BMPC_RIC_NT);
+        LAUNCH(bmpc_k_ric_sel, n_act, BMPC_RIC_NT);
+    } else if (n_act < lat_below) LAUNCH(bmpc_k_ric_lat, n_act, BMPC_RIC_NT);
     else LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
     if (e1) (void)hipEventRecord(e1, st);
     if (was_lat) *was_lat = n_act < lat_below;

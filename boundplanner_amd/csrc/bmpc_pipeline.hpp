@@ -57,6 +57,11 @@ constexpr int dg_pos_c(int i) {
 BMPC_HD int pos17(int i) { return i < 7 ? Z_Q + i : (i < 14 ? Z_DQ + i - 7 : Z_PI + i - 14); }
 
 constexpr int KREC = 320;               // gains per pair: K (9x32) + kf (2x16)
+// speculative factorisation attempts (k_ric_att / k_ric_sel, bmpc_ric_kernel.hpp): attempts run side by side per instance, and per
+// (instance, attempt) the doubles k_ric_sel needs: [0] sweep succeeded [1] status [2] barrier parameter [3] KKT error, [8 ..) rows
+// 24 .. 31 of the packed P, then pv0[24..31], pv1[24..31]
+constexpr int RIC_NATT = 5 /* at most; PipeArgs.natt of them run */, RIC_FS_P0 = 24 * 25 / 2, RIC_FS_P = NPSYM - RIC_FS_P0, RIC_FS = 256;
+static_assert(8 + RIC_FS_P + 16 <= RIC_FS, "forward-start record");
 constexpr int NPART = 272;              // per-pair partial sums (16) + forces for k_curv (27) + point-group results (121) + PT_SIG (10) + pose-row results (88)
 constexpr int PT_FORCE = 16;            // Fp[3], Fv[6], Fc[6][3]
 constexpr int PT_SIG = 169;             // k_eval -> k_curv: c1 = 2 sig sig'' |e|^2, dpp[3], 2 sig sig' De^T e [6] (exact curvature of sig^2 |e|^2)
@@ -83,6 +88,7 @@ struct InstState {
     int flip, stall;             // stall: iterations since the KKT error last improved by 10 %; flip: which copy of the double-buffered arrays (t / t_t, zeta / zeta_t) holds the iterate (cur_* below)
     double mu, alpha, ad, ap, hreg, err_prev, filt_mu, theta_max, theta_min;
     int gn_skip, gn_back;        // iterations for which the exact Hessian is not tried (after a Gauss-Newton fallback) / current back-off
+    int ksel, pad_;              // copy of the gains the forward recursion reads (0: the slot's own; > 0: a speculative attempt's, ric_krec)
     double dw_last, err_best;    // last successful inertia correction delta_w (0 = none yet); best KKT error so far
     double f0, th0, ls0, D, phi0, fk;
     double filt_th[8], filt_phi[8];
@@ -112,6 +118,7 @@ constexpr int NCNT = 14;
 template <int DEV> struct PipeArgsT {
     typedef PtrT<DEV> PT;
     int B, N;
+    int natt, pad0_;                     // speculative factorisation attempts per instance in k_ric_att / k_ric_sel (<= RIC_NATT)
     SolverOpts o;
     typename PT::RC rc;
     typename PT::CD x0, lbx, ubx, p;
@@ -127,6 +134,7 @@ template <int DEV> struct PipeArgsT {
     typename PT::D hrec;                 // HREC doubles per pair
     typename PT::D krec;                 // KREC doubles per pair
     typename PT::D dx1;                  // [B][32] step of x_1 (k_ric -> k_fwd)
+    typename PT::D kspec, fspec;         // speculative attempts: [slot][RIC_NATT-1][(N-1) KREC] gains, [slot][RIC_NATT][RIC_FS] forward-start records
     typename PT::D part;                 // NPART fields
     typename PT::S st;                   // [slots]
     typename PT::I src;                  // [slots] input / output row of the instance in the slot (streaming: B rows
@@ -162,7 +170,8 @@ inline size_t pipe_slot_block(int N) { return ((PIPE_SOA_FIELDS + HREC + KREC) *
 inline size_t pipe_np_field_major(int cap, int N) { return ((size_t)cap * (N - 1) + 63) / 64 * 64 + 64; }
 inline size_t pipe_workspace_doubles(int cap, int N, int slot_major) {
     return (slot_major ? pipe_slot_block(N) * (size_t)cap + 64
-                       : (PIPE_SOA_FIELDS + HREC + KREC) * pipe_np_field_major(cap, N)) + (size_t)cap * NX;
+                       : (PIPE_SOA_FIELDS + HREC + KREC) * pipe_np_field_major(cap, N)) + (size_t)cap * NX
+           + (size_t)cap * ((size_t)(RIC_NATT - 1) * (N - 1) * KREC + (size_t)RIC_NATT * RIC_FS);
 }
 template <class AT> inline void pipe_carve(AT& A, double* w, int cap, int N, int slot_major) {
     const size_t S = (size_t)(N - 1);
@@ -177,6 +186,8 @@ template <class AT> inline void pipe_carve(AT& A, double* w, int cap, int N, int
     if (slot_major) w = w0 + ((size_t)(w - w0) + 15) / 16 * 16;      // records 128-byte aligned inside the slot block
     A.hrec = w; w += HREC * NP; A.krec = w; w += KREC * NP;
     A.dx1 = slot_major ? w0 + pipe_slot_block(N) * (size_t)cap + 64 : w;
+    A.kspec = A.dx1 + (size_t)cap * NX;
+    A.fspec = A.kspec + (size_t)cap * (RIC_NATT - 1) * (size_t)(N - 1) * KREC;
 }
 
 // parameters of the instances of a wavefront are staged in LDS (every thread reads ~500 of them):

@@ -233,6 +233,28 @@ template <int NT> BMPC_DEV double rmin(double v, LDSD* red, int lane) {
     return s;
 }
 
+// gains of (slot b, stage k): copy 0 in the slot's block, copies 1 .. RIC_NATT-1 (speculative attempts, k_ric_att) in A.kspec
+template <class AT> BMPC_INL auto ric_krec(const AT& A, int b, int k, int copy) -> decltype(A.krec) {
+    if (copy == 0) return A.krec + krec_of(A, b, k);
+    return A.kspec + ((size_t)b * (RIC_NATT - 1) + (size_t)(copy - 1)) * ((size_t)(A.N - 1) * KREC) + (size_t)(k - 1) * KREC;
+}
+
+// The sequence of factorisation attempts of one iteration (oracle/bmpc_solve.c "inertia"; Waechter & Biegler 2006, Algorithm IC):
+// attempt 0 = the iterate's Hessian (exact or Gauss-Newton, delta_w = 0); after a failed attempt either the Gauss-Newton fallback or
+// the next delta_w.  The sequence is known BEFORE any attempt has run, which is what lets k_ric_att run several at once.
+struct RicAttempt { int hess_mode, tries, gn_fell, dead; double dw; };
+BMPC_INL void ric_attempt_next(RicAttempt& a, int gn_ok, double dwl, double dw0) {
+    if (a.hess_mode && gn_ok) { a.hess_mode = 0; a.tries += 1; a.gn_fell = 1; }      // second-order terms not convex here: Gauss-Newton
+    else {
+        // inertia correction: delta_w I on the Hessian, natural coordinates
+        double dw = a.dw;
+        if (dw == 0.0) dw = (dwl == 0.0) ? dw0 : fmax(1e-20, dwl / 3.0);
+        else dw *= (dwl == 0.0) ? 100.0 : 8.0;
+        a.dw = dw;
+        if (++a.tries > 14 || dw > 1e20) a.dead = 1;
+    }
+}
+
 // backward recursion over the horizon; returns false if a control block is not positive definite
 // The Riccati kernel reads the argument block through the plain-pointer view: with global-qualified
 // pointers this compiler (ROCm 7.2) mis-assigns an odd register pair when it reloads a spilled
@@ -604,7 +626,7 @@ BMPC_INL bool ric_phase_factor_impl(RicArgs AH, LDSD* lds, int b, int lane, int 
     // ---- control block factorisation, gains, Schur complement ----
     // the factor is needed by the 34 lanes that solve for a gain column: the first wavefront computes it (every lane for
     // itself: no LDS round trips inside the factorisation), the second skips the whole block; the verdict travels through LDS
-    double* krec = A.krec + krec_of(A, b, k);
+    double* krec = ric_krec(A, b, k, (int)RL(R_park)[15]);      // (the gains of a speculative attempt go to its own copy)
     if (lane < 64) {
       double Lc[45], invd[NU];
       const bool pd = chol9i(RL(R_W), reg, Lc, invd);
@@ -922,6 +944,7 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
     const int b = A.L.step[blk], N = A.N;
     const DynC dc = make_dync(A.o.dt);
     const double mu = A.st[b].mu;
+    const int ksel = A.st[b].ksel;                  // which copy of the gains this iteration's factorisation left (ric_finish)
     constexpr int NK = (NU * NX + 63) / 64;
     // stage data in flight: FW_DEPTH stages ahead.  (Measured in round 4: depth 3 at 128 registers 181 us, depth 1 178 us at 8192
     // live instances -- the kernel does not wait for its gains; it is bound by instruction issue at 9 .. 32 busy lanes of 64)
@@ -930,7 +953,7 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
     BMPC_UNROLL
     for (int s = 0; s < D; s++) { fkf[s] = 0; few[s] = 0; frd[s] = 0; }
     auto fetch = [&](int k, int s) {
-        GCD krec = A.krec + krec_of(A, b, k);
+        GCD krec = ric_krec(A, b, k, ksel);
         GCD rec = A.hrec + hrec_of(A, b, k);
         BMPC_UNROLL
         for (int m = 0; m < NK; m++) { int e = lane + 64 * m; fK[s][m] = (e < NU * NX) ? krec[e] : 0.0; }
@@ -1020,10 +1043,8 @@ BMPC_NOINL int ric_kkt_and_barrier(RicArgs AH, LDSD* lds, int b, int lane, int i
 #endif
     if (err <= o.tol && dual <= 1.0 && prim <= 1e-4 && cmax <= 1e-4) return 0;
     if (it >= o.max_iter) return 1;
-    if (lane == 0) {
-        st->err_prev = err;
-        if (err < 0.9 * st->err_best) { st->err_best = err; st->stall = 0; } else st->stall += 1;
-    }
+    // (the error goes into the instance state in ric_note_err: k_ric_att must not touch what its sibling attempts read)
+    if (lane == 0) RL(R_park)[5] = err;
     // monotone Fiacco-McCormick barrier update; a decrease stops at (scaled error) / mu_floor_k
     double emu = fmax(fmax(dual / sd, prim), fmax(fabs(cmax - mu), fabs(cmin - mu)) / sc);
     while (emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
@@ -1042,117 +1063,182 @@ BMPC_NOINL int ric_kkt_and_barrier(RicArgs AH, LDSD* lds, int b, int lane, int i
     return -1;
 }
 
+BMPC_INL void ric_note_err(InstState* st, double err) {      // lane 0, after ric_kkt_and_barrier returned -1
+    st->err_prev = err;
+    if (err < 0.9 * st->err_best) { st->err_best = err; st->stall = 0; } else st->stall += 1;
+}
+
+// ---- pieces of the Riccati kernels ----
+// pinned part of x_1 and its defect -> R_r0
+template <class AT> BMPC_INL void ric_load_r0(const AT& A, LDSD* lds, int b, int lane) {
+    const int N = A.N, n_w = 44 * N + 6;
+    const double* lbx = A.lbx + (size_t)A.src[b] * n_w;
+    if (lane == 0) {
+        double x1fix[24];
+        x1fix_eval((GCD)lbx, N, A.o.dt, x1fix);
+        for (int i = 0; i < 24; i++) RL(R_x1fix)[i] = x1fix[i];
+    }
+    BMPC_SYNC();
+    if (lane < 24) RL(R_r0)[lane] = RL(R_x1fix)[lane] - cur_zeta(A, A.st[b].flip)[(size_t)lane * A.NP + pair_of(A, b, 1)];
+}
+// KKT partial sums of the pairs: staged in LDS [quantity][pair], then one lane per quantity adds them
+// in pair order (fixed order -> reproducible; N - 1 <= 63 pairs) -> R_park[0..4], [7]; f0 -> [8]
+template <class AT> BMPC_INL void ric_load_kkt_sums(const AT& A, LDSD* lds, int b, int lane) {
+    const int N = A.N;
+    LDSD* stg = RL(R_W);          // free until the backward sweep
+    if (lane < N - 1) {
+        const double* P = A.part + pair_of(A, b, 1) + lane;
+        stg[0 * 64 + lane] = P[PT_CMAX * A.NP]; stg[1 * 64 + lane] = P[PT_CSUM * A.NP]; stg[2 * 64 + lane] = P[PT_CMIN * A.NP];
+        stg[3 * 64 + lane] = P[PT_ZSUM * A.NP]; stg[4 * 64 + lane] = P[PT_PRIM * A.NP]; stg[5 * 64 + lane] = P[PT_NROWS * A.NP];
+    }
+    BMPC_SYNC();
+    if (lane < 6) {
+        const int kind = (lane == 0 || lane == 4) ? 1 : (lane == 2 ? 2 : 0);      // 0 sum, 1 max, 2 min
+        double v = stg[lane * 64];
+#pragma unroll 4
+        for (int k = 1; k < N - 1; k++) {
+            double x = stg[lane * 64 + k];
+            v = kind == 0 ? v + x : (kind == 1 ? fmax(v, x) : fmin(v, x));
+        }
+        RL(R_park)[lane == 5 ? 7 : lane] = v;        // cmax, csum, cmin, zsum, prim -> [0..4], nrows -> [7]
+    }
+    if (lane == 6) RL(R_park)[8] = A.st[b].f0;
+    BMPC_SYNC();
+}
+// what an iteration's factorisation leaves in the instance state, and the list the instance goes to (lane 0)
+template <class AT> BMPC_INL void ric_finish(const AT& A, LDSD* lds, int b, int status, const RicAttempt& at, int hess_mode_in, double mu, int ksel) {
+    InstState* st = A.st + b;
+    const auto& o = A.o;
+    if (status >= 0) {
+        st->state = ST_DONE; st->status = status; st->fk = RL(R_park)[8];
+        BMPC_ATOMIC_INC(A.L.cnt + 5);
+        int pos = BMPC_ATOMIC_INC(A.L.cnt + 8);      // to be retired (outputs written, slot refilled)
+        A.L.done[pos] = b;
+    } else {
+        if (at.dw > 0.0) st->dw_last = at.dw;
+        // after a Gauss-Newton fallback the exact Hessian is tried again after 1, 2, ... gn_backoff iterations (ls_instance, in k_trial)
+        if (at.gn_fell && o.gn_backoff > 0) {
+            const int gb = st->gn_back ? (2 * st->gn_back < o.gn_backoff ? 2 * st->gn_back : o.gn_backoff) : 1;
+            st->gn_back = gb; st->gn_skip = gb;
+        } else if (at.tries == 0 && hess_mode_in) st->gn_back = 0;
+        st->hreg = at.dw; st->mu = mu; st->tries = at.tries; st->ksel = ksel; st->state = ST_STEP;
+        int pos = BMPC_ATOMIC_INC(A.L.cnt + 1);
+        A.L.step[pos] = b;
+    }
+}
+
 // lds: RIC_LDS_DOUBLES.  One workgroup (one wavefront) per entry of the eval list.
-template <int NT, bool SPLIT = true>
+// RESUME: the second kernel of the speculative pair (k_ric_att -> k_ric_sel): attempts 0 .. RIC_NATT-1 have been run side by side by
+// k_ric_att, one workgroup each; this kernel walks the same sequence, takes the first attempt whose sweep succeeded (forward start
+// from the state that attempt saved) and only runs sweeps of its own for attempts beyond the speculated ones.
+template <int NT, bool SPLIT = true, bool RESUME = false>
 BMPC_DEV void k_ric_body(RicArgs AH, int blk, int lane, LDSD* lds) {
     RicArgsRef A = ric_args(AH);
     const int count = A.L.cnt[0];
     if (blk >= count) return;
     const int b = BMPC_UNIFORM(A.L.eval[blk]);
-    if (lane == 0) BMPC_ATOMIC_INC(A.L.cnt + (SPLIT ? 11 : 12));      // instance-iterations of this variant (bmpc_debug_ric_stats)
-    const int N = A.N, n_w = 44 * N + 6;
+    if (!RESUME && lane == 0) BMPC_ATOMIC_INC(A.L.cnt + (SPLIT ? 11 : 12));      // instance-iterations of this variant (bmpc_debug_ric_stats)
     const auto& o = A.o;
     InstState* st = A.st + b;
-    const double* lbx = A.lbx + (size_t)A.src[b] * n_w;
-    // pinned part of x_1 and its defect
-    if (lane == 0) {
-        double x1fix[24];
-        x1fix_eval((GCD)lbx, N, o.dt, x1fix);
-        for (int i = 0; i < 24; i++) RL(R_x1fix)[i] = x1fix[i];
-    }
-    BMPC_SYNC();
-    if (lane < 24) RL(R_r0)[lane] = RL(R_x1fix)[lane] - cur_zeta(A, A.st[b].flip)[(size_t)lane * A.NP + pair_of(A, b, 1)];
-    // KKT partial sums of the pairs: staged in LDS [quantity][pair], then one lane per quantity adds them
-    // in pair order (fixed order -> reproducible; N - 1 <= 63 pairs)
-    {
-        LDSD* stg = RL(R_W);          // free until the backward sweep
-        if (lane < N - 1) {
-            const double* P = A.part + pair_of(A, b, 1) + lane;
-            stg[0 * 64 + lane] = P[PT_CMAX * A.NP]; stg[1 * 64 + lane] = P[PT_CSUM * A.NP]; stg[2 * 64 + lane] = P[PT_CMIN * A.NP];
-            stg[3 * 64 + lane] = P[PT_ZSUM * A.NP]; stg[4 * 64 + lane] = P[PT_PRIM * A.NP]; stg[5 * 64 + lane] = P[PT_NROWS * A.NP];
-        }
-        BMPC_SYNC();
-        if (lane < 6) {
-            const int kind = (lane == 0 || lane == 4) ? 1 : (lane == 2 ? 2 : 0);      // 0 sum, 1 max, 2 min
-            double v = stg[lane * 64];
-#pragma unroll 4
-            for (int k = 1; k < N - 1; k++) {
-                double x = stg[lane * 64 + k];
-                v = kind == 0 ? v + x : (kind == 1 ? fmax(v, x) : fmin(v, x));
-            }
-            RL(R_park)[lane == 5 ? 7 : lane] = v;        // cmax, csum, cmin, zsum, prim -> [0..4], nrows -> [7]
-        }
-        if (lane == 6) RL(R_park)[8] = st->f0;
-        BMPC_SYNC();
-    }
+    ric_load_r0(A, lds, b, lane);
+    if (!RESUME) ric_load_kkt_sums(A, lds, b, lane);
+    else { if (lane == 6) RL(R_park)[8] = st->f0; }
 #ifdef BMPC_PROFILE
     if (lane < 16) RL(R_misc)[32 + lane] = 0.0;
 #endif
     // uniform scalars that must survive the (non-inlined) sweeps: integers in scalar registers, mu, delta_w and the last
     // successful delta_w in LDS (R_park[11], [12], [14]) -- every vector register kept across the calls adds to the kernel's count
-    int hess_mode = BMPC_UNIFORM(st->hess_mode), tries = 0, gn_fell = 0;
-    const int hess_mode_in = hess_mode;
+    RicAttempt at;
+    at.hess_mode = BMPC_UNIFORM(st->hess_mode); at.tries = 0; at.gn_fell = 0; at.dead = 0; at.dw = 0.0;
+    const int hess_mode_in = at.hess_mode;
     const int it = BMPC_UNIFORM(st->it);
     // not positive definite with the exact Hessian: Gauss-Newton fallback while far from a solution and still improving,
     // inertia correction otherwise (oracle/bmpc_solve.c, "inertia"); err_prev is still the previous iterate's error here
     const int gn_ok = BMPC_UNIFORM((o.inertia == 0 || (o.inertia == 2 && st->err_prev > o.inertia_err && st->stall < o.stall_n)) ? 1 : 0);
-    if (lane == 0) { RL(R_park)[12] = 0.0; RL(R_park)[11] = st->mu; RL(R_park)[14] = st->dw_last; }
+    if (lane == 0) { RL(R_park)[12] = 0.0; RL(R_park)[11] = st->mu; RL(R_park)[14] = st->dw_last; RL(R_park)[15] = 0.0; }
     bool first = true;
-    int status = -1;
-    for (;;) {
+    int status = -1, ksel = 0;
+    for (int att = 0;; att++) {
         BMPC_SYNC();
-        bool ok = ric_backward<NT, SPLIT>(AH, lds, b, lane, hess_mode, first ? 0 : 1);
+        bool ok;
+        if (RESUME && att < A.natt) {
+            // the attempt has been run by k_ric_att: its verdict, (attempt 0) the KKT test and the new barrier parameter, and the
+            // state the forward start needs
+            const double* fs = A.fspec + ((size_t)b * RIC_NATT + att) * RIC_FS;
+            ok = fs[0] != 0.0;
+            if (att == 0) {
+                status = (int)fs[1];
+                if (lane == 0) { RL(R_park)[11] = fs[2]; RL(R_park)[5] = fs[3]; }
+            }
+            if (ok && status < 0) {
+                for (int e = lane; e < RIC_FS_P; e += NT) RL(R_P)[RIC_FS_P0 + e] = fs[8 + e];
+                if (lane < 8) { RL(R_pv0)[24 + lane] = fs[8 + RIC_FS_P + lane]; RL(R_pv1)[24 + lane] = fs[8 + RIC_FS_P + 8 + lane]; }
+            }
+            BMPC_SYNC();
+        } else ok = ric_backward<NT, SPLIT>(AH, lds, b, lane, at.hess_mode, first ? 0 : 1);
         if (first) {
             first = false;
-            status = ric_kkt_and_barrier<SPLIT>(AH, lds, b, lane, it, hess_mode, gn_ok);
+            if (!RESUME) status = ric_kkt_and_barrier<SPLIT>(AH, lds, b, lane, it, at.hess_mode, gn_ok);
             if (status >= 0) break;
+            if (lane == 0) ric_note_err(st, RL(R_park)[5]);
         }
         { RPROF_START(); if (ok) ok = ric_forward<NT, SPLIT>(AH, lds, b, lane); RPROF(6); }
-        if (ok) break;
-        if (hess_mode && gn_ok) {                        // second-order terms not convex here: Gauss-Newton
-            hess_mode = 0; ++tries; gn_fell = 1;
+        if (ok) { ksel = (RESUME && att < A.natt) ? att : 0; break; }
+        at.dw = RL(R_park)[12];                          // (delta_w lives in LDS across the sweeps, not in a register)
+        ric_attempt_next(at, gn_ok, RL(R_park)[14], o.dw0);
 #ifdef BMPC_EMU_TRACE
-            if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d]      GN fallback\n", A.src[b]);
+        if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d]      attempt %d: hess_mode %d dw %.3e\n", A.src[b], at.tries, at.hess_mode, at.dw);
 #endif
-        }
-        else {
-            // inertia correction (Waechter & Biegler 2006, Algorithm IC): delta_w I on the Hessian, natural coordinates
-            double dw = RL(R_park)[12];
-            const double dwl = RL(R_park)[14];
-            if (dw == 0.0) dw = (dwl == 0.0) ? o.dw0 : fmax(1e-20, dwl / 3.0);
-            else dw *= (dwl == 0.0) ? 100.0 : 8.0;
-            BMPC_SYNC();
-            if (lane == 0) RL(R_park)[12] = dw;
-#ifdef BMPC_EMU_TRACE
-            if (lane == 0 && getenv("BMPC_EMU_TRACE")) printf("[b %d]      dw %.3e tries %d\n", A.src[b], dw, tries + 1);
-#endif
-            if (++tries > 14 || dw > 1e20) { status = 3; break; }
-        }
+        BMPC_SYNC();
+        if (lane == 0) { RL(R_park)[12] = at.dw; RL(R_park)[15] = 0.0; }
+        if (at.dead) { status = 3; break; }
     }
     BMPC_SYNC();
-    const double dw = RL(R_park)[12];
     const double mu = RL(R_park)[11];
+    at.dw = RL(R_park)[12];
 #ifdef BMPC_PROFILE
     BMPC_SYNC();
     if (lane < 16) atomicAdd(A.prof + lane, RL(R_misc)[32 + lane]);
 #endif
-    if (lane == 0) {
-        if (status >= 0) {
-            st->state = ST_DONE; st->status = status; st->fk = RL(R_park)[8];
-            BMPC_ATOMIC_INC(A.L.cnt + 5);
-            int pos = BMPC_ATOMIC_INC(A.L.cnt + 8);      // to be retired (outputs written, slot refilled)
-            A.L.done[pos] = b;
-        } else {
-            if (dw > 0.0) st->dw_last = dw;
-            // after a Gauss-Newton fallback the exact Hessian is tried again after 1, 2, ... gn_backoff iterations (ls_instance, in k_trial)
-            if (gn_fell && o.gn_backoff > 0) {
-                const int gb = st->gn_back ? (2 * st->gn_back < o.gn_backoff ? 2 * st->gn_back : o.gn_backoff) : 1;
-                st->gn_back = gb; st->gn_skip = gb;
-            } else if (tries == 0 && hess_mode_in) st->gn_back = 0;
-            st->hreg = dw; st->mu = mu; st->tries = tries; st->state = ST_STEP;
-            int pos = BMPC_ATOMIC_INC(A.L.cnt + 1);
-            A.L.step[pos] = b;
-        }
+    if (lane == 0) ric_finish(A, lds, b, status, at, hess_mode_in, mu, ksel);
+}
+
+// The first kernel of the speculative pair: workgroup (instance e, attempt a) runs the backward sweep of attempt a of the sequence
+// above -- attempt 0 with the KKT test and the barrier update, as k_ric_body; attempts >= 1 stop at the first control block that is
+// not positive definite -- and leaves in A.fspec what k_ric_sel needs: verdict, (a = 0) status / barrier parameter / KKT error, and
+// the rows of P and the entries of the value-function gradients that the forward start reads.  Gains go to the attempt's own copy.
+// Nothing any sibling attempt reads is written.  In the straggler tail the slowest instance of a launch needs two or three sweeps;
+// side by side they cost the time of one.
+template <int NT, bool SPLIT>
+BMPC_DEV void k_ric_att_body(RicArgs AH, int blk, int lane, LDSD* lds) {
+    RicArgsRef A = ric_args(AH);
+    const int count = A.L.cnt[0];
+    if (blk >= count * A.natt) return;
+    const int att = blk / count, e = blk - att * count;
+    const int b = BMPC_UNIFORM(A.L.eval[e]);
+    const auto& o = A.o;
+    InstState* st = A.st + b;
+    if (att == 0 && lane == 0) BMPC_ATOMIC_INC(A.L.cnt + (SPLIT ? 11 : 12));
+    if (att == 0) ric_load_kkt_sums(A, lds, b, lane);
+    RicAttempt at;
+    at.hess_mode = BMPC_UNIFORM(st->hess_mode); at.tries = 0; at.gn_fell = 0; at.dead = 0; at.dw = 0.0;
+    const int it = BMPC_UNIFORM(st->it);
+    const int gn_ok = BMPC_UNIFORM((o.inertia == 0 || (o.inertia == 2 && st->err_prev > o.inertia_err && st->stall < o.stall_n)) ? 1 : 0);
+    const double dwl = st->dw_last;
+    for (int i = 0; i < att; i++) ric_attempt_next(at, gn_ok, dwl, o.dw0);
+    double* fs = A.fspec + ((size_t)b * RIC_NATT + att) * RIC_FS;
+    if (at.dead) { if (lane == 0) fs[0] = 0.0; return; }
+    BMPC_SYNC();
+    if (lane == 0) { RL(R_park)[12] = at.dw; RL(R_park)[11] = st->mu; RL(R_park)[14] = dwl; RL(R_park)[15] = (double)att; RL(R_park)[5] = 0.0; }
+    BMPC_SYNC();
+    const bool ok = ric_backward<NT, SPLIT>(AH, lds, b, lane, at.hess_mode, att == 0 ? 0 : 1);
+    int status = -1;
+    if (att == 0) status = ric_kkt_and_barrier<SPLIT>(AH, lds, b, lane, it, at.hess_mode, gn_ok);
+    BMPC_SYNC();
+    if (lane == 0) { fs[0] = ok ? 1.0 : 0.0; fs[1] = (double)status; fs[2] = RL(R_park)[11]; fs[3] = RL(R_park)[5]; }
+    if (ok) {
+        for (int i = lane; i < RIC_FS_P; i += NT) fs[8 + i] = RL(R_P)[RIC_FS_P0 + i];
+        if (lane < 8) { fs[8 + RIC_FS_P + lane] = RL(R_pv0)[24 + lane]; fs[8 + RIC_FS_P + 8 + lane] = RL(R_pv1)[24 + lane]; }
     }
 }
 
@@ -1164,7 +1250,7 @@ BMPC_INL void inst_reset(const PipeArgs& A, int slot) {
     st->state = ST_EVAL; st->it = 0; st->status = 1; st->nfilt = 0; st->hess_mode = 0; st->bt = 0; st->armijo = 0; st->tries = 0;
     st->flip = 0; st->stall = 0; st->dw_last = 0; st->err_best = 1e300; st->gn_skip = 0; st->gn_back = 0;
     st->mu = A.o.mu_init; st->alpha = 0; st->ad = 0; st->ap = 0; st->hreg = 0; st->err_prev = 1e300; st->filt_mu = -1;
-    st->theta_max = 1e300; st->theta_min = 0; st->fk = 0;
+    st->theta_max = 1e300; st->theta_min = 0; st->fk = 0; st->ksel = 0;
 }
 
 // first fill of the pool: slot i takes input row i (host sets cnt[0] = cnt[9] = cnt[6] = number of slots filled)

@@ -86,7 +86,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     RobotConst rc;
     fill_robot_const(rc);
     PipeArgs A;   // emulation: BMPC_AS1 is empty, host and device views coincide
-    A.B = B; A.N = N;
+    A.B = B; A.N = N; A.natt = 0; A.pad0_ = 0;
     A.lam_g = nullptr; A.lam_x = nullptr; A.cont = nullptr;
     A.o = SolverOpts{N, dt, tol, max_iter, hess, hess_switch, mu_init, kappa_mu, theta_mu, kappa_eps, mu_floor_k, dw0, inertia_err, ls_alpha_mem, inertia, stall_n, gn_backoff, slack_reset, trial_repeats};
     A.rc = &rc;
@@ -130,6 +130,11 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_pose_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[10]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
+        if (getenv("BMPC_EMU_RIC_SPEC") && atoi(getenv("BMPC_EMU_RIC_SPEC"))) {      // the speculative pair (the deep tail's kernels on the GPU)
+            A.natt = 3;
+            launch(cnt[0] * A.natt, [&](int blk, int l) { k_ric_att_body<EMU_RIC_NT, false>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
+            launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT, false, true>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
+        } else
         launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
         launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });

@@ -441,9 +441,10 @@ def test_config3_all_65536_rows_on_one_gpu(backends):
 
 
 def test_ric_variants_agree_bitwise(tmp_path):
-    """bmpc_k_ric (throughput variant, three noinline sweeps) and bmpc_k_ric_lat (one body, used below 512 active instances)
-    are two compilations of the same arithmetic; results must not depend on which one ran.  BMPC_RIC_LAT_BELOW is read once
-    per process, so the two settings run in two child processes."""
+    """bmpc_k_ric (throughput variant, three noinline sweeps), bmpc_k_ric_lat (one body, used below 512 active instances) and the
+    speculative pair bmpc_k_ric_att + bmpc_k_ric_sel (below 160: the factorisation attempts of an iteration side by side, then
+    the first successful one is taken) are compilations / schedules of the same arithmetic; results must not depend on which one
+    ran.  BMPC_RIC_LAT_BELOW / BMPC_RIC_SPEC_BELOW are read once per process, so the settings run in child processes."""
     import os
     import subprocess
     import sys
@@ -454,12 +455,13 @@ def test_ric_variants_agree_bitwise(tmp_path):
             "r = be.solve_batch(b['x0'], b['lbx'], b['ubx'], b['p'])\n"
             "np.savez(sys.argv[1], **{k: r[k] for k in ('x', 'f', 'iters', 'status', 'viol')})\n") % root
     out = []
-    for v in ("0", "1000000000"):
-        path = str(tmp_path / f"ric_{v}.npz")
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, BMPC_RIC_LAT_BELOW=v), timeout=600)
+    for lat, spec in (("0", "0"), ("1000000000", "0"), ("1000000000", "1000000000")):
+        path = str(tmp_path / f"ric_{lat}_{spec}.npz")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, BMPC_RIC_LAT_BELOW=lat, BMPC_RIC_SPEC_BELOW=spec), timeout=600)
         out.append(np.load(path))
     for k in ("x", "f", "iters", "status", "viol"):
         assert np.array_equal(out[0][k], out[1][k]), k
+        assert np.array_equal(out[0][k], out[2][k]), ("speculative pair", k)
     assert out[0]["iters"].max() > 40       # stragglers included
 
 
