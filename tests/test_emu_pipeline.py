@@ -115,3 +115,19 @@ def test_emulated_four_wavefront_trial_kernel_agrees_with_the_default():
     b = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], variant="trial4")
     assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
     assert np.abs(a["x"] - b["x"]).max() < 1e-8
+
+
+def test_emulated_speculative_factorisation_attempts_are_bitwise_the_sequential_ones(monkeypatch):
+    """bmpc_k_ric_att + bmpc_k_ric_sel (the deep tail's Riccati kernels on the GPU): the attempts of an iteration -- delta_w = 0, then
+    the Gauss-Newton fallback or escalating delta_w -- run as workgroups of their own, the selection kernel takes the first one that
+    succeeded and only sweeps itself beyond the speculated ones.  Every attempt is the arithmetic the sequential loop would have done:
+    the results are bitwise the same, here on instances that need inertia corrections (iteration counts up to the limit)."""
+    N = 15
+    batch = scenes.make_batch(128, N, 7, O.fk_batch, randomize_sets=True)
+    pick = [49, 108, 86, 74, 58, 8]              # the instances of this batch with the most factorisation retries
+    a = tuple(batch[k][pick] for k in ("x0", "lbx", "ubx", "p"))
+    seq = E.solve_batch(N, *a, want_g=True, max_iter=40)
+    monkeypatch.setenv("BMPC_EMU_RIC_SPEC", "1")
+    spec = E.solve_batch(N, *a, want_g=True, max_iter=40)
+    for k in ("x", "g", "f", "iters", "status", "viol"):
+        assert np.array_equal(seq[k], spec[k]), k
