@@ -317,7 +317,8 @@ def main():
     # its launches over their summed duration, measured live with HIP events around every launch on the handle's stream while the
     # step-0 batch is solved alone (no other call in flight: a launch's duration is its own).  An instance-iteration is one
     # backward sweep over the N-1 stages (retry sweeps -- Gauss-Newton fallback, delta_w escalation -- run in the same launch
-    # and are not counted as work).  The latency variant bmpc_k_ric_lat (nearly empty super-steps of the tail) is reported beside it.
+    # and are not counted as work).  The tail regime (fewer than 512 live instances: bmpc_k_ric_att / _att_thr + bmpc_k_ric_sel, the
+    # attempts of an iteration side by side; bmpc_k_ric_lat with BMPC_RIC_SPEC_BELOW=0) is reported beside it.
     roof = {"bound": "valu_fp64", "kernel": "bmpc_k_ric", "achieved": None, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None}
     if ric is not None:
         ms_b, n_b, sw_b = ric["bmpc_k_ric"]
@@ -329,7 +330,7 @@ def main():
         roof.update({"launches": int(n_b), "launch_ms_avg": ms_b / n_b if n_b else None, "launch_ms_sum": ms_b, "instance_iterations": int(sw_b),
                      "alg_flops_per_instance_iteration": fl,
                      "measured": "HIP events around every launch on the solver handle's stream (bmpc_debug_time_ric), the step-0 batch alone",
-                     "latency_variant": {"kernel": "bmpc_k_ric_lat", "launches": int(n_l), "launch_ms_avg": ms_l / n_l if n_l else None,
+                     "latency_variant": {"kernel": "bmpc_k_ric_att(_thr) + bmpc_k_ric_sel (tail regime, < 512 live instances; bmpc_k_ric_lat when speculation is off)", "launches": int(n_l), "launch_ms_avg": ms_l / n_l if n_l else None,
                                          "launch_ms_sum": ms_l, "instance_iterations": int(sw_l)}})
     roof.update({"traffic": traffic, "traffic_stale": traffic_stale, "traffic_note": traffic_note,
                  # measured HBM bytes of a batch (all kernels) over the per-batch time of THIS run: what the memory system sustains

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv(PipeArgsH 
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
 #ifndef BMPC_RIC_SPEC_BELOW
-#define BMPC_RIC_SPEC_BELOW 256     // live instances below which bmpc_k_ric_att + bmpc_k_ric_sel replace bmpc_k_ric_lat (2 .. 5 attempts per instance: <= 512 workgroups, two per CU)
+#define BMPC_RIC_SPEC_BELOW 512     // live instances below which bmpc_k_ric_att(_thr) + bmpc_k_ric_sel replace bmpc_k_ric_lat / bmpc_k_ric (2 .. 5 attempts per instance)
 #endif
 #ifndef BMPC_RIC_WPE
 #define BMPC_RIC_WPE 3      // wavefronts per SIMD the throughput variant is compiled for
@@ -89,6 +89,11 @@ __global__ __launch_bounds__(BMPC_RIC_NT, 1) __attribute__((disable_tail_calls))
 __global__ __launch_bounds__(BMPC_RIC_NT, 1) __attribute__((disable_tail_calls)) void bmpc_k_ric_att(PipeArgsH H) {
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
     k_ric_att_body<BMPC_RIC_NT, false>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
+}
+// (the same with the throughput compilation of the sweeps: more attempts than 512 workgroups -- two per CU -- can hold)
+__global__ __launch_bounds__(BMPC_RIC_NT, BMPC_RIC_WPE) __attribute__((disable_tail_calls)) void bmpc_k_ric_att_thr(PipeArgsH H) {
+    __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
+    k_ric_att_body<BMPC_RIC_NT, true>(ric_kernel_args(), blockIdx.x, threadIdx.x, (LDSD*)lds);
 }
 __global__ __launch_bounds__(BMPC_RIC_NT, 1) __attribute__((disable_tail_calls)) void bmpc_k_ric_sel(PipeArgsH H) {
     __shared__ __attribute__((aligned(16))) double lds[RIC_LDS_DOUBLES];
@@ -169,17 +174,19 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     if (e0) (void)hipEventRecord(e0, st);
     // BMPC_RIC_SPEC_BELOW (read once; 0 = never): below it the factorisation attempts of an iteration run side by side
     static const int spec_below = [] { const char* e = getenv("BMPC_RIC_SPEC_BELOW"); return e ? atoi(e) : BMPC_RIC_SPEC_BELOW; }();
-    if (n_act < spec_below && n_act < lat_below && n_act > 0) {
-        // as many attempts per instance as fit the chip at two workgroups per CU
+    if (n_act < spec_below && n_act > 0) {
+        // as many attempts per instance as the chip holds at once: up to 512 workgroups with the latency compilation of the sweeps
+        // (two per CU), up to 1536 with the throughput compilation (six per CU)
         static const int natt_env = [] { const char* e = getenv("BMPC_RIC_NATT"); return e ? atoi(e) : 0; }();
-        int natt = natt_env > 0 ? natt_env : 512 / n_act;
+        int natt = natt_env > 0 ? natt_env : (n_act * RIC_NATT <= 512 ? RIC_NATT : 1536 / n_act);
         A->natt = natt < 2 ? 2 : (natt > RIC_NATT ? RIC_NATT : natt);
-        LAUNCH(bmpc_k_ric_att, n_act * A->natt, BMPC_RIC_NT);
+        if (n_act * A->natt <= 512) LAUNCH(bmpc_k_ric_att, n_act * A->natt, BMPC_RIC_NT);
+        else LAUNCH(bmpc_k_ric_att_thr, n_act * A->natt, BMPC_RIC_NT);
         LAUNCH(bmpc_k_ric_sel, n_act, BMPC_RIC_NT);
     } else if (n_act < lat_below) LAUNCH(bmpc_k_ric_lat, n_act, BMPC_RIC_NT);
     else LAUNCH(bmpc_k_ric, n_act, BMPC_RIC_NT);
     if (e1) (void)hipEventRecord(e1, st);
-    if (was_lat) *was_lat = n_act < lat_below;
+    if (was_lat) *was_lat = n_act < lat_below || n_act < spec_below;      // (the launches of the tail regime, whichever kernels ran)
     LAUNCH(bmpc_k_fwd, n_act, 64);
     LAUNCH_DYN(bmpc_k_step, nw, 64, pair_lds_doubles(A->N, false));
     // (BMPC_TRIAL_REPEATS in the environment, read once, overrides bmpc_opts.trial_repeats: A/B runs)

@@ -1218,7 +1218,7 @@ BMPC_DEV void k_ric_att_body(RicArgs AH, int blk, int lane, LDSD* lds) {
     const int b = BMPC_UNIFORM(A.L.eval[e]);
     const auto& o = A.o;
     InstState* st = A.st + b;
-    if (att == 0 && lane == 0) BMPC_ATOMIC_INC(A.L.cnt + (SPLIT ? 11 : 12));
+    if (att == 0 && lane == 0) BMPC_ATOMIC_INC(A.L.cnt + 12);      // counted with the latency regime whichever compilation of the sweeps runs (bench.py: flops per launch time)
     if (att == 0) ric_load_kkt_sums(A, lds, b, lane);
     RicAttempt at;
     at.hess_mode = BMPC_UNIFORM(st->hess_mode); at.tries = 0; at.gn_fell = 0; at.dead = 0; at.dw = 0.0;
