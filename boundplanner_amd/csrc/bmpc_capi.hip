@@ -29,6 +29,7 @@ extern "C" hipError_t bmpc_pipe_launch_retire_admit(const PipeArgsH* A, int n_ma
 // (device pointers: list, its length); enqueues the caller's post-processing / next-problem kernels on the stream
 typedef int (*bmpc_retire_hook)(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream);
 extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int* was_lat);
+extern "C" hipError_t bmpc_pipe_launch_pick(PipeArgsH* A0, PipeArgsH* A1, const int* prio, int n_max, hipStream_t st);
 extern "C" hipError_t bmpc_pipe_launch_mult(const PipeArgsH* A, hipStream_t st);
 extern "C" void bmpc_pipe_build_table(int* tbl);
 extern "C" size_t bmpc_pipe_state_bytes(void);
@@ -45,9 +46,15 @@ struct bmpc_handle {
     int slot_major = [] { const char* e = getenv("BMPC_LAYOUT"); return e ? atoi(e) : 1; }();
     double* d_pipe = nullptr;      // one slab: SoA iterate/row arrays, stage records, gains, partials
     void* d_pipe_st = nullptr;     // InstState[cap]
-    int* d_pipe_lists = nullptr;   // 8 lists + the slot -> row map of cap ints each + NCNT counters
+    int* d_pipe_lists = nullptr;   // 8 lists + the slot -> row map of cap ints each + NCNT counters; then the same block again for
+                                   // the fast lane of the closed loop without lock step (pipe_solve)
     int* d_pipe_tbl = nullptr;     // scatter table of the stage record
-    int* h_cnt = nullptr;          // pinned host copy of the counters
+    int* h_cnt = nullptr;          // pinned host copy of the counters (2 x NCNT: bulk lane, fast lane)
+    // closed loop without lock step, two lanes: streams of the fast lane / of the bulk lane (null: the caller's stream), fork / join events
+    hipStream_t st_fast = nullptr, st_bulk = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join_f = nullptr, ev_join_b = nullptr;
+    int lane_cfg[4] = {0, 0, 0, 0};         // [0] 1 = streams exist; what they were created for: [1] reserved CUs [2] fast lane on all CUs
+    double lane_stats[8] = {0};    // last hooked solve: [0] bursts [1] fast super-steps [2] bulk super-steps [3] sum of the fast lane's instance counts at its round ends [6] fast-lane rounds
     int last_steps = 0;
     PipeArgsH last_args;           // arguments of the most recent pipeline solve (its final iterate stays in the workspace)
     bool last_valid = false;
@@ -164,7 +171,7 @@ extern "C" int bmpc_create(const bmpc_opts* o, bmpc_handle** out) {
         bmpc_pipe_build_table(tbl.data());
         HIPCHK(h, hipMalloc((void**)&h->d_pipe_tbl, tbl.size() * sizeof(int)));
         HIPCHK(h, hipMemcpy(h->d_pipe_tbl, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(h, hipHostMalloc((void**)&h->h_cnt, NCNT * sizeof(int)));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_cnt, 2 * NCNT * sizeof(int)));
     }
     HIPCHK(h, hipStreamCreate(&h->stream));
     HIPCHK(h, hipEventCreate(&h->ev0));
@@ -211,6 +218,8 @@ extern "C" void bmpc_destroy(bmpc_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
+    for (hipEvent_t e : {h->ev_fork, h->ev_join_f, h->ev_join_b}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {h->st_fast, h->st_bulk}) if (s) (void)hipStreamDestroy(s);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -291,7 +300,7 @@ static int pipe_ensure(bmpc_handle* h, int B) {
     const size_t n = pipe_workspace_doubles(cap, h->o.N, h->slot_major);
     HIPCHK(h, hipMalloc((void**)&h->d_pipe, n * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_pipe_st, (size_t)cap * bmpc_pipe_state_bytes()));
-    HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, (9 * (size_t)cap + NCNT) * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&h->d_pipe_lists, 2 * (9 * (size_t)cap + NCNT) * sizeof(int)));
     h->pipe_cap = cap;
     return 0;
 }
@@ -313,10 +322,41 @@ static void ric_collect(bmpc_handle* h) {        // the stream is idle: every re
     h->ric_pending = 0;
 }
 
+// Two-lane closed loop (pipe_solve with a retire hook and priority flags): streams of the lanes.  reserved_cus > 0: the bulk lane's
+// stream is masked off that many CUs and the fast lane's stream runs on them alone (fast_all: on every CU) -- the fast lane's
+// small grids never queue behind the bulk kernels' workgroups; reserved_cus == 0: the bulk lane stays on the caller's stream, the
+// fast lane gets a stream of the highest priority.
+static int lanes_ensure(bmpc_handle* h, int reserved_cus, int fast_all) {
+    if (h->lane_cfg[0] && h->lane_cfg[1] == reserved_cus && h->lane_cfg[2] == fast_all) return 0;
+    for (hipStream_t* s : {&h->st_fast, &h->st_bulk}) if (*s) { (void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr; }
+    if (!h->ev_fork) {
+        HIPCHK(h, hipEventCreate(&h->ev_fork));
+        HIPCHK(h, hipEventCreate(&h->ev_join_f));
+        HIPCHK(h, hipEventCreate(&h->ev_join_b));
+    }
+    if (reserved_cus > 0 && reserved_cus < h->n_cu) {
+        const int words = (h->n_cu + 31) / 32;
+        std::vector<uint32_t> fast(words, 0u), bulk(words, 0u);
+        for (int c = 0; c < h->n_cu; c++) {
+            if (c < reserved_cus) fast[c / 32] |= 1u << (c % 32); else bulk[c / 32] |= 1u << (c % 32);
+            if (fast_all) fast[c / 32] |= 1u << (c % 32);
+        }
+        HIPCHK(h, hipExtStreamCreateWithCUMask(&h->st_fast, (uint32_t)words, fast.data()));
+        HIPCHK(h, hipExtStreamCreateWithCUMask(&h->st_bulk, (uint32_t)words, bulk.data()));
+    } else {
+        int lo = 0, hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->st_fast, hipStreamNonBlocking, hi));
+    }
+    h->lane_cfg[0] = 1; h->lane_cfg[1] = reserved_cus; h->lane_cfg[2] = fast_all;
+    return 0;
+}
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
                       const double* d_p, double* d_x, double* d_g, double* d_f, int* d_iters, int* d_status,
                       double* d_viol, hipStream_t st, bmpc_retire_hook hook = nullptr, void* hook_ctx = nullptr,
-                      const int* d_cont = nullptr) {
+                      const int* d_cont = nullptr, const int* d_prio = nullptr, int prio_max = 0) {
     WEDGED_FAIL(h);
     int rc = pipe_ensure(h, B);
     if (rc) return rc;
@@ -341,12 +381,34 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     A.cont = d_cont;
     h->last_valid = false;
     if (hook && B > cap) { h->err = "closed-loop solve: more rollouts than workspace slots"; return 1; }
-    auto retire = [&](int n_max, int refill) -> int {
-        HIPCHK(h, bmpc_pipe_launch_retire_out(&A, n_max, st));
-        if (hook) { if (int r = hook(hook_ctx, A.L.done, A.L.cnt + 8, n_max, (void*)st)) { h->err = "retire hook failed"; return r; } }
-        HIPCHK(h, bmpc_pipe_launch_retire_admit(&A, n_max, refill, st));
+    auto retire_lane = [&](PipeArgsH& AA, int n_max, int refill, hipStream_t s_) -> int {
+        HIPCHK(h, bmpc_pipe_launch_retire_out(&AA, n_max, s_));
+        if (hook) { if (int r = hook(hook_ctx, AA.L.done, AA.L.cnt + 8, n_max, (void*)s_)) { h->err = "retire hook failed"; return r; } }
+        HIPCHK(h, bmpc_pipe_launch_retire_admit(&AA, n_max, refill, s_));
         return 0;
     };
+    auto retire = [&](int n_max, int refill) -> int { return retire_lane(A, n_max, refill, st); };
+    // Closed loop without lock step, TWO LANES (round 4).  With one lane every live rollout iterates at the cadence of a full
+    // super-step (2.5 ms at 4096 x N=30), and the run lasts as long as the slowest rollout's iterations (13 k of them on
+    // configs[4]) times that.  Here the rollouts that lag behind (d_prio, at most prio_max: set by the caller's hook from the
+    // steps they have left) iterate in a lane of their own -- lists and counters of its own over the SAME slots and state --
+    // on a second stream, several super-steps of a few dozen instances per bulk super-step.  Per-instance arithmetic does not
+    // depend on the lane, so the log stays bitwise that of the lock-step loop.
+    const bool two = hook && d_prio && prio_max > 0;
+    PipeArgsH A1 = A;
+    hipStream_t sb = st, sf = st;
+    const int lane_burst = env_int("BMPC_FAST_BURST", 4);  // super-steps of the bulk lane per burst
+    const int lane_k = env_int("BMPC_FAST_K", 3);          // super-steps of the fast lane per round
+    if (two) {
+        if (int r = lanes_ensure(h, env_int("BMPC_FAST_CUS", 0), env_int("BMPC_FAST_ALL", 0))) return r;
+        sf = h->st_fast; if (h->st_bulk) sb = h->st_bulk;
+        int* L1 = L + 9 * (size_t)cap + NCNT;
+        A1.L.eval = L1; A1.L.step = L1 + cap; A1.L.trial = L1 + 2 * (size_t)cap; A1.L.eval_next = L1 + 3 * (size_t)cap;
+        A1.L.trial_next = L1 + 4 * (size_t)cap; A1.L.done = L1 + 5 * (size_t)cap; A1.L.admit = L1 + 6 * (size_t)cap;
+        A1.L.curv = L1 + 8 * (size_t)cap; A1.L.cnt = L1 + 9 * (size_t)cap;
+        HIPCHK(h, hipMemsetAsync(A1.L.cnt, 0, NCNT * sizeof(int), st));
+    }
+    if (hook) for (double& v : h->lane_stats) v = 0;
     // The workspace is a pool of `cap` slots.  B <= cap: every instance has its slot (slot = row).  B > cap (a handle
     // created with pool_slots): the rows stream through the pool -- a slot whose instance has finished is retired
     // (outputs written) and takes the next row at the start of the following super-step, so the kernels keep working on
@@ -373,17 +435,50 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
             // problem), re-admission -- with grids sized by that count; nothing is launched when nobody finished.  (Round 3 ran
             // the whole retirement sequence before every super-step with grids sized for all rollouts: ~1 ms of empty launches
             // per super-step.)  A finished rollout waits at most one burst for its next problem.
-            for (int i = 0; i < burst; i++, steps++) HIPCHK(h, step_timed(h, &A, n_act, st));
-            HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
-            if (int r = wait_stream(h, st)) return r;
-            ric_collect(h);
-            const int n_done = h->h_cnt[8];
-            if (n_done > 0) { if (int r = retire(n_done, 1)) return r; }
-            retired = h->h_cnt[7];                   // rows whose rollout has ended (counted by k_admit: one burst behind)
-            if (n_done > 0 && retired + n_done >= B) {      // possibly the last ones: their retirement decides whether anybody goes on
+            if (two && steps >= 8) {
+                // deal the live instances out between the lanes; the bulk lane then runs its burst while the fast lane goes through
+                // rounds of its own -- a few super-steps, counters back, retirement of ITS finished rollouts (hook and re-admission on
+                // the fast lane's stream: they touch those rollouts only) -- until the bulk burst has ended
+                const int n1 = n_act < prio_max ? n_act : prio_max;
+                HIPCHK(h, bmpc_pipe_launch_pick(&A, &A1, d_prio, n_act, st));
+                HIPCHK(h, hipEventRecord(h->ev_fork, st));
+                HIPCHK(h, hipStreamWaitEvent(sf, h->ev_fork, 0));
+                if (sb != st) HIPCHK(h, hipStreamWaitEvent(sb, h->ev_fork, 0));
+                for (int i = 0; i < lane_burst; i++, steps++) HIPCHK(h, step_timed(h, &A, n_act, sb));
+                HIPCHK(h, hipEventRecord(h->ev_join_b, sb));
+                h->lane_stats[0] += 1; h->lane_stats[2] += lane_burst;
+                for (int round = 0;; round++) {
+                    for (int i = 0; i < lane_k; i++) HIPCHK(h, bmpc_pipe_launch_step(&A1, n1, sf, nullptr, nullptr, nullptr));
+                    HIPCHK(h, hipMemcpyAsync(h->h_cnt + NCNT, A1.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, sf));
+                    if (int r = wait_stream(h, sf)) return r;
+                    const int live1 = h->h_cnt[NCNT + 0] + h->h_cnt[NCNT + 2], nd1 = h->h_cnt[NCNT + 8];
+                    h->lane_stats[1] += lane_k; h->lane_stats[3] += live1 + nd1; h->lane_stats[6] += 1;
+                    const hipError_t q = hipEventQuery(h->ev_join_b);
+                    if (q != hipErrorNotReady) { HIPCHK(h, q); break; }          // the bulk burst is over: join (what the fast lane finished last is retired below)
+                    if (live1 + nd1 == 0) break;                                  // nobody in the fast lane
+                    if (nd1 > 0) { if (int r = retire_lane(A1, nd1, 1, sf)) return r; }
+                }
+                HIPCHK(h, hipEventRecord(h->ev_join_f, sf));
+                HIPCHK(h, hipStreamWaitEvent(st, h->ev_join_f, 0));
+                if (sb != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join_b, 0));
+            } else {
+                for (int i = 0; i < burst; i++, steps++) HIPCHK(h, step_timed(h, &A, n_act, st));
+            }
+            auto read_counters = [&]() -> int {
                 HIPCHK(h, hipMemcpyAsync(h->h_cnt, A.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
-                if (int r = wait_stream(h, st)) return r;
-                retired = h->h_cnt[7];
+                if (two) HIPCHK(h, hipMemcpyAsync(h->h_cnt + NCNT, A1.L.cnt, NCNT * sizeof(int), hipMemcpyDeviceToHost, st));
+                else for (int i = 0; i < NCNT; i++) h->h_cnt[NCNT + i] = 0;
+                return wait_stream(h, st);
+            };
+            if (int r = read_counters()) return r;
+            ric_collect(h);
+            const int n_done = h->h_cnt[8], n_done1 = h->h_cnt[NCNT + 8];
+            if (n_done > 0) { if (int r = retire(n_done, 1)) return r; }
+            if (n_done1 > 0) { if (int r = retire_lane(A1, n_done1, 1, st)) return r; }
+            retired = h->h_cnt[7] + h->h_cnt[NCNT + 7];      // rows whose rollout has ended (counted by k_admit: one burst behind)
+            if (n_done + n_done1 > 0 && retired + n_done + n_done1 >= B) {      // possibly the last ones: their retirement decides whether anybody goes on
+                if (int r = read_counters()) return r;
+                retired = h->h_cnt[7] + h->h_cnt[NCNT + 7];
             }
             n_act = B - retired;
             h->n_active.store(B - retired);
@@ -407,7 +502,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
         h->n_active.store(B - retired);
     }
     h->last_steps = steps;
-    h->ric_sweeps[0] = h->h_cnt[11]; h->ric_sweeps[1] = h->h_cnt[12];
+    h->ric_sweeps[0] = h->h_cnt[11] + (two ? h->h_cnt[NCNT + 11] : 0); h->ric_sweeps[1] = h->h_cnt[12] + (two ? h->h_cnt[NCNT + 12] : 0);
     HIPCHK(h, hipEventRecord(h->ev1, st));
     // the outputs are complete and the per-handle workspace is free when the call returns (the loop above synchronised)
     if (int r = wait_stream(h, st)) return r;
@@ -442,13 +537,20 @@ extern "C" int bmpc_solve_dev(bmpc_handle* h, int B, const double* d_x0, const d
 // place by `hook`; a row is solved again while d_cont[row] != 0.  Internal to the library (bmpc_loop.hip).
 extern "C" int bmpc_solve_dev_hooked(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
                                      const double* d_p, double* d_x, double* d_f, int* d_iters, int* d_status, double* d_viol,
-                                     void* stream, bmpc_retire_hook hook, void* hook_ctx, const int* d_cont) {
+                                     void* stream, bmpc_retire_hook hook, void* hook_ctx, const int* d_cont,
+                                     const int* d_prio, int prio_max) {
     if (!h || B <= 0 || !hook || !d_cont) return 1;
     int wrc = bmpc_wait(h);
     if (wrc) return wrc;
     BUSY_OR_FAIL(h, "bmpc_loop_run_async");
     HIPCHK(h, hipSetDevice(h->o.device));
-    return pipe_solve(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, nullptr, d_f, d_iters, d_status, d_viol, (hipStream_t)stream, hook, hook_ctx, d_cont);
+    return pipe_solve(h, B, d_x0, d_lbx, d_ubx, d_p, d_x, nullptr, d_f, d_iters, d_status, d_viol, (hipStream_t)stream, hook, hook_ctx, d_cont, d_prio, prio_max);
+}
+// lane statistics of the last two-lane hooked solve (tools/closed_loop_device.py): see bmpc_handle::lane_stats
+extern "C" int bmpc_debug_lane_stats(bmpc_handle* h, double* out8) {
+    if (!h || !out8) return 1;
+    for (int i = 0; i < 8; i++) out8[i] = h->lane_stats[i];
+    return 0;
 }
 
 // Asynchronous form of bmpc_solve_dev: returns at once; the data-dependent launch sequence is driven by

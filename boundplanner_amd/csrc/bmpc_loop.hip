@@ -104,6 +104,33 @@ __global__ __launch_bounds__(256) void bmpc_loop_k_keep(int R, int N, const doub
     if (S[(size_t)r * LS_SIZE + LS_accept] != 0.0) prev[o] = x[o];
 }
 
+// bmpc_loop_run_async, two lanes: priority flags of the rollouts for the solver (bmpc_capi.hip, pipe_solve).  The rollouts that
+// lag behind -- most steps left -- are flagged, as many whole "steps left" classes from the top as fit prio_max; nobody while the
+// class of the laggards alone is larger (at the start every rollout has all its steps left).  One workgroup.
+__global__ __launch_bounds__(1024) void bmpc_loop_k_prio(int R, const int* steps_left, int* prio, int prio_max) {
+    __shared__ int hist[1024];
+    __shared__ int s_max, s_thr;
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    int m = 0;
+    for (int r = tid; r < R; r += 1024) m = max(m, steps_left[r]);
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const int base = s_max - 1023;                 // classes below `base` share bin 0 (never reached before the budget is spent unless all fit)
+    for (int r = tid; r < R; r += 1024) { const int v = steps_left[r]; if (v > 0) atomicAdd(&hist[max(v - base, 0)], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int cum = 0, thr = 1024;
+        for (int b = 1023; b >= 0; b--) { if (cum + hist[b] > prio_max) break; cum += hist[b]; thr = b; }
+        s_thr = thr;
+    }
+    __syncthreads();
+    const int thr = s_thr;
+    for (int r = tid; r < R; r += 1024) { const int v = steps_left[r]; prio[r] = (v > 0 && max(v - base, 0) >= thr) ? 1 : 0; }
+}
+
 struct bmpc_loop {
     bmpc_handle* h = nullptr;
     int R = 0, N = 0, n_w = 0, dev = 0;
@@ -117,6 +144,8 @@ struct bmpc_loop {
     int* d_scene_i = nullptr;      // nrows | nv
     double* d_colres = nullptr;
     int *d_steps_left = nullptr, *d_cont = nullptr;    // bmpc_loop_run_async
+    int* d_prio = nullptr;         // ... its fast lane: [R] 1 = the rollout lags behind (bmpc_loop_k_prio)
+    int prio_max = 0;
     int* d_rec_slot = nullptr;     // [R] index of the rollout's record in a step's block, or -1 (bmpc_loop_set_record)
     int n_rec = 0;
     double* d_rec = nullptr;       // [steps][n_rec][lp_rec_doubles(N)] of the last bmpc_loop_run
@@ -189,6 +218,7 @@ extern "C" void bmpc_loop_destroy(bmpc_loop* L) {
     if (L->d_colres) (void)hipFree(L->d_colres);
     if (L->d_steps_left) (void)hipFree(L->d_steps_left);
     if (L->d_cont) (void)hipFree(L->d_cont);
+    if (L->d_prio) (void)hipFree(L->d_prio);
     if (L->e0) (void)hipEventDestroy(L->e0);
     if (L->e1) (void)hipEventDestroy(L->e1);
     if (L->h) bmpc_handle_release(L->h);     // a bmpc_destroy deferred because of this loop runs now
@@ -420,14 +450,20 @@ extern "C" int bmpc_loop_run(bmpc_loop* L, int nsteps, double* log, float* ms_to
 typedef int (*bmpc_retire_hook)(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream);
 extern "C" int bmpc_solve_dev_hooked(bmpc_handle* h, int B, const double* d_x0, const double* d_lbx, const double* d_ubx,
                                      const double* d_p, double* d_x, double* d_f, int* d_iters, int* d_status, double* d_viol,
-                                     void* stream, bmpc_retire_hook hook, void* hook_ctx, const int* d_cont);
+                                     void* stream, bmpc_retire_hook hook, void* hook_ctx, const int* d_cont,
+                                     const int* d_prio, int prio_max);
 
 static int loop_retire_hook(void* ctx, const int* d_done, const int* d_n_done, int n_max, void* stream) {
     bmpc_loop* L = (bmpc_loop*)ctx;
     hipStream_t st = (hipStream_t)stream;
     if (n_max > L->R) n_max = L->R;          // the solver's slot count may exceed the rollouts (workspace sized by max_batch)
     if (int rc = launch_finish(L, st, n_max, L->async_log, d_done, d_n_done, L->d_steps_left, L->d_cont, L->async_nsteps)) return rc;
-    return launch_prepare(L, st, n_max, d_done, d_n_done);
+    if (int rc = launch_prepare(L, st, n_max, d_done, d_n_done)) return rc;
+    if (L->prio_max > 0) {                   // the steps left have changed: who lags behind now
+        hipLaunchKernelGGL(bmpc_loop_k_prio, dim3(1), dim3(1024), 0, st, L->R, (const int*)L->d_steps_left, L->d_prio, L->prio_max);
+        LCHK(L, hipGetLastError());
+    }
+    return 0;
 }
 
 extern "C" int bmpc_loop_run_async(bmpc_loop* L, int nsteps, double* log, float* ms_total) {
@@ -437,7 +473,13 @@ extern "C" int bmpc_loop_run_async(bmpc_loop* L, int nsteps, double* log, float*
     if (!L->d_steps_left) {
         LCHK(L, hipMalloc((void**)&L->d_steps_left, (size_t)L->R * sizeof(int)));
         LCHK(L, hipMalloc((void**)&L->d_cont, (size_t)L->R * sizeof(int)));
+        LCHK(L, hipMalloc((void**)&L->d_prio, (size_t)L->R * sizeof(int)));
     }
+    // fast lane for the rollouts that lag behind: at most BMPC_FAST_LANE of them.  Off unless asked for: measured on configs[4]
+    // (EXPERIMENTS.md) it does not pay yet -- a super-step of a few dozen instances beside the bulk lane takes 0.85 - 1.1 ms
+    // (0.64 ms on an empty GPU), no faster than the bulk lane's own once half of the rollouts have finished
+    { const char* e = getenv("BMPC_FAST_LANE"); L->prio_max = e ? atoi(e) : 0; }
+    LCHK(L, hipMemsetAsync(L->d_prio, 0, (size_t)L->R * sizeof(int), L->st));
     std::vector<int> left((size_t)L->R, nsteps);
     LCHK(L, hipMemcpyAsync(L->d_steps_left, left.data(), left.size() * sizeof(int), hipMemcpyHostToDevice, L->st));
     LCHK(L, hipMemsetAsync(L->d_cont, 0, (size_t)L->R * sizeof(int), L->st));
@@ -447,7 +489,7 @@ extern "C" int bmpc_loop_run_async(bmpc_loop* L, int nsteps, double* log, float*
     LCHK(L, hipEventRecord(L->e0, L->st));
     if (int rc = launch_prepare(L, L->st, L->R)) return rc;         // step 0 of every rollout
     int rc = bmpc_solve_dev_hooked(L->h, L->R, L->d_x0, L->d_lbx, L->d_ubx, L->d_p, L->d_x, L->d_f, L->d_iters, L->d_status, L->d_viol,
-                                   (void*)L->st, loop_retire_hook, L, L->d_cont);
+                                   (void*)L->st, loop_retire_hook, L, L->d_cont, L->prio_max > 0 ? L->d_prio : nullptr, L->prio_max);
     if (rc != 0) { L->err = std::string("bmpc_solve_dev_hooked: ") + bmpc_last_error(L->h); return rc; }
     LCHK(L, hipEventRecord(L->e1, L->st));
     LCHK(L, hipStreamSynchronize(L->st));

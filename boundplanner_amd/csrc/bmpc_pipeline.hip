@@ -119,6 +119,25 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_mult(PipeArgsH H) { 
 __global__ __launch_bounds__(64) void bmpc_k_mult_sweep(PipeArgsH H) { k_mult_sweep_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 __global__ __launch_bounds__(64) void bmpc_k_fin(PipeArgsH H) { k_fin_body(DV(H), blockIdx.x * 64 + threadIdx.x); }
 
+// Closed loop without lock step, two lanes (bmpc_capi.hip, pipe_solve): the live instances -- eval and trial lists of both lanes --
+// are dealt out again between the bulk lane H0 and the fast lane H1 by the priority flag of their row (prio[row] != 0: the
+// rollout lags behind, its instances iterate at the cadence of a nearly empty GPU).  Destination: the *_next lists (empty between
+// super-steps); bmpc_k_rotate of either lane then makes them current.  Per-instance arithmetic does not depend on the lane.
+__global__ __launch_bounds__(64) void bmpc_k_pick(PipeArgsH H0, PipeArgsH H1, const int* prio) {
+    const PipeArgs& A0 = DV(H0);
+    const PipeArgs& A1 = DV(H1);
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    for (int src = 0; src < 4; src++) {
+        const PipeArgs& S = (src & 1) ? A1 : A0;
+        const bool trial = src >= 2;
+        if (e >= S.L.cnt[trial ? 2 : 0]) continue;
+        const int b = (trial ? S.L.trial : S.L.eval)[e];
+        const PipeArgs& T = prio[A0.src[b]] ? A1 : A0;
+        if (trial) { const int pos = BMPC_ATOMIC_INC(T.L.cnt + 4); T.L.trial_next[pos] = b; }
+        else { const int pos = BMPC_ATOMIC_INC(T.L.cnt + 3); T.L.eval_next[pos] = b; }
+    }
+}
+
 #define LAUNCH(kern, nb, nt)                                            \
     do {                                                                \
         if ((nb) > 0) hipLaunchKernelGGL(kern, dim3(nb), dim3(nt), 0, st, *A); \
@@ -196,6 +215,18 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
     t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;
+    return hipGetLastError();
+}
+
+// two-lane closed loop: deal the (at most n_max) live instances out between the lanes; swaps the double-buffered lists of both
+extern "C" hipError_t bmpc_pipe_launch_pick(PipeArgsH* A0, PipeArgsH* A1, const int* prio, int n_max, hipStream_t st) {
+    if (n_max <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bmpc_k_pick, dim3((n_max + 63) / 64), dim3(64), 0, st, *A0, *A1, prio);
+    for (PipeArgsH* A : {A0, A1}) {
+        hipLaunchKernelGGL(bmpc_k_rotate, dim3(1), dim3(64), 0, st, *A);
+        int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;
+        t = A->L.trial; A->L.trial = A->L.trial_next; A->L.trial_next = t;
+    }
     return hipGetLastError();
 }
 

@@ -172,6 +172,10 @@ int bmpc_debug_inst_state(bmpc_handle* h, int B, double* out);
  * in out6[3..5].  bench.py derives its roofline line from these. */
 int bmpc_debug_time_ric(bmpc_handle* h, int on);
 int bmpc_debug_ric_stats(bmpc_handle* h, double* out6);
+/* Measurement: the two lanes of the most recent bmpc_loop_run_async on this handle (see there): {bursts, fast-lane super-steps,
+ * bulk-lane super-steps, summed fast-lane instance counts at the ends of its rounds, 0, 0, fast-lane rounds, 0}; all zero when the
+ * run had one lane. */
+int bmpc_debug_lane_stats(bmpc_handle* h, double* out8);
 /* Diagnostic: keeps the handle's stream busy for `ms` milliseconds (at most 10 s, then the kernel ends by itself), so that the
  * watchdog (bmpc_opts.watchdog_ms) can be exercised without a kernel that really hangs. */
 int bmpc_debug_spin(bmpc_handle* h, int ms);

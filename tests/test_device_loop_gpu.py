@@ -376,15 +376,33 @@ def test_async_closed_loop_equals_lock_step():
     boxes, _, _, _ = scenes.example_scene()
     for obstacles in (None, scenes.boxes_to_sets(boxes[4:8])):
         logs = []
-        for mode in ("run", "run_async"):
+        # run_async: one lane (default), and two lanes (BMPC_FAST_LANE: the rollouts that lag behind iterate in a fast lane of their
+        # own, bmpc_capi.hip) -- default knobs, a small fast lane with short bursts, the lanes on disjoint sets of CUs
+        variants = [("run", {}), ("run_async", {"BMPC_FAST_LANE": "64"}), ("run_async", {}), ("run_async", {"BMPC_FAST_LANE": "7", "BMPC_FAST_BURST": "1"}),
+                    ("run_async", {"BMPC_FAST_LANE": "24", "BMPC_FAST_CUS": "32"})]
+        lanes = []
+        for mode, env in variants:
             loop = _config4_loop(be, q_start, fs, fg, params, np.arange(R))
             if obstacles is not None:
                 loop.set_obstacles(*obstacles)
-            logs.append(getattr(loop, mode)(steps))
+            old_env = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                logs.append(getattr(loop, mode)(steps))
+            finally:
+                for k, v in old_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            lanes.append(be.lane_stats() if mode == "run_async" else None)
         assert np.isfinite(logs[0]).all()
         L = loop.LOG
         assert len(set(logs[0][:, :, L["iters"]].ravel().tolist())) > 3          # the solves do take different numbers of iterations
-        assert np.array_equal(logs[0], logs[1])
+        for lg in logs[1:]:
+            assert np.array_equal(logs[0], lg)
+        assert lanes[1]["fast_super_steps"] > 0 and lanes[1]["fast_lane_instances_mean"] > 0      # the fast lane did run, with instances in it
+        assert lanes[2]["bursts"] == 0                                                            # ... and not by default
 
 
 def test_config0_plan_then_track_with_replanning_on_the_device_loop(golden_dir):

@@ -147,6 +147,11 @@ def run(args, progress=True):
         "iters_sum_of_per_step_max": int(it.max(axis=1).sum()), "iters_per_rollout_total_max": int(it.sum(axis=0).max()),
         "iters_per_rollout_total_mean": float(it.sum(axis=0).mean()),
     }
+    if args.async_:
+        out["lanes"] = dict(bes[0].lane_stats(), fast_lane_max=int(os.environ.get("BMPC_FAST_LANE", "0")),
+                            reserved_cus=int(os.environ.get("BMPC_FAST_CUS", "0")))
+        tot = it.sum(axis=0)
+        out["iters_per_rollout_total_quantiles"] = {f"p{q}": float(np.percentile(tot, q)) for q in (50, 75, 90, 95, 98, 99)}
     if args.dump_failing and G == 1:
         sol = loop.solution()
         x0_, lbx_, ubx_, p_ = loop.problem()
