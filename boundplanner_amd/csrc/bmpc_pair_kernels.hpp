@@ -1071,12 +1071,9 @@ BMPC_INL void ls0_instance(const PipeArgs& A, int b) {
 // filter acceptance test of one instance's trial point (Waechter & Biegler 2006, Sec. 2.3) from the per-pair partials of
 // k_trial; returns true when the trial becomes the iterate.  A rejected instance goes to the next super-step's trial list
 // only when k_trial does not try again itself (`requeue`)
-BMPC_INL bool ls_instance(const PipeArgs& A, int b, bool requeue) {
-    const int N = A.N;
+// (f1, th1, ls1: objective, infeasibility and sum log t of the trial point with step length st->alpha)
+BMPC_INL bool ls_decide(const PipeArgs& A, int b, double f1, double th1, double ls1, bool requeue) {
     GST st = A.st + b;
-    GCD P = A.part + pair_of(A, b, 1);
-    double f1 = 0, th1 = 0, ls1 = 0;
-    for (int k = 0; k < N - 1; k++) { f1 += P[PT_F1 * A.NP + k]; th1 += P[PT_TH1 * A.NP + k]; ls1 += P[PT_LS1 * A.NP + k]; }
     const double mu = st->mu, th0 = st->th0, D = st->D, phi0 = st->phi0, alpha = st->alpha;
     double phi1 = f1 - mu * ls1;
     bool acc = (th1 <= st->theta_max);
@@ -1116,6 +1113,12 @@ BMPC_INL bool ls_instance(const PipeArgs& A, int b, bool requeue) {
         A.L.trial_next[pos] = b;
     }
     return false;
+}
+BMPC_INL bool ls_instance(const PipeArgs& A, int b, bool requeue) {      // the trial point's pieces from the per-pair partials, in pair order
+    GCD P = A.part + pair_of(A, b, 1);
+    double f1 = 0, th1 = 0, ls1 = 0;
+    for (int k = 0; k < A.N - 1; k++) { f1 += P[PT_F1 * A.NP + k]; th1 += P[PT_TH1 * A.NP + k]; ls1 += P[PT_LS1 * A.NP + k]; }
+    return ls_decide(A, b, f1, th1, ls1, requeue);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1313,8 +1316,11 @@ struct TrialVisitor {
 // One part (ROLES: stage.hpp WR_*) of the trial point of pair (b, k): trial slacks, multiplier update, the part's share of theta and of
 // sum log t; WR_POSE also writes the trial zeta and adds the dynamics defect and the objective.
 struct TrialPart { double f, th, thr, lp; int le; };
+// t_out / zeta_out: where the trial slacks and the trial zeta go, indexed like the workspace arrays (field * A.NP + pi); null = the other
+// copy of the double-buffered arrays
 template <int ROLES>
-BMPC_INL void trial_part(const PipeArgs& A, PGP pg, int b, int k, size_t pi, bool live, bool dual, double alpha, int flip, TrialPart& R) {
+BMPC_INL void trial_part(const PipeArgs& A, PGP pg, int b, int k, size_t pi, bool live, bool dual, double alpha, int flip, TrialPart& R,
+                         GD t_out = nullptr, GD zeta_out = nullptr) {
     const int N = A.N, n_w = 44 * N + 6;
     const bool term = (k == N - 1);
     const DynC dc = make_dync(A.o.dt);
@@ -1325,14 +1331,14 @@ BMPC_INL void trial_part(const PipeArgs& A, PGP pg, int b, int k, size_t pi, boo
     BMPC_UNROLL
     for (int i = 0; i < NZ; i++) S.zeta[i] = zc[(size_t)i * A.NP + pi] + alpha * A.dz[(size_t)i * A.NP + pi];
     if constexpr ((ROLES & WR_POSE) != 0) {
-        GD zo = oth_zeta(A, flip);
+        GD zo = zeta_out ? zeta_out : oth_zeta(A, flip);
         if (live)
             BMPC_UNROLL
             for (int i = 0; i < NZ; i++) zo[(size_t)i * A.NP + pi] = S.zeta[i];
     }
     nat_all(S.zeta, dc, S.y);
     TrialVisitor V;
-    V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = oth_t(A, flip);
+    V.A = &A; V.pi = pi; V.valid = live; V.alpha = alpha; V.thr = 0.0; V.lp = 1.0; V.le = 0; V.tc = cur_t(A, flip); V.tn_out = t_out ? t_out : oth_t(A, flip);
     V.dual = dual; V.ad = A.st[b].ad; V.mu = A.st[b].mu; V.zc = cur_z(A, flip); V.zn_out = oth_z(A, flip);
     // The walk in three phases, each with its own inputs: the box rows need the natural coordinates only and run BEFORE kinematics
     // and reference context exist; the pose rows need the context; the collision points need the joint origins only.  (One walk
@@ -1451,6 +1457,84 @@ BMPC_KBODY void k_trial_body_t(const PipeArgs& A, int wave, int tid, LDSD* lds_p
     }
 }
 BMPC_KBODY void k_trial_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par) { k_trial_body_t<1>(A, wave, lane, lds_par); }
+
+// ------------------------------------------------------------------------------------------
+// k_trial_spec (tail regime: fewer groups of pairs than CUs): the step lengths of a line search are known before any of them
+// is tried -- alpha, alpha / 2, alpha / 4, ... -- and their acceptance tests do not depend on each other (the filter changes only
+// when a point is accepted).  A workgroup of TRIAL_SPEC wavefronts per group of pairs evaluates that many trial points side by side,
+// the wavefront of the first one into the other copy of the double-buffered arrays as k_trial does, the others into candidate
+// records (the gain copies of the speculative Riccati attempts: dead once k_fwd has run); the lane of stage 1 then walks the tests
+// in the order of the sequential search (ls_decide, the same code), and the candidate of the first accepted step length is copied
+// over.  Every trial point and every test is the arithmetic k_trial would have done, one after the other: bitwise the same
+// iterate, at one trial's latency (+ a copy) instead of up to ten.  Slot-major layout only (candidate records are indexed like a slot's
+// own arrays).  Always ends the search (trial_repeats is scheduling only).  tid = thread index in the workgroup.
+// ------------------------------------------------------------------------------------------
+constexpr int TRIAL_SPEC = 4;
+static_assert(TRIAL_SPEC - 1 <= RIC_NATT - 1 && NSLOT + NZ <= KREC, "candidate trial points fit the speculative gain copies");
+static_assert(TRIAL_SPEC * 64 * 3 + IPW_MAX <= TRIAL_SPEC * 64 * TRIAL_COMB, "k_trial_spec's LDS fits trial_lds_doubles(N, 4)");
+BMPC_KBODY void k_trial_spec_body(const PipeArgs& A, int wave, int tid, LDSD* lds_par) {
+    const int count = A.L.cnt[2], N = A.N;
+    if (wave * ipw_of(N) >= count) return;
+    const int lane = tid & 63, role = tid >> 6;
+    const PairMap m = pair_map(A, A.L.trial, count, wave, lane);
+    const int ipw = ipw_of(N), S = N - 1;
+    (void)stage_params<true, 64 * TRIAL_SPEC>(A, A.L.trial, count, wave, tid, m, lds_par);
+    LDSD* ended = lds_par + (size_t)ipw * NPARL;         // [IPW_MAX] 1: the instance's line search has ended (or no such instance)
+    LDSD* comb = ended + IPW_MAX;                        // [trial][lane][3]: f, theta, sum log t of the pair at that trial point
+    LDSD* win = comb + TRIAL_SPEC * 64 * 3;              // [IPW_MAX] which trial of this round became the iterate (-1: none)
+    if (tid < IPW_MAX) ended[tid] = (tid < ipw && wave * ipw + tid < count) ? 0.0 : 1.0;
+    BMPC_SYNC();
+    const int flip = A.st[m.b].flip;                     // (flipped by the accepting test: read once, the instance is dead then)
+    for (int round = 0;; round++) {
+        int b = m.b, k = m.k, li = m.li;
+        BMPC_OPAQUE_I(b); BMPC_OPAQUE_I(k); BMPC_OPAQUE_I(li);
+        const size_t pi = pair_of(A, b, k);
+        PGP pg = lds_par + li * NPARL;
+        const bool live = m.valid && ended[li] == 0.0;
+        const int bt0 = live ? A.st[b].bt : 0;                              // index of this round's first trial in the search
+        const bool mine = live && bt0 + role <= 9;                          // (a search has at most ten trials)
+        double alpha = live ? A.st[b].alpha : 0.0;
+        for (int r = 0; r < role; r++) alpha *= 0.5;                        // (exactly what the sequential search's halvings give)
+        // candidate record of (slot, role): [field][stage], fields 0 .. NSLOT-1 = t, then zeta
+        GD cand = A.kspec + ((size_t)b * (RIC_NATT - 1) + (size_t)(role > 0 ? role - 1 : 0)) * ((size_t)S * KREC);
+        GD t_out = role > 0 ? cand + (size_t)(k - 1) - pi : nullptr;
+        GD zeta_out = role > 0 ? cand + (size_t)NSLOT * S + (size_t)(k - 1) - pi : nullptr;
+        TrialPart R;
+        trial_part<WR_ALL>(A, pg, b, k, pi, mine, mine && role == 0 && round == 0, alpha, flip, R, t_out, zeta_out);
+        {
+            LDSD* c = comb + (size_t)(role * 64 + lane) * 3;
+            c[0] = R.f; c[1] = R.th + R.thr; c[2] = log(R.lp) + (double)R.le * 0.69314718055994530942;
+        }
+        if (tid < IPW_MAX) win[tid] = -1.0;
+        BMPC_FENCE_SYNC();
+        if (live && role == 0 && k == 1) {
+            // the tests in the order of the sequential search; the pieces of a trial point summed in pair order, as ls_instance does
+            for (int j = 0; j < TRIAL_SPEC && bt0 + j <= 9; j++) {
+                double f1 = 0, th1 = 0, ls1 = 0;
+                for (int kk = 0; kk < S; kk++) {
+                    const LDSD* c = comb + (size_t)(j * 64 + lane + kk) * 3;
+                    f1 += c[0]; th1 += c[1]; ls1 += c[2];
+                }
+                if (ls_decide(A, b, f1, th1, ls1, false)) { win[li] = (double)j; ended[li] = 1.0; break; }
+            }
+        }
+        BMPC_FENCE_SYNC();
+        // the accepted candidate becomes the other copy (trial 0 is there already); the workgroup's wavefronts share the fields
+        if (m.valid) {
+            const int w = (int)win[li];
+            if (w > 0) {
+                GCD src = A.kspec + ((size_t)b * (RIC_NATT - 1) + (size_t)(w - 1)) * ((size_t)S * KREC) + (size_t)(k - 1);
+                GD to = oth_t(A, flip), zo = oth_zeta(A, flip);
+                for (int f = role; f < NSLOT; f += TRIAL_SPEC) to[(size_t)f * A.NP + pi] = src[(size_t)f * S];
+                for (int f = role; f < NZ; f += TRIAL_SPEC) zo[(size_t)f * A.NP + pi] = src[(size_t)(NSLOT + f) * S];
+            }
+        }
+        bool left = false;
+        for (int q = 0; q < ipw; q++) left = left || (ended[q] == 0.0);
+        if (!left) break;
+        BMPC_FENCE_SYNC();           // (win / comb are rewritten in the next round)
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // k_out: x in the reference layout, constraint vector g, violation partials

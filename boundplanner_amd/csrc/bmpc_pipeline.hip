@@ -113,6 +113,13 @@ __global__ void bmpc_k_pool_reset(PipeArgsH H, int done_too) { if (threadIdx.x =
 __global__ __launch_bounds__(64 * BMPC_TRIAL_NW, BMPC_TRIAL_WPS) void bmpc_k_trial(PipeArgsH H) {
     k_trial_body_t<BMPC_TRIAL_NW>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
+// the line search of the tail regime: four step lengths side by side, one wavefront (one SIMD) each (bmpc_pair_kernels.hpp)
+__global__ __launch_bounds__(64 * TRIAL_SPEC, 1) void bmpc_k_trial_spec(PipeArgsH H) {
+    k_trial_spec_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+}
+#ifndef BMPC_TRIAL_SPEC_WGS
+#define BMPC_TRIAL_SPEC_WGS 256       // groups of pairs up to which bmpc_k_trial_spec replaces bmpc_k_trial: one workgroup (four SIMDs) per CU (0 = never)
+#endif
 __global__ void bmpc_k_rotate(PipeArgsH H) { if (threadIdx.x == 0 && blockIdx.x == 0) k_rotate_body(DV(H)); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_out(PipeArgsH H) { k_out_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_mult(PipeArgsH H) { k_mult_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
@@ -211,6 +218,10 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     // (BMPC_TRIAL_REPEATS in the environment, read once, overrides bmpc_opts.trial_repeats: A/B runs)
     static const int env_repeats = [] { const char* e = getenv("BMPC_TRIAL_REPEATS"); return e ? atoi(e) : -1; }();
     if (env_repeats >= 0) A->o.trial_repeats = env_repeats;
+    // BMPC_TRIAL_SPEC_WGS (read once; 0 = never): up to that many groups of pairs the step lengths of a line search are tried side by side (slot-major layout)
+    static const int trial_spec_wgs = [] { const char* e = getenv("BMPC_TRIAL_SPEC_WGS"); return e ? atoi(e) : BMPC_TRIAL_SPEC_WGS; }();
+    if (nw <= trial_spec_wgs && A->NP == (size_t)(A->N - 1)) LAUNCH_DYN(bmpc_k_trial_spec, nw, 64 * TRIAL_SPEC, trial_lds_doubles(A->N, TRIAL_SPEC));
+    else
     LAUNCH_DYN(bmpc_k_trial, nw, 64 * BMPC_TRIAL_NW, trial_lds_doubles(A->N, BMPC_TRIAL_NW));      // trial points (+ multiplier update) + filter test, backtracking inside
     LAUNCH(bmpc_k_rotate, 1, 64);
     int* t = A->L.eval; A->L.eval = A->L.eval_next; A->L.eval_next = t;

@@ -935,9 +935,15 @@ BMPC_NOINL bool ric_forward(RicArgs AH, LDSD* lds, int b, int lane) {
 #define BMPC_FW_DEPTH 1
 #endif
 constexpr int FW_DEPTH = BMPC_FW_DEPTH;
-constexpr int FW_Kl = 0, FW_kf = FW_Kl + NU * NX, FW_ew = FW_kf + 32, FW_rdef = FW_ew + 42, FW_dx = FW_rdef + NX + 6,
-              FW_dzeta = FW_dx + NX, FW_LDS_DOUBLES = FW_dzeta + ZPAD;
+static_assert(FW_DEPTH == 1, "k_fwd keeps one stage in flight (depth 3 / 5 measured in round 4: no gain)");
+constexpr int FW_kf = 0, FW_ew = FW_kf + 32, FW_rdef = FW_ew + 42, FW_dx = FW_rdef + NX + 6,
+              FW_dzeta = FW_dx + NX, FW_part = FW_dzeta + ZPAD, FW_LDS_DOUBLES = FW_part + 40;
+static_assert(NX == 32 && NU == 9, "k_fwd: nine gain rows in four parts of eight columns, one (row, part) per lane");
 
+// The product K dx runs on 36 lanes -- lane 4 l + p holds columns 8 p .. 8 p + 7 of row l in registers, straight from the gain
+// record (64 contiguous bytes per lane), and the four partial sums of a row are added in the order p = 0 .. 3.  (Until the end of
+// round 4 nine lanes walked a row of 32 each out of LDS, all nine on the same bank: the kernel was bound by instruction issue
+// at 9 .. 32 busy lanes of 64.)
 BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
     const int count = A.L.cnt[1];
     if (blk >= count) return;
@@ -945,39 +951,38 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
     const DynC dc = make_dync(A.o.dt);
     const double mu = A.st[b].mu;
     const int ksel = A.st[b].ksel;                  // which copy of the gains this iteration's factorisation left (ric_finish)
-    constexpr int NK = (NU * NX + 63) / 64;
-    // stage data in flight: FW_DEPTH stages ahead.  (Measured in round 4: depth 3 at 128 registers 181 us, depth 1 178 us at 8192
-    // live instances -- the kernel does not wait for its gains; it is bound by instruction issue at 9 .. 32 busy lanes of 64)
-    constexpr int D = FW_DEPTH;
-    double fK[D][NK], fkf[D], few[D], frd[D];
-    BMPC_UNROLL
-    for (int s = 0; s < D; s++) { fkf[s] = 0; few[s] = 0; frd[s] = 0; }
-    auto fetch = [&](int k, int s) {
+    const int kl = (lane < 4 * NU) ? lane : 0;      // (lanes beyond the 36 load row 0 again and drop the product)
+    const int krow = kl >> 2, kpart = kl & 3;
+    // stage data in flight: one stage ahead
+    double nK[8], n_kf = 0, n_ew = 0, n_rd = 0;
+    auto fetch = [&](int k) {
         GCD krec = ric_krec(A, b, k, ksel);
         GCD rec = A.hrec + hrec_of(A, b, k);
         BMPC_UNROLL
-        for (int m = 0; m < NK; m++) { int e = lane + 64 * m; fK[s][m] = (e < NU * NX) ? krec[e] : 0.0; }
-        if (lane < 32) fkf[s] = krec[NU * NX + lane];
-        if (lane < 42) few[s] = rec[F_EW + lane];
-        if (lane < NX) frd[s] = rec[F_RDEF + lane];
+        for (int i = 0; i < 8; i++) nK[i] = krec[krow * NX + 8 * kpart + i];
+        if (lane < 32) n_kf = krec[NU * NX + lane];
+        if (lane < 42) n_ew = rec[F_EW + lane];
+        if (lane < NX) n_rd = rec[F_RDEF + lane];
     };
-    BMPC_UNROLL
-    for (int s = 0; s < D; s++)
-        if (1 + s < N) fetch(1 + s, s);
+    fetch(1);
     if (lane < NX) lds[FW_dx + lane] = A.dx1[(size_t)b * NX + lane];
 #pragma unroll 1
-    for (int k0 = 1; k0 < N; k0 += D) {
-      BMPC_UNROLL
-      for (int s = 0; s < D; s++) {
-        const int k = k0 + s;
-        if (k >= N) break;
+    for (int k = 1; k < N; k++) {
         const size_t pi = pair_of(A, b, k);
+        double cK[8];
         BMPC_UNROLL
-        for (int m = 0; m < NK; m++) { int e = lane + 64 * m; if (e < NU * NX) lds[FW_Kl + e] = fK[s][m]; }
-        if (lane < 32) lds[FW_kf + lane] = fkf[s];
-        if (lane < 42) lds[FW_ew + lane] = few[s];
-        if (lane < NX) lds[FW_rdef + lane] = frd[s];
-        if (k + D < N) fetch(k + D, s);
+        for (int i = 0; i < 8; i++) cK[i] = nK[i];
+        if (lane < 32) lds[FW_kf + lane] = n_kf;
+        if (lane < 42) lds[FW_ew + lane] = n_ew;
+        if (lane < NX) lds[FW_rdef + lane] = n_rd;
+        if (k + 1 < N) fetch(k + 1);
+        BMPC_SYNC();
+        {   // partial sums of K dx
+            double s = 0;
+            BMPC_UNROLL
+            for (int i = 0; i < 8; i++) s += cK[i] * lds[FW_dx + 8 * kpart + i];
+            if (lane < 4 * NU) lds[FW_part + lane] = s;
+        }
         BMPC_SYNC();
         // dzeta = (dx, kf0 + mu kf1 + K dx)
         double dzv = 0;
@@ -986,7 +991,7 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
             const int l = lane - NX;
             double sum = lds[FW_kf + l] + mu * lds[FW_kf + 16 + l];
             BMPC_UNROLL
-            for (int j = 0; j < NX; j++) sum += lds[FW_Kl + l * NX + j] * lds[FW_dx + j];
+            for (int pp = 0; pp < 4; pp++) sum += lds[FW_part + 4 * l + pp];
             dzv = sum;
         }
         if (lane < NZ) { lds[FW_dzeta + lane] = dzv; A.dz[(size_t)lane * A.NP + pi] = dzv; }
@@ -1016,7 +1021,6 @@ BMPC_DEV void k_fwd_body(const PipeArgs& A, int blk, int lane, LDSD* lds) {
             if (lane < NX) lds[FW_dx + lane] = v;
         }
         BMPC_SYNC();
-      }
     }
 }
 

@@ -105,7 +105,7 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
     A.L.eval_next = l_evn.data(); A.L.trial_next = l_trn.data(); A.L.cnt = cnt.data();
     A.L.done = l_done.data(); A.L.admit = l_admit.data(); A.L.curv = l_curv.data(); A.src = srcv.data();
     A.tbl = tbl.data();
-    std::vector<double> lds(std::max<size_t>(std::max<size_t>(pair_lds_doubles(N, true), trial_lds_doubles(N, EMU_TRIAL_NW)), RIC_LDS_DOUBLES) + 64);
+    std::vector<double> lds(std::max<size_t>(std::max<size_t>(pair_lds_doubles(N, true), trial_lds_doubles(N, 4)), RIC_LDS_DOUBLES) + 64);
     const int n0 = cap;
     const int nb_inst = (cap + 63) / 64, nw = waves_for(N, cap);
     cnt[0] = n0; cnt[6] = n0; cnt[9] = n0;
@@ -138,6 +138,9 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         launch(cnt[0], [&](int blk, int l) { k_ric_body<EMU_RIC_NT>(*reinterpret_cast<const PipeArgsH*>(&A), blk, l, lds.data()); }, EMU_RIC_NT);
         launch(cnt[1], [&](int blk, int l) { k_fwd_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[1]), [&](int blk, int l) { k_step_body(A, blk, l, lds.data()); });
+        if (getenv("BMPC_EMU_TRIAL_SPEC") && atoi(getenv("BMPC_EMU_TRIAL_SPEC")) && slot_major)      // the tail regime's line search on the GPU
+            launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_spec_body(A, blk, l, lds.data()); }, 64 * TRIAL_SPEC);
+        else
         launch(waves_for(N, cnt[2]), [&](int blk, int l) { k_trial_body_t<EMU_TRIAL_NW>(A, blk, l, lds.data()); }, 64 * EMU_TRIAL_NW);
         k_rotate_body(A);
         std::swap(A.L.eval, A.L.eval_next);

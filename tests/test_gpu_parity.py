@@ -455,13 +455,19 @@ def test_ric_variants_agree_bitwise(tmp_path):
             "r = be.solve_batch(b['x0'], b['lbx'], b['ubx'], b['p'])\n"
             "np.savez(sys.argv[1], **{k: r[k] for k in ('x', 'f', 'iters', 'status', 'viol')})\n") % root
     out = []
-    for lat, spec in (("0", "0"), ("1000000000", "0"), ("1000000000", "1000000000")):
-        path = str(tmp_path / f"ric_{lat}_{spec}.npz")
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, BMPC_RIC_LAT_BELOW=lat, BMPC_RIC_SPEC_BELOW=spec), timeout=600)
+    # (the last two: the tail regime's line search, bmpc_k_trial_spec -- four step lengths of a search side by side -- never / always)
+    for lat, spec, tspec in (("0", "0", None), ("1000000000", "0", None), ("1000000000", "1000000000", None), ("0", "0", "0"), ("0", "0", "1000000000")):
+        path = str(tmp_path / f"ric_{lat}_{spec}_{tspec}.npz")
+        env = dict(os.environ, BMPC_RIC_LAT_BELOW=lat, BMPC_RIC_SPEC_BELOW=spec)
+        if tspec is not None:
+            env["BMPC_TRIAL_SPEC_WGS"] = tspec
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
         out.append(np.load(path))
     for k in ("x", "f", "iters", "status", "viol"):
         assert np.array_equal(out[0][k], out[1][k]), k
         assert np.array_equal(out[0][k], out[2][k]), ("speculative pair", k)
+        assert np.array_equal(out[0][k], out[3][k]), ("sequential line search everywhere", k)
+        assert np.array_equal(out[0][k], out[4][k]), ("speculative line search everywhere", k)
     assert out[0]["iters"].max() > 40       # stragglers included
 
 
