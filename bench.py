@@ -79,7 +79,8 @@ def block_diffs(N, xa, xb):
 
 def visible_gpus():
     """GPUs this process would see, WITHOUT touching the HIP runtime (the launcher must not initialise the GPU before it starts
-    its ranks): the KFD topology nodes that have SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set."""
+    its ranks): the KFD topology nodes that have SIMDs and whose render node this process may open (a container can list every GPU
+    of the host in sysfs while only some /dev/dri/renderD* are passed in), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES."""
     n = 0
     base = "/sys/class/kfd/kfd/topology/nodes"
     try:
@@ -87,12 +88,15 @@ def visible_gpus():
     except OSError:
         nodes = []
     for node in nodes:
-        try:                                  # (a container sees only its own GPUs' nodes; the others are not readable)
+        try:
             with open(os.path.join(base, node, "properties")) as f:
                 props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
         except OSError:
             continue
         if int(props.get("simd_count", "0")) > 0:
+            minor = props.get("drm_render_minor")
+            if minor is not None and int(minor) > 0 and not os.access(f"/dev/dri/renderD{int(minor)}", os.R_OK | os.W_OK):
+                continue                      # listed, but not ours to open
             n += 1
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
