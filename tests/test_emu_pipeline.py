@@ -137,16 +137,14 @@ def test_emulated_speculative_line_search_is_bitwise_the_sequential_one(monkeypa
     """bmpc_k_trial_spec (the tail regime's line search on the GPU): the step lengths of a search -- alpha, alpha / 2, ... -- are
     tried four at a time by a workgroup of four wavefronts, the tests run in the order of the sequential search and the first
     accepted candidate is copied over.  Same trial points, same tests: bitwise the results of k_trial's own backtracking, here on
-    instances whose searches do backtrack (the same six as above: up to the iteration limit), and with the line search spread over
-    super-steps in the sequential run (trial_repeats = 0)."""
+    instances whose searches do backtrack (four of the six above: up to the iteration limit)."""
     N = 15
     batch = scenes.make_batch(128, N, 7, O.fk_batch, randomize_sets=True)
-    pick = [49, 108, 86, 74, 58, 8]
+    pick = [49, 108, 86, 74]
     a = tuple(batch[k][pick] for k in ("x0", "lbx", "ubx", "p"))
-    seq = E.solve_batch(N, *a, want_g=True, max_iter=40)
-    seq0 = E.solve_batch(N, *a, want_g=True, max_iter=40, trial_repeats=0)
+    seq = E.solve_batch(N, *a, want_g=True, max_iter=30)
     monkeypatch.setenv("BMPC_EMU_TRIAL_SPEC", "1")
-    spec = E.solve_batch(N, *a, want_g=True, max_iter=40)
+    spec = E.solve_batch(N, *a, want_g=True, max_iter=30)
     for k in ("x", "g", "f", "iters", "status", "viol"):
         assert np.array_equal(seq[k], spec[k]), k
-        assert np.array_equal(seq0[k], spec[k]), k
+    assert seq["iters"].max() >= 30          # (the searches of these instances do backtrack: they run into the limit)
