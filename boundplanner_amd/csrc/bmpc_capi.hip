@@ -75,7 +75,9 @@ struct bmpc_handle {
     // bmpc_debug_time_ric: HIP events around every launch of the Riccati kernel (the dominant kernel: bench.py's roofline leg)
     bool time_ric = false;
     hipEvent_t ric_ev[16] = {nullptr};      // 8 pairs: a burst has at most 8 super-steps and ends with a wait for the stream
-    int ric_pending = 0, ric_is_lat[8] = {0};
+    int ric_pending = 0, ric_is_lat[8] = {0}, ric_nact[8] = {0};
+    int ric_full_n = 0;                     // grid size that counts as "the whole batch" (the first burst of a solve)
+    double ric_full[3] = {0, 0, 0};         // launches of bmpc_k_ric over the whole batch: summed duration [ms], launches, instance-iterations
     double ric_ms[2] = {0, 0};              // [0] bmpc_k_ric, [1] bmpc_k_ric_lat: summed launch durations of the last solve
     long ric_launches[2] = {0, 0}, ric_sweeps[2] = {0, 0};
     bool wedged = false;           // a wait ran into the watchdog: the stream may still be busy, the handle refuses further work
@@ -310,6 +312,7 @@ static int pipe_ensure(bmpc_handle* h, int B) {
 static hipError_t step_timed(bmpc_handle* h, PipeArgsH* A, int n_act, hipStream_t st) {
     if (!h->time_ric || h->ric_pending >= 8) return bmpc_pipe_launch_step(A, n_act, st, nullptr, nullptr, nullptr);
     const int i = h->ric_pending++;
+    h->ric_nact[i] = n_act;
     return bmpc_pipe_launch_step(A, n_act, st, h->ric_ev[2 * i], h->ric_ev[2 * i + 1], &h->ric_is_lat[i]);
 }
 static void ric_collect(bmpc_handle* h) {        // the stream is idle: every recorded pair has completed
@@ -317,6 +320,7 @@ static void ric_collect(bmpc_handle* h) {        // the stream is idle: every re
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ric_ev[2 * i], h->ric_ev[2 * i + 1]) == hipSuccess) {
             h->ric_ms[h->ric_is_lat[i] ? 1 : 0] += ms; h->ric_launches[h->ric_is_lat[i] ? 1 : 0] += 1;
+            if (!h->ric_is_lat[i] && h->ric_nact[i] >= h->ric_full_n) { h->ric_full[0] += ms; h->ric_full[1] += 1; h->ric_full[2] += h->ric_nact[i]; }
         }
     }
     h->ric_pending = 0;
@@ -426,6 +430,7 @@ static int pipe_solve(bmpc_handle* h, int B, const double* d_x0, const double* d
     int n_act = n0, steps = 0, retired = 0, next_row = n0;
     h->n_active.store(B);
     h->ric_pending = 0; h->ric_ms[0] = h->ric_ms[1] = 0; h->ric_launches[0] = h->ric_launches[1] = 0;
+    h->ric_full_n = n0; h->ric_full[0] = h->ric_full[1] = h->ric_full[2] = 0;
     const long max_steps = hook ? (1L << 40) : 12L * (h->o.max_iter + 2) * ((B + cap - 1) / cap + 1);
     while (retired < B && steps < max_steps) {
         const int burst = steps < 8 ? 8 : 4;
@@ -790,6 +795,12 @@ extern "C" int bmpc_debug_ric_stats(bmpc_handle* h, double* out6) {
 }
 
 // diagnostic: keep the handle's stream busy for `ms` milliseconds (at most 10 s) -- lets a test exercise the watchdog
+extern "C" int bmpc_debug_ric_stats_full(bmpc_handle* h, double* out3) {
+    if (!h || !out3) return 1;
+    for (int i = 0; i < 3; i++) out3[i] = h->ric_full[i];
+    return 0;
+}
+
 extern "C" int bmpc_debug_spin(bmpc_handle* h, int ms) {
     if (!h) return 1;
     WEDGED_FAIL(h);

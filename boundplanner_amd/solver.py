@@ -29,7 +29,7 @@ class BmpcOpts(ctypes.Structure):
 EXPORTS = ["bmpc_default_opts", "bmpc_create", "bmpc_destroy", "bmpc_last_error", "bmpc_dims",
            "bmpc_gbounds", "bmpc_solve", "bmpc_solve_dev", "bmpc_solve_dev_async", "bmpc_multipliers_dev", "bmpc_wait", "bmpc_active", "bmpc_fk",
            "bmpc_last_kernel_ms", "bmpc_get_opts", "bmpc_stream", "bmpc_robot_iiwa14", "bmpc_robot_gen3", "bmpc_set_robot", "bmpc_get_robot",
-           "bmpc_debug_phase_cycles", "bmpc_debug_spin", "bmpc_debug_inst_state", "bmpc_debug_time_ric", "bmpc_debug_ric_stats", "bmpc_debug_lane_stats",
+           "bmpc_debug_phase_cycles", "bmpc_debug_spin", "bmpc_debug_inst_state", "bmpc_debug_time_ric", "bmpc_debug_ric_stats", "bmpc_debug_ric_stats_full", "bmpc_debug_lane_stats",
            "bmpc_loop_state_doubles", "bmpc_loop_log_doubles", "bmpc_loop_field", "bmpc_loop_create", "bmpc_loop_destroy",
            "bmpc_loop_last_error", "bmpc_loop_record_doubles", "bmpc_loop_set_record", "bmpc_loop_records", "bmpc_loop_set_obstacles", "bmpc_loop_upload", "bmpc_loop_download", "bmpc_loop_run", "bmpc_loop_run_async", "bmpc_loop_prepare",
            "bmpc_loop_solve", "bmpc_loop_finish", "bmpc_loop_problem", "bmpc_loop_solution", "bmpc_loop_set_solution"]
@@ -90,6 +90,7 @@ def load_library():
         lib.bmpc_debug_time_ric.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.bmpc_debug_ric_stats.argtypes = [ctypes.c_void_p, _dp]
         lib.bmpc_debug_lane_stats.argtypes = [ctypes.c_void_p, _dp]
+        lib.bmpc_debug_ric_stats_full.argtypes = [ctypes.c_void_p, _dp]
         lib.bmpc_loop_set_record.argtypes = [ctypes.c_void_p, ctypes.c_int, _ip]
         lib.bmpc_loop_records.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _ip]
         lib.bmpc_loop_record_doubles.argtypes = [ctypes.c_int]
@@ -188,7 +189,9 @@ class HipBoundMPC:
         """{kernel: (summed launch ms, launches, instance-iterations)} of the most recent solve (bmpc_debug_ric_stats)."""
         out = np.zeros(6)
         self._chk(self.lib.bmpc_debug_ric_stats(self._h, _P(out)), "bmpc_debug_ric_stats")
-        return {"bmpc_k_ric": tuple(out[:3]), "bmpc_k_ric_lat": tuple(out[3:])}
+        full = np.zeros(3)
+        self._chk(self.lib.bmpc_debug_ric_stats_full(self._h, _P(full)), "bmpc_debug_ric_stats_full")
+        return {"bmpc_k_ric": tuple(out[:3]), "bmpc_k_ric_lat": tuple(out[3:]), "bmpc_k_ric_full_batch": tuple(full)}
 
     def lane_stats(self):
         """The two lanes of the most recent closed-loop run without lock step on this handle (bmpc_debug_lane_stats)."""

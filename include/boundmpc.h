@@ -172,6 +172,9 @@ int bmpc_debug_inst_state(bmpc_handle* h, int B, double* out);
  * in out6[3..5].  bench.py derives its roofline line from these. */
 int bmpc_debug_time_ric(bmpc_handle* h, int on);
 int bmpc_debug_ric_stats(bmpc_handle* h, double* out6);
+/* ... and of those launches of the throughput variant whose grid was the whole batch (the first super-steps of a solve, before anybody
+ * has finished: the kernel at full occupancy): {summed durations [ms], launches, instance-iterations}. */
+int bmpc_debug_ric_stats_full(bmpc_handle* h, double* out3);
 /* Measurement: the two lanes of the most recent bmpc_loop_run_async on this handle (see there): {bursts, fast-lane super-steps,
  * bulk-lane super-steps, summed fast-lane instance counts at the ends of its rounds, 0, 0, fast-lane rounds, 0}; all zero when the
  * run had one lane. */
