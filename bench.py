@@ -412,8 +412,9 @@ def main():
         hs.run(args.steps)
         torch.cuda.synchronize(dev)
         out["value_pcie_inclusive_pipelined"] = args.steps * B / (time.perf_counter() - t1)
-        out["pcie_pipelined_note"] = (f"{depth} solver calls in flight, each: hipMemcpyAsync of x0, lbx, ubx, p for {M} batches from pinned host memory on the "
-                                      "handle's stream -> streaming solve -> x, f, iters, status, viol back to pinned host memory")
+        out["pcie_pipelined_note"] = (f"{depth} solver calls in flight, each: hipMemcpyAsync of x0, lbx, ubx, p for {M} batches from pinned host memory (upload "
+                                      "stream; a handle's next call is fetched while its current one is solved) -> streaming solve -> x, f, iters, status, viol "
+                                      "back to pinned host memory (download stream); the timed region starts with nothing uploaded")
         same = all(bool(torch.equal(hs.h_out[0][k][:B], outs[0][k][:B].cpu())) for k in ("x", "iters", "status")) if nd_h >= 1 and args.steps % (depth * M) == 0 else None
         out["pcie_pipelined_first_batch_equals_device_resident"] = same
         del hs, pinned

@@ -90,9 +90,11 @@ class BatchStream:
 
 class HostBatchStream:
     """The same schedule with the transfers inside ("incl. H2D of inputs and D2H of x, iters, status"): every
-    solver call's x0, lbx, ubx, p come from PINNED host memory with asynchronous copies on the handle's own stream, its x, f,
-    iters, status, viol go back to pinned host memory when the call has retired; the copies of one handle run beside the
-    kernels of the others.  torch provides the pinned buffers and wraps the handles' streams (plumbing only)."""
+    solver call's x0, lbx, ubx, p come from PINNED host memory by asynchronous copies, its x, f, iters, status, viol go back to
+    pinned host memory when the call has retired.  Uploads and downloads have a stream each and every handle two sets of staging
+    buffers: the inputs of its NEXT call are fetched while the current one is being solved, and the outputs of the previous call
+    leave while the next one runs (until round 4's last session the copies sat on the handle's own stream, between its calls).  torch provides the pinned buffers, the copy streams and events and wraps the handles' streams
+    (plumbing only)."""
 
     def __init__(self, backends, host_inputs, B, merge, dev):
         import torch
@@ -104,41 +106,73 @@ class HostBatchStream:
         n_w, n_p = host_inputs["x0"].shape[1], host_inputs["p"].shape[1]
         f64, i32 = torch.float64, torch.int32
         self.streams = [torch.cuda.ExternalStream(b.stream(), device=dev) for b in backends]
-        self.d_in = [{k: torch.empty((n, n_p if k == "p" else n_w), dtype=f64, device=dev) for k in ("x0", "lbx", "ubx", "p")} for _ in backends]
-        self.d_out = [dict(x=torch.empty((n, n_w), dtype=f64, device=dev), f=torch.empty(n, dtype=f64, device=dev), viol=torch.empty(n, dtype=f64, device=dev),
-                           iters=torch.empty(n, dtype=i32, device=dev), status=torch.empty(n, dtype=i32, device=dev)) for _ in backends]
-        self.h_out = [{k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in o.items()} for o in self.d_out]
-        self.busy = [0] * self.depth
+        # one stream for all uploads, one for all downloads: copies are served in the order the calls need them (with a copy stream per
+        # handle the first calls of a run all waited for the sum of their uploads)
+        self.h2d, self.d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.d_in = [[{k: torch.empty((n, n_p if k == "p" else n_w), dtype=f64, device=dev) for k in ("x0", "lbx", "ubx", "p")} for _ in range(2)]
+                     for _ in backends]
+        self.d_out = [[dict(x=torch.empty((n, n_w), dtype=f64, device=dev), f=torch.empty(n, dtype=f64, device=dev), viol=torch.empty(n, dtype=f64, device=dev),
+                            iters=torch.empty(n, dtype=i32, device=dev), status=torch.empty(n, dtype=i32, device=dev)) for _ in range(2)] for _ in backends]
+        self.h_out = [{k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in o[0].items()} for o in self.d_out]
+        self.ev_in = [[torch.cuda.Event() for _ in range(2)] for _ in backends]       # inputs of the set have arrived
+        self.ev_out = [[None, None] for _ in backends]                               # outputs of the set have left (None: never used)
+        self.fetched = [[None, None] for _ in backends]                              # global call index whose inputs the set holds
+        self.busy = [0] * self.depth                         # batches of the call in flight on the handle
+        self.par = [0] * self.depth                          # staging set of the call in flight / of the next call
         self.calls = 0
+
+    def _fetch(self, j, p, g, m):
+        """inputs of global call g (m batches) into staging set p of handle j, on the handle's copy stream"""
+        s = (g * self.M) % self.nd
+        n = m * self.B
+        with self.torch.cuda.stream(self.h2d):
+            for k, v in self.d_in[j][p].items():
+                v[:n].copy_(self.src[k][s * self.B:s * self.B + n], non_blocking=True)
+            self.ev_in[j][p].record()
+        self.fetched[j][p] = g
 
     def _retire(self, j):
         if not self.busy[j]:
             return
         self.be[j].wait()                                    # every kernel of the call has been enqueued and has finished
         n = self.busy[j] * self.B
-        with self.torch.cuda.stream(self.streams[j]):
-            for k, v in self.d_out[j].items():
+        p = self.par[j]
+        with self.torch.cuda.stream(self.d2h):
+            for k, v in self.d_out[j][p].items():
                 self.h_out[j][k][:n].copy_(v[:n], non_blocking=True)
+            ev = self.torch.cuda.Event()
+            ev.record()
+        self.ev_out[j][p] = ev
         self.busy[j] = 0
+        self.par[j] = 1 - p
 
     def run(self, nbatches):
-        left = nbatches
-        while left > 0:
-            m = min(self.M, left)
-            j = self.calls % self.depth
+        ncalls = (nbatches + self.M - 1) // self.M
+        g0 = self.calls
+        for c in range(ncalls):
+            g = g0 + c
+            m = min(self.M, nbatches - c * self.M)
+            j = g % self.depth
             self._retire(j)
-            s = (self.calls * self.M) % self.nd
+            p = self.par[j]
+            if self.fetched[j][p] != g:
+                self._fetch(j, p, g, m)                      # (the first calls of a run: nothing was fetched ahead)
+            st = self.streams[j]
+            st.wait_event(self.ev_in[j][p])                  # enqueued before the handle's worker thread launches anything
+            if self.ev_out[j][p] is not None:
+                st.wait_event(self.ev_out[j][p])             # the outputs this set held two calls ago have left
+            i, o = self.d_in[j][p], self.d_out[j][p]
             n = m * self.B
-            with self.torch.cuda.stream(self.streams[j]):       # (behind the D2H of the previous call on this stream)
-                for k, v in self.d_in[j].items():
-                    v[:n].copy_(self.src[k][s * self.B:s * self.B + n], non_blocking=True)
-            i, o = self.d_in[j], self.d_out[j]
             self.be[j].solve_dev_async(n, i["x0"].data_ptr(), i["lbx"].data_ptr(), i["ubx"].data_ptr(), i["p"].data_ptr(), o["x"].data_ptr(),
                                        o["f"].data_ptr(), o["iters"].data_ptr(), o["status"].data_ptr(), o["viol"].data_ptr())
             self.busy[j] = m
             self.calls += 1
-            left -= m
+            # this handle's next call of the run: its inputs travel while this one is being solved (the other staging set: its
+            # last reader, the handle's previous call, has retired)
+            c2 = c + self.depth
+            if c2 < ncalls:
+                self._fetch(j, 1 - p, g0 + c2, min(self.M, nbatches - c2 * self.M))
         for q in range(self.depth):
             self._retire((self.calls + q) % self.depth)
-        for st in self.streams:
+        for st in self.streams + [self.h2d, self.d2h]:
             st.synchronize()
