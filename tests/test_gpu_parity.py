@@ -641,3 +641,32 @@ def test_watchdog_turns_a_stuck_stream_into_an_error():
     again = ok.solve_batch(batch["x0"], batch["lbx"], batch["ubx"], batch["p"])
     assert np.array_equal(again["x"], ref["x"])
     be.close(); be2.close()
+
+
+def test_host_batch_stream_prefetches_and_returns_what_a_direct_solve_returns():
+    """HostBatchStream (bench.py's leg with the transfers inside): inputs from pinned host memory on an upload stream, two staging
+    sets per handle, a handle's next call fetched while its current one is solved, outputs through a download stream.  Five calls of
+    two batches on two handles (the third call of handle 0 and the second of handle 1 are prefetched): the outputs left in the
+    pinned buffers are bitwise those of direct solves of the same rows."""
+    import torch
+    from boundplanner_amd import scenes
+    from boundplanner_amd.batch_stream import HostBatchStream
+    from boundplanner_amd.solver import HipBoundMPC
+    N, B, M, nd = 10, 64, 2, 6
+    dev = torch.device("cuda:0")
+    bes = [HipBoundMPC(N, pool_slots=64) for _ in range(2)]
+    batch = scenes.make_batch(nd * B, N, 31, bes[0].fk, randomize_sets=True)
+    pinned = {k: torch.from_numpy(np.ascontiguousarray(batch[k])).pin_memory() for k in ("x0", "lbx", "ubx", "p")}
+    hs = HostBatchStream(bes, pinned, B, M, dev)
+    hs.run(5 * M)                       # calls 0, 2, 4 on handle 0; 1, 3 on handle 1
+    ref = HipBoundMPC(N)
+    for j, g in ((0, 4), (1, 3)):
+        s = (g * M) % nd
+        rows = slice(s * B, s * B + M * B)
+        r = ref.solve_batch(batch["x0"][rows], batch["lbx"][rows], batch["ubx"][rows], batch["p"][rows])
+        for k in ("x", "f", "iters", "status", "viol"):
+            assert np.array_equal(hs.h_out[j][k][:M * B].numpy(), r[k]), (j, k)
+    assert hs.fetched[0][0] == 4 and hs.fetched[1][1] == 3      # those calls' inputs did come from the prefetch
+    del hs
+    for b in bes + [ref]:
+        b.close()
