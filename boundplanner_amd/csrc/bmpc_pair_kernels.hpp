@@ -466,9 +466,9 @@ BMPC_INL void chain_cols(const KinT& K, const double Jl[3][7], const double G[6]
 
 struct ChainOut { double g17[3][17]; };
 
-template <int J, int I>
+template <int J, int I, class EM>
 BMPC_INL void chain_rows(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* t1,
-                         const double* t2, const PointRes& PR, Emitter& E) {
+                         const double* t2, const PointRes& PR, EM& E) {
     if constexpr (I <= J) {
         double cO[6], cV[6];
         chain_cols<I>(K, Jl, G, hdt, cO, cV);
@@ -480,9 +480,9 @@ BMPC_INL void chain_rows(const KinT& K, const double Jl[3][7], const double G[6]
         chain_rows<J, I + 1>(K, Jl, G, hdt, t1, t2, PR, E);
     }
 }
-template <int J>
+template <int J, class EM>
 BMPC_INL void chain_column(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* M6,
-                           const double* Hv, const PointRes& PR, Emitter& E) {
+                           const double* Hv, const PointRes& PR, EM& E) {
     double cO[6], cV[6], t1[6], t2[6];
     chain_cols<J>(K, Jl, G, hdt, cO, cV);
     BMPC_UNROLL
@@ -494,9 +494,9 @@ BMPC_INL void chain_column(const KinT& K, const double Jl[3][7], const double G[
     }
     chain_rows<J, 0>(K, Jl, G, hdt, t1, t2, PR, E);
 }
-template <int J>
+template <int J, class EM>
 BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][7], double hdt, const double* M6,
-                        const double* Hv, const PointRes& PR, Emitter& E) {
+                        const double* Hv, const PointRes& PR, EM& E) {
     if constexpr (J < 17) {
         chain_column<J>(K, Jl, G, hdt, M6, Hv, PR, E);
         chain_all<J + 1>(K, Jl, G, hdt, M6, Hv, PR, E);
@@ -504,10 +504,10 @@ BMPC_INL void chain_all(const KinT& K, const double Jl[3][7], const double G[6][
 }
 // P17 blocks: for position I of the (q, dq, pi) block emit the three slack-column couplings, then
 // D, g0, g1, gz of that position (its diagonal rows are walked here), 7 fields
-template <int I, int IEND, class RP, class BP>
+template <int I, int IEND, class RP, class BP, class EM>
 BMPC_INL void p17_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp, int k, const double* y, const KinT& K,
                            const double Jl[3][7], const double G[6][7], double hdt, RowAcc& R, const PointRes& PA,
-                           const PoseAsm& P, const double* bv, Emitter& E) {
+                           const PoseAsm& P, const double* bv, EM& E) {
     if constexpr (I < IEND) {
         PGP wts = pg + P_W;
         double cO[6], cV[6];
@@ -611,9 +611,9 @@ BMPC_INL void curvature_emit(const KinT& K, const double Jl[3][7], const double*
 }
 
 // DG entries: position I of the dg order
-template <int I, class RP, class BP>
+template <int I, class RP, class BP, class EM>
 BMPC_INL void dg_emit_all(const PipeArgs& A, PGP pg, const RP& rp, const BP& bp, int k, bool term,
-                          const double* y, RowAcc& R, const PointRes& PA, const PoseAsm& PO, Emitter& E) {
+                          const double* y, RowAcc& R, const PointRes& PA, const PoseAsm& PO, EM& E) {
     if constexpr (I < 38) {
         PGP wts = pg + P_W;
         DiagAsm dgv;
@@ -743,6 +743,11 @@ BMPC_KBODY void k_pose_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 }
 
 // lds: EM_DOUBLES doubles per wave
+// MODE 0: the whole record.  Tail regime (fewer groups of pairs than CUs: a launch costs its single-thread latency), two wavefronts side
+// by side: MODE 1 everything but the chained (q, dq, pi) block -- a third of the arithmetic, with no row of its own (no KKT partial
+// sum depends on it) --, MODE 2 that block alone, straight into the record.  Same expressions entry for entry, and the library is
+// built with -ffp-contract=on (contraction per source expression, whatever else the surrounding body computes): bitwise the record of MODE 0.
+template <int MODE>
 BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     const int count = A.L.cnt[0], N = A.N;
     if (wave * ipw_of(N) >= count) return;
@@ -753,9 +758,31 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
     GCD lbx = A.lbx + (size_t)A.src[m.b] * n_w;
     GCD ubx = A.ubx + (size_t)A.src[m.b] * n_w;
     PGP pg = stage_params(A, A.L.eval, count, wave, lane, m, lds + EM_DOUBLES + 8);
+    if constexpr (MODE == 2) {
+        struct { double zeta[NZ], y[NZ]; KinT K; double Jl[3][7]; } S;
+        const int flip = A.st[m.b].flip;
+        load_zeta(cur_zeta(A, flip), A.NP, m.pi, S.zeta);
+        nat_all(S.zeta, dc, S.y);
+        kin_chain(A.rc, S.y + Z_Q, S.K);
+        kin_jlin(S.K, S.Jl);
+        double G[6][7];
+        kin_G(S.K, S.Jl, S.y + Z_DQ, G);
+        PointRes PA;
+        PA.base = A.part + (size_t)PT_SIDE * A.NP + m.pi; PA.NP = A.NP;
+        GCD Pz = A.part + (size_t)PT_POSE * A.NP + m.pi;
+        double Hv[21], M6[21];
+        cost_hess_v(pg, N, k, Hv);
+        BMPC_UNROLL
+        for (int i = 0; i < 21; i++) M6[i] = Pz[(size_t)(PZ_M6 + i) * A.NP];
+        PA.load_hqq();
+        DirectEmitter D;
+        D.out = A.hrec + hrec_of(A, m.b, m.k) + F_H17; D.valid = m.valid; D.f = 0;
+        chain_all<0>(S.K, S.Jl, G, 0.5 * dc.dt, M6, Hv, PA, D);
+        return;
+    }
     const double ad = A.st[m.b].ad;
-    Emitter E;
-    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid);
+    EmitterT<MODE == 1> E;
+    E.init(lds, A.hrec, lane, hrec_of(A, m.b, m.k), m.valid, 0, F_H17, F_EW);
     BMPC_SYNC();
     // kinematic columns at the iterate (the reference / error context and the pose rows are k_pose's: their results come from the side array)
     struct { double zeta[NZ], y[NZ]; KinT K; double Jl[3][7]; } S;
@@ -817,7 +844,10 @@ BMPC_KBODY void k_eval_body(const PipeArgs& A, int wave, int lane, LDSD* lds) {
         }
     }
     // ---- chained (q, dq, pi) block ----
-    {
+    if constexpr (MODE == 1) {
+        BMPC_UNROLL
+        for (int i = 0; i < F_EW - F_H17; i++) E.put(0.0);      // (the chain part's fields: pass through the tile, not stored)
+    } else {
         double Hv[21];
         cost_hess_v(pg, N, k, Hv);
         BMPC_UNROLL

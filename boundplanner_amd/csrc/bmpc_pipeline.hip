@@ -44,7 +44,7 @@ extern __shared__ __attribute__((aligned(16))) double bmpc_dyn_lds[];
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_init(PipeArgsH H) { k_init_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_pose(PipeArgsH H) { k_pose_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval(PipeArgsH H) {
-    k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+    k_eval_body<0>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
 __global__ __launch_bounds__(64, BMPC_POINTS_WPS) void bmpc_k_points(PipeArgsH H) { k_points_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_curv(PipeArgsH H) {
@@ -61,9 +61,19 @@ __global__ __launch_bounds__(64, BMPC_PAIR_WPS) void bmpc_k_points_pose(PipeArgs
     else k_pose_body(DV(H), (int)blockIdx.x - nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
 __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv(PipeArgsH H, int nw) {
-    if ((int)blockIdx.x < nw) k_eval_body(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+    if ((int)blockIdx.x < nw) k_eval_body<0>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
     else k_curv_body(DV(H), (int)blockIdx.x - nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
+// tail regime (at most BMPC_EVAL_SPLIT_WGS groups of pairs): k_eval as two wavefronts side by side -- everything but the chained block /
+// the chained block alone (bmpc_pair_kernels.hpp, k_eval_body) -- beside k_curv
+__global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv_split(PipeArgsH H, int nw) {
+    if ((int)blockIdx.x < nw) k_eval_body<1>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+    else if ((int)blockIdx.x < 2 * nw) k_eval_body<2>(DV(H), (int)blockIdx.x - nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+    else k_curv_body(DV(H), (int)blockIdx.x - 2 * nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
+}
+#ifndef BMPC_EVAL_SPLIT_WGS
+#define BMPC_EVAL_SPLIT_WGS 256       // groups of pairs up to which bmpc_k_eval_curv_split replaces bmpc_k_eval_curv (0 = never)
+#endif
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
 #endif
@@ -193,6 +203,11 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
         LAUNCH(bmpc_k_curv, nw, 64);
     } else if (nw > 0) {
         hipLaunchKernelGGL(bmpc_k_points_pose, dim3(2 * nw), dim3(64), pair_lds_doubles(A->N, false) * sizeof(double), st, *A, nw);
+        // BMPC_EVAL_SPLIT_WGS (read once; 0 = never)
+        static const int eval_split_wgs = [] { const char* e = getenv("BMPC_EVAL_SPLIT_WGS"); return e ? atoi(e) : BMPC_EVAL_SPLIT_WGS; }();
+        if (nw <= eval_split_wgs)
+            hipLaunchKernelGGL(bmpc_k_eval_curv_split, dim3(A->o.hess == 2 ? 3 * nw : 2 * nw), dim3(64), pair_lds_doubles(A->N, true) * sizeof(double), st, *A, nw);
+        else
         hipLaunchKernelGGL(bmpc_k_eval_curv, dim3(A->o.hess == 2 ? 2 * nw : nw), dim3(64), pair_lds_doubles(A->N, true) * sizeof(double), st, *A, nw);
     }
     // BMPC_RIC_LAT_BELOW in the environment (read once): A/B runs and the test that the two variants agree bitwise

@@ -285,12 +285,16 @@ BMPC_HD size_t pair_lds_doubles(int N, bool with_tile) { return (size_t)ipw_of(N
 constexpr int EM_LD = 66;                      // tile row stride (doubles): conflict-free both ways
 constexpr int EM_DOUBLES = 16 * EM_LD + 64;    // tile + per-lane record base (as double)
 static_assert(EM_DOUBLES == EM_DOUBLES_C, "emitter tile size");
-struct Emitter {
+// HOLE: fields [h0, h1) of the record belong to another writer (k_eval without the chained block, tail regime) -- they pass through the
+// tile like the others but are not stored
+template <bool HOLE> struct EmitterT {
     LDSD* tile;        // [16][EM_LD]
     GD out;            // record array base
     int lane, f;
-    BMPC_INL void init(LDSD* lds, GD out_, int lane_, size_t rec, bool valid, int f0 = 0) {
+    int h0, h1;
+    BMPC_INL void init(LDSD* lds, GD out_, int lane_, size_t rec, bool valid, int f0 = 0, int hole0 = 0, int hole1 = 0) {
         tile = lds; out = out_; lane = lane_; f = f0;     // f0: multiple of 16; rec: offset of this lane's record in `out`
+        h0 = hole0; h1 = hole1;
         // publish every lane's record base (exact in a double: < 2^53) for the transposed store;
         // -1 = this lane must not store
         lds[16 * EM_LD + lane] = valid ? (double)rec : -1.0;
@@ -303,16 +307,24 @@ struct Emitter {
     BMPC_INL void flush() {
         BMPC_SYNC();
         const int ff = lane & 15, p0 = lane >> 4, c0 = f - 16;
+        bool mine = true;
+        if constexpr (HOLE) mine = (c0 + ff < h0) || (c0 + ff >= h1);
         BMPC_UNROLL
         for (int i = 0; i < 16; i++) {
             int pr = 4 * i + p0;
             double base = tile[16 * EM_LD + pr];
             double v = tile[ff * EM_LD + pr];
-            if (base >= 0.0) out[(size_t)base + c0 + ff] = v;
+            if (base >= 0.0 && mine) out[(size_t)base + c0 + ff] = v;
         }
         BMPC_SYNC();
     }
     BMPC_INL void pad_to(int n) { while (f < n) put(0.0); }
+};
+typedef EmitterT<false> Emitter;
+// the chained block alone (k_eval's chain part, tail regime): straight into the lane's record
+struct DirectEmitter {
+    GD out; bool valid; int f;
+    BMPC_INL void put(double v) { if (valid) out[f] = v; f++; }
 };
 
 }  // namespace bmpc

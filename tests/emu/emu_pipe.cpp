@@ -128,7 +128,11 @@ extern "C" int emu_pipe_solve(int N, double dt, double tol, int max_iter, int he
         if (verbose) printf("step %d: n_eval %d n_trial %d finished %d retired %d next row %d\n", steps, cnt[0], cnt[2], cnt[5], cnt[7], cnt[6]);
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_points_body(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_pose_body(A, blk, l, lds.data()); });
-        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body(A, blk, l, lds.data()); });
+        if (getenv("BMPC_EMU_EVAL_SPLIT") && atoi(getenv("BMPC_EMU_EVAL_SPLIT"))) {      // the tail regime's two-wavefront k_eval on the GPU
+            launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body<2>(A, blk, l, lds.data()); });
+            launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body<1>(A, blk, l, lds.data()); });
+        } else
+        launch(waves_for(N, cnt[0]), [&](int blk, int l) { k_eval_body<0>(A, blk, l, lds.data()); });
         launch(waves_for(N, cnt[10]), [&](int blk, int l) { k_curv_body(A, blk, l, lds.data()); });
         if (getenv("BMPC_EMU_RIC_SPEC") && atoi(getenv("BMPC_EMU_RIC_SPEC"))) {      // the speculative pair (the deep tail's kernels on the GPU)
             A.natt = 3;

@@ -147,3 +147,16 @@ def test_emulated_speculative_line_search_is_bitwise_the_sequential_one(monkeypa
     for k in ("x", "g", "f", "iters", "status", "viol"):
         assert np.array_equal(seq[k], spec[k]), k
     assert seq["iters"].max() >= 30          # (the searches of these instances do backtrack: they run into the limit)
+
+
+def test_emulated_two_wavefront_k_eval_is_bitwise_the_one_wavefront_kernel(monkeypatch):
+    """bmpc_k_eval_curv_split (the tail regime's evaluation on the GPU): k_eval as two bodies -- everything but the chained (q, dq, pi)
+    block, with a hole in its record stores / that block alone, straight into the record.  Same expressions entry for entry: bitwise
+    the results of the one-wavefront kernel (here the chain part runs first: the other part must not touch its fields)."""
+    N, B = 6, 5
+    batch = scenes.make_batch(B, N, 6, O.fk_batch, randomize_sets=True)
+    a = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    monkeypatch.setenv("BMPC_EMU_EVAL_SPLIT", "1")
+    b = E.solve_batch(N, batch["x0"], batch["lbx"], batch["ubx"], batch["p"], want_g=True)
+    for k in ("x", "g", "f", "iters", "status", "viol"):
+        assert np.array_equal(a[k], b[k]), k

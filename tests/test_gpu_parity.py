@@ -461,6 +461,7 @@ def test_ric_variants_agree_bitwise(tmp_path):
         env = dict(os.environ, BMPC_RIC_LAT_BELOW=lat, BMPC_RIC_SPEC_BELOW=spec)
         if tspec is not None:
             env["BMPC_TRIAL_SPEC_WGS"] = tspec
+            env["BMPC_EVAL_SPLIT_WGS"] = tspec      # (and the two-wavefront k_eval of the tail regime, bmpc_k_eval_curv_split)
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
         out.append(np.load(path))
     for k in ("x", "f", "iters", "status", "viol"):

@@ -7,7 +7,7 @@ CS=$ROOT/boundplanner_amd/csrc
 OUT=$ROOT/build/variants
 NAME=$1; shift
 mkdir -p $OUT/$NAME
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on"
 for o in bmpc_fk.o bmpc_loop.o; do [ -f $CS/$o ] || { echo "build the product library first (python -c 'import __graft_entry__ as g; g.build()')"; exit 1; }; done
 hipcc $FL "$@" -c $CS/bmpc_pipeline.hip -o $OUT/$NAME/pipe.o
 hipcc $FL "$@" -c $CS/bmpc_capi.hip -o $OUT/$NAME/capi.o

@@ -5,7 +5,7 @@ import os, re, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "p.s")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", *sys.argv[1:], "--cuda-device-only", "-S",
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", *sys.argv[1:], "--cuda-device-only", "-S",
                            os.path.join(R, "boundplanner_amd", "csrc", "bmpc_pipeline.hip"), "-o", out], stderr=subprocess.DEVNULL)
     txt = open(out).read()
 pat = r"\.agpr_count:\s+(\d+).*?\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)"
