@@ -743,8 +743,8 @@ BMPC_KBODY void k_pose_body(const PipeArgs& A, int wave, int lane, LDSD* lds_par
 }
 
 // lds: EM_DOUBLES doubles per wave
-// MODE 0: the whole record.  Tail regime (fewer groups of pairs than CUs: a launch costs its single-thread latency), two wavefronts side
-// by side: MODE 1 everything but the chained (q, dq, pi) block -- a third of the arithmetic, with no row of its own (no KKT partial
+// MODE 0: the whole record (A/B runs: BMPC_EVAL_SPLIT_WGS=0).  The product runs two wavefronts side by side -- in the tail regime a
+// launch costs its single-thread latency, in the bulk regime the two lighter bodies spill less --: MODE 1 everything but the chained (q, dq, pi) block -- a third of the arithmetic, with no row of its own (no KKT partial
 // sum depends on it) --, MODE 2 that block alone, straight into the record.  Same expressions entry for entry, and the library is
 // built with -ffp-contract=on (contraction per source expression, whatever else the surrounding body computes): bitwise the record of MODE 0.
 template <int MODE>

@@ -64,15 +64,21 @@ __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv(PipeArgsH 
     if ((int)blockIdx.x < nw) k_eval_body<0>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
     else k_curv_body(DV(H), (int)blockIdx.x - nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
-// tail regime (at most BMPC_EVAL_SPLIT_WGS groups of pairs): k_eval as two wavefronts side by side -- everything but the chained block /
+// k_eval as two wavefronts side by side (up to BMPC_EVAL_SPLIT_WGS groups of pairs: always, by default) -- everything but the chained block /
 // the chained block alone (bmpc_pair_kernels.hpp, k_eval_body) -- beside k_curv
 __global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_curv_split(PipeArgsH H, int nw) {
     if ((int)blockIdx.x < nw) k_eval_body<1>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds);
     else if ((int)blockIdx.x < 2 * nw) k_eval_body<2>(DV(H), (int)blockIdx.x - nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
     else k_curv_body(DV(H), (int)blockIdx.x - 2 * nw, threadIdx.x, (LDSD*)bmpc_dyn_lds);
 }
+// (the two bodies as kernels of their own: per-kernel profiles, BMPC_SPLIT_LAUNCHES=1)
+__global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_main(PipeArgsH H) { k_eval_body<1>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
+__global__ __launch_bounds__(64, BMPC_EVAL_WPS) void bmpc_k_eval_chain(PipeArgsH H) { k_eval_body<2>(DV(H), blockIdx.x, threadIdx.x, (LDSD*)bmpc_dyn_lds); }
 #ifndef BMPC_EVAL_SPLIT_WGS
-#define BMPC_EVAL_SPLIT_WGS 256       // groups of pairs up to which bmpc_k_eval_curv_split replaces bmpc_k_eval_curv (0 = never)
+// groups of pairs up to which bmpc_k_eval_curv_split replaces bmpc_k_eval_curv (0 = never).  Always: built for the latency of the tail
+// regime (a third of k_eval's arithmetic beside the rest), the two lighter bodies also beat the one-wavefront kernel in the bulk regime
+// (544 - 566 -> 493 - 497 us at 8192 live, bench 124.3 - 125.0 -> 127.4 - 127.9 k solves/s in an ABAB run on one box)
+#define BMPC_EVAL_SPLIT_WGS (1 << 30)
 #endif
 #ifndef BMPC_RIC_NT
 #define BMPC_RIC_NT 128     // lanes cooperating on one instance in the Riccati kernel
@@ -199,6 +205,11 @@ extern "C" hipError_t bmpc_pipe_launch_step(PipeArgsH* A, int n_act, hipStream_t
     if (split_launches) {
         LAUNCH_DYN(bmpc_k_points, nw, 64, pair_lds_doubles(A->N, false));
         LAUNCH_DYN(bmpc_k_pose, nw, 64, pair_lds_doubles(A->N, false));
+        static const int eval_split_wgs_s = [] { const char* e = getenv("BMPC_EVAL_SPLIT_WGS"); return e ? atoi(e) : BMPC_EVAL_SPLIT_WGS; }();
+        if (nw <= eval_split_wgs_s) {
+            LAUNCH_DYN(bmpc_k_eval_main, nw, 64, pair_lds_doubles(A->N, true));
+            LAUNCH_DYN(bmpc_k_eval_chain, nw, 64, pair_lds_doubles(A->N, true));
+        } else
         LAUNCH_DYN(bmpc_k_eval, nw, 64, pair_lds_doubles(A->N, true));
         LAUNCH(bmpc_k_curv, nw, 64);
     } else if (nw > 0) {

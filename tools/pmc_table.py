@@ -10,7 +10,7 @@ NB = 3          # batches in the depth-1 stats run of tools/profile_round.sh (--
 ks = {r[0].split("(")[0]: float(r[2]) / 1e6 / NB for r in list(csv.reader(open(f"{d}/kernel_stats_depth1_merge1.csv")))[1:]}
 tot_flop = 0
 print("kernel            busy_ms  trace_ms  wait  HBM_GB  GFLOP  lds_conf")
-for k in ("bmpc_k_ric", "bmpc_k_ric_lat", "bmpc_k_eval", "bmpc_k_pose", "bmpc_k_step", "bmpc_k_trial", "bmpc_k_points", "bmpc_k_curv", "bmpc_k_fwd"):
+for k in ("bmpc_k_ric", "bmpc_k_ric_att_thr", "bmpc_k_eval_main", "bmpc_k_eval_chain", "bmpc_k_eval", "bmpc_k_pose", "bmpc_k_step", "bmpc_k_trial", "bmpc_k_trial_spec", "bmpc_k_points", "bmpc_k_curv", "bmpc_k_fwd"):
     a = acc[k]
     busy = a.get("GRBM_GUI_ACTIVE", 0) / 8 / 2.4e9 * 1e3
     wait = a.get("SQ_WAIT_ANY", 0) / max(1, a.get("SQ_WAVE_CYCLES", 1))

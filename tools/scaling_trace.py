@@ -35,6 +35,8 @@ def parse(path):
     solves, cur = [], []
     for r in rows:
         name = r["Kernel_Name"].split("(")[0]
+        if name == "bmpc_k_eval_curv_split": name = "bmpc_k_eval_curv"      # (the two-wavefront k_eval beside k_curv: same column)
+        if name == "bmpc_k_trial_spec": name = "bmpc_k_trial"
         if name == "bmpc_k_init_inst" and cur:
             solves.append(cur); cur = []
         cur.append((name, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
